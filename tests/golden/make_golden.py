@@ -1,0 +1,325 @@
+"""Generate the golden fixtures by running the REAL reference on the CPU.
+
+Runs only in the build container (``/root/reference`` is not shipped to the GPU
+box):  ``python tests/golden/make_golden.py``  ->  ``tests/golden/*.npz``.
+
+Only data (inputs, expected outputs, seeds) is written; no reference source is
+copied.  Weights come from ``oracle.nets.deterministic_state`` and are loaded
+into the reference modules with ``load_state_dict`` so fixtures stay small.
+"""
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference"
+sys.dont_write_bytecode = True
+sys.path.insert(0, REPO)
+sys.path.insert(1, REF)
+sys.path.insert(2, HERE)
+
+# netCDF4 is only used by the reference's download code (download_data.py:14-15)
+_nc = types.ModuleType("netCDF4")
+_nc.Dataset = object
+_nc.MFDataset = object
+sys.modules.setdefault("netCDF4", _nc)
+
+from oracle import nets as onets  # noqa: E402
+from oracle.gan import synthetic_batch  # noqa: E402
+
+from CNN_models import torch_blocks as ref_blocks  # noqa: E402
+from CNN_models.Discriminator_3D import Discriminator_3D as RefD  # noqa: E402
+from CNN_models.Generator_3D_Resnet_ESRGAN import Generator_3D as RefG  # noqa: E402
+from GAN_models import wind_field_GAN_3D as ref_gan  # noqa: E402
+from config.config import Config as RefConfig  # noqa: E402
+import process_data as ref_pd  # noqa: E402
+import tools.trainingtricks as ref_tricks  # noqa: E402
+
+torch.set_num_threads(8)
+
+
+def np_(t):
+    return t.detach().cpu().numpy()
+
+
+def save(name, **arrays):
+    path = os.path.join(HERE, name)
+    np.savez_compressed(path, **arrays)
+    print(f"wrote {name}: {os.path.getsize(path) / 1024:.1f} KiB")
+
+
+# --------------------------------------------------------------------------- #
+# 1. per-op conv cases (every (k, stride, pad, bias, act) combination on the path)
+# --------------------------------------------------------------------------- #
+from cases import CONV_CASES  # noqa: E402
+
+
+def gen_conv_cases():
+    out = {}
+    for idx, (name, cin, cout, k, s, p, bias, act, xyz, B) in enumerate(CONV_CASES):
+        g = torch.Generator().manual_seed(1000 + idx)
+        if bias:
+            m = torch.nn.Conv3d(cin, cout, k, s, p)
+            layers = [m] + ([torch.nn.LeakyReLU(0.2)] if act else [])
+            mod = torch.nn.Sequential(*layers)
+        else:
+            mod = ref_blocks.create_conv_lrelu_layer(cin, cout, k, stride=s, padding=p, lrelu=act)
+            m = mod[0]
+        with torch.no_grad():
+            m.weight.copy_(torch.randn(m.weight.shape, generator=g) * (2.0 / (cin * k[0] * k[1] * k[2])) ** 0.5)
+            if bias:
+                m.bias.copy_(torch.randn(m.bias.shape, generator=g) * 0.1)
+        x = torch.randn((B, cin) + xyz, generator=g, requires_grad=True)
+        y = mod(x)
+        gy = torch.randn(y.shape, generator=g)
+        (y * gy).sum().backward()
+        out[f"{name}.x"] = np_(x)
+        out[f"{name}.w"] = np_(m.weight)
+        if bias:
+            out[f"{name}.b"] = np_(m.bias)
+            out[f"{name}.db"] = np_(m.bias.grad)
+        out[f"{name}.y"] = np_(y)
+        out[f"{name}.gy"] = np_(gy)
+        out[f"{name}.dx"] = np_(x.grad)
+        out[f"{name}.dw"] = np_(m.weight.grad)
+    save("conv_cases.npz", **out)
+
+
+# --------------------------------------------------------------------------- #
+# 2. blocks: RDB, RRDB, UpConv, discriminator block (reference helpers)
+# --------------------------------------------------------------------------- #
+def gen_blocks():
+    out = {}
+    g = torch.Generator().manual_seed(77)
+    rrdb = ref_blocks.RRDB(16, 8, 5, lff_kern_size=1, mode="3D")
+    with torch.no_grad():
+        for p in rrdb.parameters():
+            p.copy_(torch.randn(p.shape, generator=g) * (0.3 if p.dim() > 1 else 0.05))
+    x = torch.randn((2, 16, 5, 4, 6), generator=g, requires_grad=True)
+    y = rrdb(x)
+    gy = torch.randn(y.shape, generator=g)
+    (y * gy).sum().backward()
+    out["rrdb.x"], out["rrdb.y"], out["rrdb.gy"], out["rrdb.dx"] = np_(x), np_(y), np_(gy), np_(x.grad)
+    for k, v in rrdb.state_dict().items():
+        out[f"rrdb.sd.{k}"] = np_(v)
+    for k, v in rrdb.named_parameters():
+        out[f"rrdb.grad.{k}"] = np_(v.grad)
+
+    up = ref_blocks.create_UpConv_block(8, 8, scale=2, mode="3D")
+    with torch.no_grad():
+        up[1][0].weight.copy_(torch.randn(up[1][0].weight.shape, generator=g) * 0.1)
+    x = torch.randn((2, 8, 3, 4, 5), generator=g, requires_grad=True)
+    y = up(x)
+    gy = torch.randn(y.shape, generator=g)
+    (y * gy).sum().backward()
+    out["up.x"], out["up.w"], out["up.y"], out["up.gy"] = np_(x), np_(up[1][0].weight), np_(y), np_(gy)
+    out["up.dx"], out["up.dw"] = np_(x.grad), np_(up[1][0].weight.grad)
+    save("blocks.npz", **out)
+
+
+# --------------------------------------------------------------------------- #
+# 3. reduced-size Generator / Discriminator (outputs + all parameter grads)
+# --------------------------------------------------------------------------- #
+G_SMALL = dict(in_channels=4, out_channels=3, nf=16, n_rrdb=2, hr_kern=5, gc=8, tf=8)
+
+
+def build_ref_G(spec: onets.GSpec):
+    G = RefG(spec.in_channels, spec.out_channels, spec.nf, spec.n_rrdb, upscale=spec.upscale,
+             hr_kern_size=spec.hr_kern, number_of_RDB_convs=spec.n_rdb_convs, RDB_gc=spec.gc,
+             lff_kern_size=spec.lff_kern, RDB_residual_scaling=spec.rdb_scale,
+             RRDB_residual_scaling=spec.rrdb_scale, terrain_number_of_features=spec.tf,
+             dropout_probability=spec.dropout_p)
+    return G
+
+
+def build_ref_D(spec: onets.DSpec):
+    return RefD(spec.in_channels, spec.bf, feat_kern_size=spec.feat_kern, number_of_z_layers=spec.nz,
+                enable_slicing=spec.enable_slicing, dropout_probability=spec.dropout_p)
+
+
+def gen_generators():
+    for scale, n, nz in ((4, 6, 5), (8, 4, 4)):
+        spec = onets.GSpec(upscale=scale, **G_SMALL)
+        G = build_ref_G(spec)
+        shapes = onets.g_param_shapes(spec)
+        ref_shapes = {k: tuple(v.shape) for k, v in G.state_dict().items()}
+        assert list(ref_shapes.items()) == list(shapes.items()), "G key/shape manifest mismatch"
+        sd = onets.deterministic_state(shapes, seed=11 + scale, scale=0.7)
+        G.load_state_dict(sd)
+        G.eval()
+        LR, HR, Z, x, y = synthetic_batch(2, n, nz, scale, seed=5 + scale)
+        out = G(LR, Z)
+        g = torch.Generator().manual_seed(99)
+        gy = torch.randn(out.shape, generator=g)
+        (out * gy).sum().backward()
+        arrays = {"out": np_(out), "gy": np_(gy)}
+        for k, p in G.named_parameters():
+            arrays[f"grad.{k}"] = np_(p.grad)
+        save(f"g_small_s{scale}.npz", **arrays)
+
+
+def gen_discriminators():
+    for slicing, xy, nz in ((True, 64, 4), (False, 128, 3), (False, 128, 21)):
+        spec = onets.DSpec(bf=4, nz=nz, enable_slicing=slicing)
+        D = build_ref_D(spec)
+        shapes = onets.d_param_shapes(spec)
+        ref_shapes = {k: tuple(v.shape) for k, v in D.state_dict().items()}
+        assert list(ref_shapes.items()) == list(shapes.items()), "D key/shape manifest mismatch"
+        sd = onets.deterministic_state(shapes, seed=31 + nz, scale=1.0)
+        D.load_state_dict(sd)
+        g = torch.Generator().manual_seed(7)
+        x = torch.rand((2, 3, xy, xy, nz), generator=g) * 2 - 1
+        x.requires_grad_(True)
+        arrays = {"x_seed": np.array(7)}  # x = rand(generator seed 7) * 2 - 1, regenerated by the tests
+        D.eval()
+        arrays["out_eval"] = np_(D(x))
+        D.train()
+        out = D(x)
+        gy = torch.tensor([[1.0], [-0.5]])
+        (out * gy).sum().backward()
+        arrays["out_train"] = np_(out)
+        arrays["dx_sub"] = np_(x.grad[:, :, ::4, ::4, :])
+        arrays["dx_abs_sum"] = np.array(float(x.grad.double().abs().sum()))
+        for k, p in D.named_parameters():
+            arrays[f"grad.{k}"] = np_(p.grad)
+        for k, v in D.state_dict().items():
+            if "running_" in k or "num_batches" in k:
+                arrays[f"after.{k}"] = np_(v)
+        tag = ("slice" if slicing else "full") + f"_z{nz}"
+        save(f"d_small_{tag}.npz", **arrays)
+
+
+# --------------------------------------------------------------------------- #
+# 4. physics operators / metrics / tricks
+# --------------------------------------------------------------------------- #
+def gen_physics():
+    LR, HR, Z, x, y = synthetic_batch(2, 5, 6, 4, seed=3)
+    g = torch.Generator().manual_seed(17)
+    SR = HR + 0.1 * torch.randn(HR.shape, generator=g)
+    x = x + torch.rand(x.shape, generator=g) * 30.0  # exercise the non-uniform branch too
+    grad_hr = ref_pd.calculate_gradient_of_wind_field(HR[:, :3], x, y, Z)
+    grad_sr = ref_pd.calculate_gradient_of_wind_field(SR[:, :3], x, y, Z)
+    norms = ref_gan.get_norm_factors_of_gradients(grad_hr, grad_sr)
+    psnr = ref_gan.calculate_PSNR(HR, SR)
+    psnr_sr, psnr_tri = ref_gan.compute_PSNR_for_SR_and_trilinear(
+        LR, HR, SR, torch.tensor(4.0), torch.tensor(1e-8), interpolate=True, scale=4)
+    torch.manual_seed(123)
+    noise = ref_tricks.instance_noise(torch.tensor(2.0), HR.shape, torch.tensor(7), torch.tensor(100))
+    torch.manual_seed(124)
+    labels = ref_tricks.noisy_labels(True, 6, true_label_val=torch.tensor(0.93), false_label_val=torch.tensor(0.0))
+    save("physics.npz", HR=np_(HR), SR=np_(SR), LR=np_(LR), Z=np_(Z), x=np_(x), y=np_(y),
+         grad_hr=np_(grad_hr), grad_sr=np_(grad_sr), norms=np.array([float(v) for v in norms]),
+         psnr=np.array(float(psnr)), psnr_sr=np.array(float(psnr_sr)), psnr_tri=np.array(float(psnr_tri)),
+         noise=np_(noise), labels=np_(labels))
+
+
+# --------------------------------------------------------------------------- #
+# 5. train-step traces from the real wind_field_GAN_3D
+# --------------------------------------------------------------------------- #
+def reduced_cfg(use_noise: bool, dropout: float, period: int = 2):
+    cfg = RefConfig(os.path.join(REF, "config", "wind_field_GAN_3D_config_local.ini"))
+    cfg.is_train, cfg.is_test, cfg.is_use = True, False, False
+    cfg.gpu_id = None
+    cfg.device = torch.device("cpu")
+    cfg.generator.num_features = 16
+    cfg.generator.num_RRDB = 1
+    cfg.generator.RDB_growth_chan = 8
+    cfg.generator.terrain_number_of_features = 4
+    cfg.generator.dropout_probability = dropout
+    cfg.discriminator.num_features = 4
+    cfg.discriminator.dropout_probability = dropout
+    cfg.gan_config.number_of_z_layers = 4
+    cfg.training.use_instance_noise = use_noise
+    cfg.training.niter = 150000
+    cfg.training.d_g_train_period = period
+    return cfg
+
+
+def specs_from_cfg(cfg):
+    gs = onets.GSpec(in_channels=4, nf=cfg.generator.num_features, n_rrdb=cfg.generator.num_RRDB,
+                     gc=cfg.generator.RDB_growth_chan, tf=cfg.generator.terrain_number_of_features,
+                     hr_kern=cfg.generator.hr_kern_size, upscale=cfg.scale,
+                     dropout_p=cfg.generator.dropout_probability)
+    ds = onets.DSpec(bf=cfg.discriminator.num_features, nz=cfg.gan_config.number_of_z_layers,
+                     enable_slicing=cfg.gan_config.enable_slicing,
+                     dropout_p=cfg.discriminator.dropout_probability)
+    return gs, ds
+
+
+def gen_trace(tag: str, use_noise: bool, dropout: float, its):
+    cfg = reduced_cfg(use_noise, dropout)
+    torch.manual_seed(2001)
+    gan = ref_gan.wind_field_GAN_3D(cfg)
+    gs, ds = specs_from_cfg(cfg)
+    gan.G.load_state_dict(onets.deterministic_state(onets.g_param_shapes(gs), seed=41, scale=0.5))
+    gan.D.load_state_dict(onets.deterministic_state(onets.d_param_shapes(ds), seed=43, scale=1.0))
+    LR, HR, Z, x, y = synthetic_batch(2, 16, 4, 4, seed=2001)
+    gan.feed_xy_niter(x, y, torch.tensor(cfg.training.niter), cfg.training.d_g_train_ratio,
+                      cfg.training.d_g_train_period)
+    torch.manual_seed(4242)  # RNG state at the first optimize_parameters call
+    keys = ["total", "adversarial", "pix", "xy_gradient", "z_gradient", "divergence", "xy_divergence", "feature_D"]
+    rows, kinds, dloss, wsum_g, wsum_d, lrs = [], [], [], [], [], []
+    for it in its:
+        gan.optimize_parameters(LR, HR, Z, it)
+        if it > 2 * cfg.training.d_g_train_period:
+            gan.update_learning_rate()
+        is_g = (it // cfg.training.d_g_train_period) % (cfg.training.d_g_train_ratio + 1) == 0
+        kinds.append(1 if is_g else 0)
+        rows.append([float(gan.get_G_train_loss_dict_ref()[k]) for k in keys])
+        dloss.append(float(gan.get_D_loss_dict_ref()["train_loss"]))
+        wsum_g.append([float(gan.G.state_dict()[k].double().abs().sum())
+                       for k in ("model.0.0.weight", "hr_convs.2.weight", "model.1.module.0.RDBs.1.LFF.bias")])
+        wsum_d.append([float(gan.D.state_dict()[k].double().abs().sum())
+                       for k in ("features.0.0.0.weight", "classifier.2.weight", "features.1.1.1.running_var")])
+        lrs.append(gan.optimizer_G.param_groups[0]["lr"])
+    final_G = {f"final_G.{k}": np_(v) for k, v in gan.G.state_dict().items()
+               if k in ("model.0.0.weight", "hr_convs.2.weight", "hr_convs.2.bias")}
+    final_D = {f"final_D.{k}": np_(v) for k, v in gan.D.state_dict().items()
+               if k in ("features.0.0.0.weight", "classifier.2.weight", "features.4.1.running_mean")}
+    save(f"gan_trace_{tag}.npz", its=np.array(list(its)), kinds=np.array(kinds), G_losses=np.array(rows),
+         D_loss=np.array(dloss), wsum_g=np.array(wsum_g), wsum_d=np.array(wsum_d), lr=np.array(lrs),
+         use_noise=np.array(use_noise), dropout=np.array(dropout), **final_G, **final_D)
+
+
+def gen_init_manifest():
+    """Seeded-init checksums of the full-size nets (RNG-order parity of init_weights)."""
+    cfg = RefConfig(os.path.join(REF, "config", "wind_field_GAN_3D_config_local.ini"))
+    cfg.is_train, cfg.is_test, cfg.is_use = True, False, False
+    cfg.gpu_id = None
+    cfg.device = torch.device("cpu")
+    torch.manual_seed(2001)
+    gan = ref_gan.wind_field_GAN_3D(cfg)
+    arrays = {}
+    for net, tag in ((gan.G, "G"), (gan.D, "D")):
+        sd = net.state_dict()
+        arrays[f"{tag}.keys"] = np.array(list(sd.keys()))
+        arrays[f"{tag}.shapes"] = np.array([str(tuple(v.shape)) for v in sd.values()])
+        arrays[f"{tag}.abs_sum"] = np.array([float(v.double().abs().sum()) for v in sd.values()])
+        arrays[f"{tag}.first"] = np.array([float(v.reshape(-1)[0]) if v.numel() else 0.0 for v in sd.values()])
+    arrays["G.n_params"] = np.array(sum(p.numel() for p in gan.G.parameters()))
+    arrays["D.n_params"] = np.array(sum(p.numel() for p in gan.D.parameters()))
+    arrays["str_cfg_head"] = np.array(str(cfg)[:4000])
+    save("init_manifest.npz", **arrays)
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["conv", "blocks", "G", "D", "physics", "trace", "init"]
+    if "conv" in which:
+        gen_conv_cases()
+    if "blocks" in which:
+        gen_blocks()
+    if "G" in which:
+        gen_generators()
+    if "D" in which:
+        gen_discriminators()
+    if "physics" in which:
+        gen_physics()
+    if "trace" in which:
+        gen_trace("plain", use_noise=False, dropout=0.0, its=[1, 2, 3, 4, 5, 6])
+        gen_trace("noise", use_noise=True, dropout=0.1, its=[1, 2, 3, 4, 5])
+    if "init" in which:
+        gen_init_manifest()

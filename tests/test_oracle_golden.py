@@ -1,0 +1,178 @@
+"""Pin the CPU oracle against fixtures produced by the real reference.
+
+(-m "not gpu".)  Tolerances: fp32 CPU vs fp32 CPU of the same arithmetic in a
+different association order -> rel-L2 <= 2e-5 on outputs, 2e-4 on gradients.
+"""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import rel_l2
+from oracle import gan as ogan
+from oracle import nets as onets
+from oracle import physics as ophys
+
+T = torch.from_numpy
+
+
+def test_conv_cases_match_functional_conv(golden):
+    """The per-op conv fixtures are plain conv3d(+bias)(+LReLU 0.2) with grads."""
+    g = golden("conv_cases.npz")
+    names = sorted({k.split(".")[0] for k in g.files})
+    assert len(names) == 11
+    from golden.cases import CONV_CASES
+
+    for (name, cin, cout, k, s, p, bias, act, xyz, B) in CONV_CASES:
+        x = T(g[f"{name}.x"]).requires_grad_(True)
+        w = T(g[f"{name}.w"]).requires_grad_(True)
+        b = T(g[f"{name}.b"]).requires_grad_(True) if bias else None
+        y = F.conv3d(x, w, b, s, p)
+        if act:
+            y = F.leaky_relu(y, 0.2)
+        assert rel_l2(y, T(g[f"{name}.y"])) < 2e-6, name
+        (y * T(g[f"{name}.gy"])).sum().backward()
+        assert rel_l2(x.grad, T(g[f"{name}.dx"])) < 2e-6, name
+        assert rel_l2(w.grad, T(g[f"{name}.dw"])) < 2e-6, name
+        if bias:
+            assert rel_l2(b.grad, T(g[f"{name}.db"])) < 2e-6, name
+
+
+def test_rrdb_and_upconv(golden):
+    g = golden("blocks.npz")
+    s = onets.GSpec(nf=16, gc=8)
+    sd = {k[len("rrdb.sd."):]: T(g[k]).requires_grad_(True) for k in g.files if k.startswith("rrdb.sd.")}
+    x = T(g["rrdb.x"]).requires_grad_(True)
+    y = onets.rrdb_forward({("x." + k): v for k, v in sd.items()}, "x", x, s)
+    assert rel_l2(y, T(g["rrdb.y"])) < 2e-6
+    (y * T(g["rrdb.gy"])).sum().backward()
+    assert rel_l2(x.grad, T(g["rrdb.dx"])) < 2e-5
+    for k, v in sd.items():
+        assert rel_l2(v.grad, T(g[f"rrdb.grad.{k}"])) < 2e-5, k
+    # UpConv: nearest x(2,2,1) -> conv k3 -> LReLU (torch_blocks.py:345-356)
+    x = T(g["up.x"]).requires_grad_(True)
+    w = T(g["up.w"]).requires_grad_(True)
+    y = F.leaky_relu(F.conv3d(F.interpolate(x, scale_factor=(2, 2, 1), mode="nearest"), w, None, 1, 1), 0.2)
+    assert rel_l2(y, T(g["up.y"])) < 2e-6
+    (y * T(g["up.gy"])).sum().backward()
+    assert rel_l2(x.grad, T(g["up.dx"])) < 2e-6
+    assert rel_l2(w.grad, T(g["up.dw"])) < 2e-6
+
+
+@pytest.mark.parametrize("scale,n,nz", [(4, 6, 5), (8, 4, 4)])
+def test_generator_small(golden, scale, n, nz):
+    g = golden(f"g_small_s{scale}.npz")
+    spec = onets.GSpec(upscale=scale, in_channels=4, out_channels=3, nf=16, n_rrdb=2, hr_kern=5, gc=8, tf=8)
+    sd = onets.deterministic_state(onets.g_param_shapes(spec), seed=11 + scale, scale=0.7)
+    for v in sd.values():
+        v.requires_grad_(True)
+    LR, HR, Z, x, y = ogan.synthetic_batch(2, n, nz, scale, seed=5 + scale)
+    out = onets.generator_forward(sd, LR, Z, spec)
+    assert out.shape == (2, 3, scale * n, scale * n, nz)
+    assert rel_l2(out, T(g["out"])) < 2e-5
+    (out * T(g["gy"])).sum().backward()
+    for k, v in sd.items():
+        assert rel_l2(v.grad, T(g[f"grad.{k}"])) < 2e-4, k
+
+
+@pytest.mark.parametrize("slicing,xy,nz", [(True, 64, 4), (False, 128, 3), (False, 128, 21)])
+def test_discriminator_small(golden, slicing, xy, nz):
+    tag = ("slice" if slicing else "full") + f"_z{nz}"
+    g = golden(f"d_small_{tag}.npz")
+    spec = onets.DSpec(bf=4, nz=nz, enable_slicing=slicing)
+    sd = onets.deterministic_state(onets.d_param_shapes(spec), seed=31 + nz, scale=1.0)
+    params = [v for k, v in sd.items() if v.is_floating_point() and "running_" not in k]
+    for p in params:
+        p.requires_grad_(True)
+    gen = torch.Generator().manual_seed(int(g["x_seed"]))
+    x = (torch.rand((2, 3, xy, xy, nz), generator=gen) * 2 - 1).requires_grad_(True)
+    out_eval = onets.discriminator_forward(sd, x, spec, training=False)
+    assert rel_l2(out_eval, T(g["out_eval"])) < 2e-5
+    out = onets.discriminator_forward(sd, x, spec, training=True)
+    assert rel_l2(out, T(g["out_train"])) < 2e-5
+    (out * torch.tensor([[1.0], [-0.5]])).sum().backward()
+    assert rel_l2(x.grad[:, :, ::4, ::4, :], T(g["dx_sub"])) < 2e-4
+    assert abs(float(x.grad.double().abs().sum()) / float(g["dx_abs_sum"]) - 1) < 1e-4
+    for k, v in sd.items():
+        if v.requires_grad:
+            assert rel_l2(v.grad, T(g[f"grad.{k}"])) < 3e-4, k
+        elif "running_" in k or "num_batches" in k:
+            assert rel_l2(v.float(), T(g[f"after.{k}"]).float()) < 1e-5, k
+
+
+def test_physics_ops(golden):
+    g = golden("physics.npz")
+    HR, SR, LR, Z, x, y = (T(g[k]) for k in ("HR", "SR", "LR", "Z", "x", "y"))
+    gh = ophys.wind_gradient(HR[:, :3], x, y, Z)
+    gs = ophys.wind_gradient(SR[:, :3], x, y, Z)
+    assert rel_l2(gh, T(g["grad_hr"])) < 1e-5
+    assert rel_l2(gs, T(g["grad_sr"])) < 1e-5
+    # the hand-written d/dx equals torch.gradient with coordinate spacing
+    tg = torch.gradient(HR[:, :3], dim=(2, 3), spacing=(x, y))
+    assert rel_l2(ophys.ddcoord(HR[:, :3], x, 2), tg[0]) < 1e-6
+    norms = ophys.gradient_norm_factors(gh, gs)
+    np.testing.assert_allclose([float(v) for v in norms], g["norms"], rtol=1e-5)
+    assert abs(float(ophys.psnr(HR, SR)) - float(g["psnr"])) < 1e-4
+    assert abs(float(ophys.psnr(HR, ophys.trilinear_baseline(LR, 4))) - float(g["psnr_tri"])) < 1e-4
+    torch.manual_seed(123)
+    noise = ogan.instance_noise(2.0, HR.shape, torch.tensor(7), torch.tensor(100))
+    assert rel_l2(noise, T(g["noise"])) < 1e-6
+    torch.manual_seed(124)
+    lab = ogan.noisy_labels(True, 6, 0.05, torch.tensor(0.0), torch.tensor(0.93))
+    assert rel_l2(lab, T(g["labels"])) < 1e-6
+
+
+def _replay_trace(g, use_noise, dropout):
+    gs = onets.GSpec(in_channels=4, nf=16, n_rrdb=1, gc=8, tf=4, hr_kern=5, upscale=4, dropout_p=dropout)
+    ds = onets.DSpec(bf=4, nz=4, enable_slicing=True, dropout_p=dropout)
+    ts = ogan.TrainSpec(use_instance_noise=use_noise, d_g_train_period=2, niter=150000)
+    sdG = onets.deterministic_state(onets.g_param_shapes(gs), seed=41, scale=0.5)
+    sdD = onets.deterministic_state(onets.d_param_shapes(ds), seed=43, scale=1.0)
+    gan = ogan.OracleGAN(sdG, sdD, gs, ds, ts)
+    LR, HR, Z, x, y = ogan.synthetic_batch(2, 16, 4, 4, seed=2001)
+    gan.feed_xy(x, y)
+    torch.manual_seed(4242)
+    keys = ["total", "adversarial", "pix", "xy_gradient", "z_gradient", "divergence", "xy_divergence", "feature_D"]
+    for row, it in enumerate(g["its"]):
+        kind = gan.optimize_parameters(LR, HR, Z, int(it))
+        if int(it) > 2 * ts.d_g_train_period:
+            gan.update_learning_rate()
+        assert (kind == "G") == bool(g["kinds"][row])
+        if kind == "G":
+            got = [float(gan.G_losses[k]) for k in keys]
+            np.testing.assert_allclose(got, g["G_losses"][row], rtol=2e-4, atol=1e-7, err_msg=f"it={it}")
+        else:
+            np.testing.assert_allclose(float(gan.D_loss), g["D_loss"][row], rtol=2e-4, atol=1e-6, err_msg=f"it={it}")
+        wg = [float(sdG[k].detach().double().abs().sum())
+              for k in ("model.0.0.weight", "hr_convs.2.weight", "model.1.module.0.RDBs.1.LFF.bias")]
+        wd = [float(sdD[k].detach().double().abs().sum())
+              for k in ("features.0.0.0.weight", "classifier.2.weight", "features.1.1.1.running_var")]
+        np.testing.assert_allclose(wg, g["wsum_g"][row], rtol=1e-5, err_msg=f"it={it}")
+        np.testing.assert_allclose(wd, g["wsum_d"][row], rtol=1e-5, err_msg=f"it={it}")
+        assert abs(gan.opt_G.param_groups[0]["lr"] - g["lr"][row]) < 1e-12
+    for k in g.files:
+        if k.startswith("final_G."):
+            assert rel_l2(sdG[k[8:]], T(g[k])) < 1e-4, k
+        if k.startswith("final_D."):
+            assert rel_l2(sdD[k[8:]], T(g[k])) < 1e-4, k
+
+
+def test_gan_trace_plain(golden):
+    """G/D alternation, losses, Adam updates over 6 iterations incl. two switches."""
+    _replay_trace(golden("gan_trace_plain.npz"), use_noise=False, dropout=0.0)
+
+
+def test_gan_trace_noise_dropout(golden):
+    """Same with uniform instance noise + Dropout3d: pins the RNG call order."""
+    _replay_trace(golden("gan_trace_noise.npz"), use_noise=True, dropout=0.1)
+
+
+def test_state_dict_manifest_full_size(golden):
+    """Key names/shapes of the full-size nets (the checkpoint drop-in boundary)."""
+    g = golden("init_manifest.npz")
+    gs = onets.GSpec()
+    ds = onets.DSpec(bf=32, nz=10, enable_slicing=True)
+    for tag, shapes in (("G", onets.g_param_shapes(gs)), ("D", onets.d_param_shapes(ds))):
+        assert list(shapes.keys()) == [str(k) for k in g[f"{tag}.keys"]]
+        assert [str(tuple(v)) for v in shapes.values()] == [str(s) for s in g[f"{tag}.shapes"]]
+    assert sum(int(np.prod(v)) for v in onets.g_param_shapes(gs).values()) == int(g["G.n_params"]) == 34769571
