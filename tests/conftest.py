@@ -10,6 +10,8 @@ if REPO not in sys.path:
     sys.path.insert(0, REPO)
 
 GOLDEN = os.path.join(REPO, "tests", "golden")
+if GOLDEN not in sys.path:
+    sys.path.insert(1, GOLDEN)
 
 
 def pytest_configure(config):

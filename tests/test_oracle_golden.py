@@ -21,7 +21,7 @@ def test_conv_cases_match_functional_conv(golden):
     g = golden("conv_cases.npz")
     names = sorted({k.split(".")[0] for k in g.files})
     assert len(names) == 11
-    from golden.cases import CONV_CASES
+    from cases import CONV_CASES
 
     for (name, cin, cout, k, s, p, bias, act, xyz, B) in CONV_CASES:
         x = T(g[f"{name}.x"]).requires_grad_(True)
