@@ -1,0 +1,95 @@
+"""ctypes binding of the C-ABI in ``include/windsr_hip.h`` (libwindsr_hip.so).
+
+There is deliberately NO fallback: if the gfx950 library is missing or a call
+fails, a ``RuntimeError`` is raised.  The product path never routes through the
+CPU oracle or through ATen/MIOpen convolutions.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libwindsr_hip.so")
+
+WSR_F32, WSR_BF16 = 0, 1
+
+EXPORTS = [
+    "wsr_abi_version", "wsr_error_string", "wsr_conv3d_fwd", "wsr_conv3d_dgrad", "wsr_conv3d_wgrad",
+    "wsr_pack_filter", "wsr_unpack_wgrad", "wsr_lrelu_bwd_inplace", "wsr_chan_axpby", "wsr_upsample2_bwd",
+    "wsr_planar_to_ndhwc", "wsr_ndhwc_to_planar", "wsr_bn_stats", "wsr_bn_apply_lrelu", "wsr_bn_bwd_reduce",
+    "wsr_bn_bwd_apply", "wsr_adam_step",
+]
+
+
+class ConvDesc(C.Structure):
+    """``wsr_conv_t``."""
+
+    _fields_ = [(n, C.c_int32) for n in (
+        "dtype", "B", "Xi", "Yi", "Zi", "Xo", "Yo", "Zo", "Cin", "in_ctot", "in_off", "Cout", "out_ctot",
+        "out_off", "KX", "KY", "KZ", "sx", "sy", "sz", "px", "py", "pz", "upsample_xy")]
+
+
+class Epilogue(C.Structure):
+    """``wsr_epilogue_t``."""
+
+    _fields_ = [
+        ("bias", C.c_void_p), ("chan_scale", C.c_void_p), ("res", C.c_void_p),
+        ("res_ctot", C.c_int32), ("res_off", C.c_int32), ("alpha", C.c_float), ("beta", C.c_float),
+        ("act", C.c_int32), ("slope", C.c_float), ("out_planar", C.c_int32),
+    ]
+
+
+_lib: Optional[C.CDLL] = None
+
+
+def lib() -> C.CDLL:
+    """Load (once) and return the library; raise loudly when it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} not found: build the gfx950 kernels first "
+            "(python -c 'import __graft_entry__ as g; g.build()' or make -C gan_sr_wind_field_amd/csrc). "
+            "There is no CPU / ATen fallback for the hot path.")
+    L = C.CDLL(LIB_PATH)
+    for name in EXPORTS:
+        if not hasattr(L, name):
+            raise RuntimeError(f"{LIB_PATH} does not export {name}")
+    vp, i32, i64, f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
+    L.wsr_abi_version.restype = C.c_int
+    L.wsr_error_string.restype = C.c_char_p
+    L.wsr_error_string.argtypes = [C.c_int]
+    sig = {
+        "wsr_conv3d_fwd": [C.POINTER(ConvDesc), vp, vp, vp, C.POINTER(Epilogue), vp],
+        "wsr_conv3d_dgrad": [C.POINTER(ConvDesc), vp, vp, vp, C.c_int, C.c_int, vp],
+        "wsr_conv3d_wgrad": [C.POINTER(ConvDesc), vp, vp, vp, vp],
+        "wsr_pack_filter": [vp, vp, i32, i32, i32, i32, i32, i32, vp],
+        "wsr_unpack_wgrad": [vp, vp, i32, i32, i32, i32, f32, vp],
+        "wsr_lrelu_bwd_inplace": [vp, i32, i32, vp, i32, i32, i32, i64, f32, i32, vp],
+        "wsr_chan_axpby": [vp, i32, i32, vp, i32, i32, i32, i64, f32, f32, i32, vp],
+        "wsr_upsample2_bwd": [vp, vp, i32, i32, i32, i32, i32, i32, vp],
+        "wsr_planar_to_ndhwc": [vp, vp, i32, i32, i64, i32, i32, i32, i32, vp],
+        "wsr_ndhwc_to_planar": [vp, vp, i32, i32, i64, i32, i32, i32, vp],
+        "wsr_bn_stats": [vp, i32, i64, vp, i32, vp],
+        "wsr_bn_apply_lrelu": [vp, vp, vp, vp, vp, vp, i32, i64, i32, f32, i32, vp],
+        "wsr_bn_bwd_reduce": [vp, vp, vp, vp, vp, i32, i64, i32, f32, vp, i32, vp],
+        "wsr_bn_bwd_apply": [vp, vp, vp, vp, vp, vp, vp, f32, i32, i64, i32, vp],
+        "wsr_adam_step": [vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, i32, vp],
+    }
+    for name, argtypes in sig.items():
+        fn = getattr(L, name)
+        fn.argtypes = argtypes
+        fn.restype = C.c_int
+    if L.wsr_abi_version() != 1:
+        raise RuntimeError("libwindsr_hip.so ABI version mismatch")
+    _lib = L
+    return L
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != 0:
+        msg = lib().wsr_error_string(rc).decode()
+        raise RuntimeError(f"windsr_hip {what} failed: {msg} (code {rc})")

@@ -1,0 +1,448 @@
+// HBM-bound helper kernels around the convolutions: filter packing, LeakyReLU
+// backward, channel-window axpby, nearest-upsample backward, planar<->NDHWC,
+// BatchNorm3d statistics/apply/backward and the flat Adam step.  All are
+// grid-stride, vectorised where the channel window allows it.
+#include "common.h"
+
+namespace {
+
+constexpr int EW_BLOCK = 256;
+static inline int ew_grid(long n) {
+  long g = (n + EW_BLOCK - 1) / EW_BLOCK;
+  if (g > 256 * 8) g = 256 * 8;  // 8 workgroups per CU, grid-stride the rest
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+// ---- filter packing -------------------------------------------------------------
+template <class T>
+__global__ void pack_filter_kernel(const float* __restrict__ w, typename T::elem* __restrict__ out, int Cout, int taps,
+                                   int Cin, int transpose, int kpad) {
+  const int rows = transpose ? Cin : Cout;
+  const long total = (long)rows * taps * kpad;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int k = (int)(i % kpad);
+    const long rt = i / kpad;
+    const int tap = (int)(rt % taps);
+    const int r = (int)(rt / taps);
+    float v = 0.f;  // master is the logical nn.Conv3d layout [Cout][Cin][taps]
+    if (!transpose) {
+      if (k < Cin) v = w[((long)r * Cin + k) * taps + tap];
+    } else {
+      if (k < Cout) v = w[((long)k * Cin + r) * taps + tap];
+    }
+    stf<T>(out + i, v);
+  }
+}
+
+// dst [Cout][Cin][taps] (logical nn.Conv3d layout) += src [Cout][taps][kpad]
+__global__ void unpack_wgrad_kernel(const float* __restrict__ src, float* __restrict__ dst, int Cout, int taps, int Cin,
+                                    int kpad, float scale) {
+  const long total = (long)Cout * Cin * taps;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int tap = (int)(i % taps);
+    const long nc = i / taps;
+    const int c = (int)(nc % Cin);
+    const int n = (int)(nc / Cin);
+    dst[i] += scale * src[((long)n * taps + tap) * kpad + c];
+  }
+}
+
+// ---- channel-window elementwise ---------------------------------------------------
+template <class T>
+__global__ void lrelu_bwd_kernel(typename T::elem* g, int g_ctot, int g_off, const typename T::elem* y, int y_ctot,
+                                 int y_off, int C, long nvox, float slope) {
+  const int c4 = C >> 2;
+  const long total = nvox * c4;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long v = i / c4;
+    const int c = (int)(i % c4) * 4;
+    typename T::elem* gp = g + v * g_ctot + g_off + c;
+    float4 gv = ld4<T>(gp);
+    const float4 yv = ld4<T>(y + v * y_ctot + y_off + c);
+    gv.x *= yv.x > 0.f ? 1.f : slope;
+    gv.y *= yv.y > 0.f ? 1.f : slope;
+    gv.z *= yv.z > 0.f ? 1.f : slope;
+    gv.w *= yv.w > 0.f ? 1.f : slope;
+    st4<T>(gp, gv);
+  }
+}
+
+template <class T>
+__global__ void chan_axpby_kernel(typename T::elem* dst, int d_ctot, int d_off, const typename T::elem* src,
+                                  int s_ctot, int s_off, int C, long nvox, float alpha, float beta) {
+  const int c4 = C >> 2;
+  const long total = nvox * c4;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long v = i / c4;
+    const int c = (int)(i % c4) * 4;
+    typename T::elem* dp = dst + v * d_ctot + d_off + c;
+    float4 s = ld4<T>(src + v * s_ctot + s_off + c);
+    float4 o = make_float4(alpha * s.x, alpha * s.y, alpha * s.z, alpha * s.w);
+    if (beta != 0.f) {
+      const float4 d = ld4<T>(dp);
+      o.x += beta * d.x;
+      o.y += beta * d.y;
+      o.z += beta * d.z;
+      o.w += beta * d.w;
+    }
+    st4<T>(dp, o);
+  }
+}
+
+template <class T>
+__global__ void upsample2_bwd_kernel(const typename T::elem* dy, typename T::elem* dx, int B, int Xi, int Yi, int Zi,
+                                     int C) {
+  const int c4 = C >> 2;
+  const long total = (long)B * Xi * Yi * Zi * c4;
+  const long rowY = (long)Zi * C;        // one y step at the fine resolution
+  const long rowX = (long)(2 * Yi) * rowY;  // one x step at the fine resolution
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % c4) * 4;
+    long v = i / c4;
+    const int z = (int)(v % Zi); v /= Zi;
+    const int y = (int)(v % Yi); v /= Yi;
+    const int x = (int)(v % Xi);
+    const int b = (int)(v / Xi);
+    const typename T::elem* p = dy + (((long)b * 2 * Xi + 2 * x) * 2 * Yi + 2 * y) * rowY + (long)z * C + c;
+    const float4 a0 = ld4<T>(p), a1 = ld4<T>(p + rowY), a2 = ld4<T>(p + rowX), a3 = ld4<T>(p + rowX + rowY);
+    st4<T>(dx + (i / c4) * C + c,
+           make_float4(a0.x + a1.x + a2.x + a3.x, a0.y + a1.y + a2.y + a3.y, a0.z + a1.z + a2.z + a3.z,
+                       a0.w + a1.w + a2.w + a3.w));
+  }
+}
+
+template <class T>
+__global__ void planar_to_ndhwc_kernel(const float* __restrict__ src, typename T::elem* __restrict__ dst, int B, int C,
+                                       long vpb, int d_ctot, int d_off, int cfill) {
+  // writes channels [d_off, d_off + cfill): the first C from src, the rest zero
+  const long total = (long)B * vpb * cfill;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % cfill);
+    const long bv = i / cfill;
+    const long v = bv % vpb;
+    const int b = (int)(bv / vpb);
+    const float x = c < C ? src[((long)b * C + c) * vpb + v] : 0.f;
+    stf<T>(dst + bv * d_ctot + d_off + c, x);
+  }
+}
+
+template <class T>
+__global__ void ndhwc_to_planar_kernel(const typename T::elem* __restrict__ src, float* __restrict__ dst, int B, int C,
+                                       long vpb, int s_ctot, int s_off) {
+  const long total = (long)B * C * vpb;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long v = i % vpb;
+    const long bc = i / vpb;
+    const int c = (int)(bc % C);
+    const int b = (int)(bc / C);
+    dst[i] = ldf<T>(src + ((long)b * vpb + v) * s_ctot + s_off + c);
+  }
+}
+
+// ---- BatchNorm3d ----------------------------------------------------------------------
+// Threads stride over the flat [nvox][C] tensor with a stride that is a multiple
+// of C, so each thread stays on one channel; per-workgroup LDS reduction over the
+// threads sharing a channel, then one float atomic per channel per workgroup.
+template <class T>
+__global__ __launch_bounds__(256) void bn_stats_kernel(const typename T::elem* __restrict__ x, int C, long nvox,
+                                                      float* sums) {
+  __shared__ float s1[256], s2[256];
+  const long total = nvox * C;
+  const long stride = (long)gridDim.x * 256;
+  float a = 0.f, b = 0.f;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += stride) {
+    const float v = ldf<T>(x + i);
+    a += v;
+    b += v * v;
+  }
+  s1[threadIdx.x] = a;
+  s2[threadIdx.x] = b;
+  __syncthreads();
+  if ((int)threadIdx.x < C) {  // C divides 256: threads t, t+C, t+2C.. share channel t
+    for (int j = threadIdx.x + C; j < 256; j += C) {
+      a += s1[j];
+      b += s2[j];
+    }
+    atomicAdd(sums + threadIdx.x, a);
+    atomicAdd(sums + C + threadIdx.x, b);
+  }
+}
+
+template <class T>
+__global__ void bn_apply_kernel(const typename T::elem* __restrict__ x, typename T::elem* __restrict__ y,
+                                const float* mean, const float* invstd, const float* gamma, const float* beta, int C,
+                                long nvox, int act, float slope) {
+  const long total = nvox * C;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C);
+    float v = (ldf<T>(x + i) - mean[c]) * invstd[c] * gamma[c] + beta[c];
+    if (act) v = v > 0.f ? v : v * slope;
+    stf<T>(y + i, v);
+  }
+}
+
+template <class T>
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(typename T::elem* dy, const typename T::elem* __restrict__ y,
+                                                           const typename T::elem* __restrict__ x, const float* mean,
+                                                           const float* invstd, int C, long nvox, int act, float slope,
+                                                           float* sums) {
+  __shared__ float s1[256], s2[256];
+  const long total = nvox * C;
+  const long stride = (long)gridDim.x * 256;
+  const int c = threadIdx.x % C;
+  const float mu = mean[c], is = invstd[c];
+  float a = 0.f, b = 0.f;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += stride) {
+    float g = ldf<T>(dy + i);
+    if (act) {
+      g *= ldf<T>(y + i) > 0.f ? 1.f : slope;
+      stf<T>(dy + i, g);
+    }
+    const float xh = (ldf<T>(x + i) - mu) * is;
+    a += g;
+    b += g * xh;
+  }
+  s1[threadIdx.x] = a;
+  s2[threadIdx.x] = b;
+  __syncthreads();
+  if ((int)threadIdx.x < C) {
+    for (int j = threadIdx.x + C; j < 256; j += C) {
+      a += s1[j];
+      b += s2[j];
+    }
+    atomicAdd(sums + threadIdx.x, a);
+    atomicAdd(sums + C + threadIdx.x, b);
+  }
+}
+
+template <class T>
+__global__ void bn_bwd_apply_kernel(const typename T::elem* __restrict__ g, const typename T::elem* __restrict__ x,
+                                    typename T::elem* dx, const float* mean, const float* invstd, const float* gamma,
+                                    const float* sums, float inv_n, int C, long nvox) {
+  const long total = nvox * C;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C);
+    float v = ldf<T>(g + i);
+    if (sums) {
+      const float xh = (ldf<T>(x + i) - mean[c]) * invstd[c];
+      v = v - sums[c] * inv_n - xh * sums[C + c] * inv_n;
+    }
+    stf<T>(dx + i, v * gamma[c] * invstd[c]);
+  }
+}
+
+// ---- Adam --------------------------------------------------------------------------------
+__global__ void adam_kernel(float* p, const float* __restrict__ g, float* m, float* v, long n, float step_size,
+                            float beta1, float beta2, float eps, float wd, float bc2_sqrt) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    float gi = g[i];
+    const float pi = p[i];
+    if (wd != 0.f) gi += wd * pi;
+    const float mi = beta1 * m[i] + (1.f - beta1) * gi;
+    const float vi = beta2 * v[i] + (1.f - beta2) * gi * gi;
+    m[i] = mi;
+    v[i] = vi;
+    const float denom = sqrtf(vi) / bc2_sqrt + eps;
+    p[i] = pi - step_size * (mi / denom);
+  }
+}
+
+}  // namespace
+
+#define DISPATCH_T(dtype, CALL_BF16, CALL_F32) \
+  do {                                         \
+    if ((dtype) == WSR_BF16) {                 \
+      CALL_BF16;                               \
+    } else if ((dtype) == WSR_F32) {           \
+      CALL_F32;                                \
+    } else {                                   \
+      return WSR_EINVAL;                       \
+    }                                          \
+  } while (0)
+
+extern "C" int wsr_abi_version(void) { return WSR_ABI_VERSION; }
+
+extern "C" const char* wsr_error_string(int code) {
+  switch (code) {
+    case WSR_OK: return "ok";
+    case WSR_EINVAL: return "invalid argument (geometry / null pointer)";
+    case WSR_EUNSUPPORTED: return "shape not supported by the gfx950 kernels";
+    default: return code > 0 ? hipGetErrorString((hipError_t)code) : "unknown error";
+  }
+}
+
+extern "C" int wsr_pack_filter(const float* w, void* out, int32_t dtype, int32_t Cout, int32_t taps, int32_t Cin,
+                               int32_t transpose, int32_t kpad, void* stream) {
+  if (!w || !out || Cout <= 0 || taps <= 0 || Cin <= 0) return WSR_EINVAL;
+  if (kpad < (transpose ? Cout : Cin)) return WSR_EINVAL;
+  const long total = (long)(transpose ? Cin : Cout) * taps * kpad;
+  DISPATCH_T(dtype,
+             hipLaunchKernelGGL(pack_filter_kernel<BF16>, dim3(ew_grid(total)), dim3(EW_BLOCK), 0, as_stream(stream), w,
+                                (unsigned short*)out, Cout, taps, Cin, transpose, kpad),
+             hipLaunchKernelGGL(pack_filter_kernel<F32>, dim3(ew_grid(total)), dim3(EW_BLOCK), 0, as_stream(stream), w,
+                                (float*)out, Cout, taps, Cin, transpose, kpad));
+  WSR_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int wsr_unpack_wgrad(const float* src, float* dst, int32_t Cout, int32_t taps, int32_t Cin, int32_t kpad,
+                                float scale, void* stream) {
+  if (!src || !dst || Cout <= 0 || taps <= 0 || Cin <= 0 || kpad < Cin) return WSR_EINVAL;
+  hipLaunchKernelGGL(unpack_wgrad_kernel, dim3(ew_grid((long)Cout * Cin * taps)), dim3(EW_BLOCK), 0,
+                     as_stream(stream), src, dst, Cout, taps, Cin, kpad, scale);
+  WSR_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int wsr_lrelu_bwd_inplace(void* g, int32_t g_ctot, int32_t g_off, const void* y, int32_t y_ctot,
+                                     int32_t y_off, int32_t C, int64_t nvox, float slope, int32_t dtype, void* stream) {
+  if (!g || !y || C <= 0 || nvox <= 0) return WSR_EINVAL;
+  if ((C | g_ctot | g_off | y_ctot | y_off) & 3) return WSR_EUNSUPPORTED;
+  const long total = nvox * (C >> 2);
+  DISPATCH_T(dtype,
+             hipLaunchKernelGGL(lrelu_bwd_kernel<BF16>, dim3(ew_grid(total)), dim3(EW_BLOCK), 0, as_stream(stream),
+                                (unsigned short*)g, g_ctot, g_off, (const unsigned short*)y, y_ctot, y_off, C,
+                                (long)nvox, slope),
+             hipLaunchKernelGGL(lrelu_bwd_kernel<F32>, dim3(ew_grid(total)), dim3(EW_BLOCK), 0, as_stream(stream),
+                                (float*)g, g_ctot, g_off, (const float*)y, y_ctot, y_off, C, (long)nvox, slope));
+  WSR_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int wsr_chan_axpby(void* dst, int32_t d_ctot, int32_t d_off, const void* src, int32_t s_ctot, int32_t s_off,
+                              int32_t C, int64_t nvox, float alpha, float beta, int32_t dtype, void* stream) {
+  if (!dst || !src || C <= 0 || nvox <= 0) return WSR_EINVAL;
+  if ((C | d_ctot | d_off | s_ctot | s_off) & 3) return WSR_EUNSUPPORTED;
+  const long total = nvox * (C >> 2);
+  DISPATCH_T(dtype,
+             hipLaunchKernelGGL(chan_axpby_kernel<BF16>, dim3(ew_grid(total)), dim3(EW_BLOCK), 0, as_stream(stream),
+                                (unsigned short*)dst, d_ctot, d_off, (const unsigned short*)src, s_ctot, s_off, C,
+                                (long)nvox, alpha, beta),
+             hipLaunchKernelGGL(chan_axpby_kernel<F32>, dim3(ew_grid(total)), dim3(EW_BLOCK), 0, as_stream(stream),
+                                (float*)dst, d_ctot, d_off, (const float*)src, s_ctot, s_off, C, (long)nvox, alpha,
+                                beta));
+  WSR_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int wsr_upsample2_bwd(const void* dy, void* dx, int32_t B, int32_t Xi, int32_t Yi, int32_t Zi, int32_t C,
+                                 int32_t dtype, void* stream) {
+  if (!dy || !dx || B <= 0 || Xi <= 0 || Yi <= 0 || Zi <= 0 || C <= 0) return WSR_EINVAL;
+  if (C & 3) return WSR_EUNSUPPORTED;
+  const long total = (long)B * Xi * Yi * Zi * (C >> 2);
+  DISPATCH_T(dtype,
+             hipLaunchKernelGGL(upsample2_bwd_kernel<BF16>, dim3(ew_grid(total)), dim3(EW_BLOCK), 0, as_stream(stream),
+                                (const unsigned short*)dy, (unsigned short*)dx, B, Xi, Yi, Zi, C),
+             hipLaunchKernelGGL(upsample2_bwd_kernel<F32>, dim3(ew_grid(total)), dim3(EW_BLOCK), 0, as_stream(stream),
+                                (const float*)dy, (float*)dx, B, Xi, Yi, Zi, C));
+  WSR_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int wsr_planar_to_ndhwc(const float* src, void* dst, int32_t B, int32_t C, int64_t vox_per_b, int32_t d_ctot,
+                                   int32_t d_off, int32_t c_fill, int32_t dtype, void* stream) {
+  if (!src || !dst || B <= 0 || C <= 0 || vox_per_b <= 0 || c_fill < C || d_off < 0 || d_off + c_fill > d_ctot)
+    return WSR_EINVAL;
+  const long total = (long)B * vox_per_b * c_fill;
+  DISPATCH_T(dtype,
+             hipLaunchKernelGGL(planar_to_ndhwc_kernel<BF16>, dim3(ew_grid(total)), dim3(EW_BLOCK), 0,
+                                as_stream(stream), src, (unsigned short*)dst, B, C, (long)vox_per_b, d_ctot, d_off,
+                                c_fill),
+             hipLaunchKernelGGL(planar_to_ndhwc_kernel<F32>, dim3(ew_grid(total)), dim3(EW_BLOCK), 0, as_stream(stream),
+                                src, (float*)dst, B, C, (long)vox_per_b, d_ctot, d_off, c_fill));
+  WSR_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int wsr_ndhwc_to_planar(const void* src, float* dst, int32_t B, int32_t C, int64_t vox_per_b, int32_t s_ctot,
+                                   int32_t s_off, int32_t dtype, void* stream) {
+  if (!src || !dst || B <= 0 || C <= 0 || vox_per_b <= 0 || s_off < 0 || s_off + C > s_ctot) return WSR_EINVAL;
+  const long total = (long)B * C * vox_per_b;
+  DISPATCH_T(dtype,
+             hipLaunchKernelGGL(ndhwc_to_planar_kernel<BF16>, dim3(ew_grid(total)), dim3(EW_BLOCK), 0,
+                                as_stream(stream), (const unsigned short*)src, dst, B, C, (long)vox_per_b, s_ctot,
+                                s_off),
+             hipLaunchKernelGGL(ndhwc_to_planar_kernel<F32>, dim3(ew_grid(total)), dim3(EW_BLOCK), 0, as_stream(stream),
+                                (const float*)src, dst, B, C, (long)vox_per_b, s_ctot, s_off));
+  WSR_LAUNCH_CHECK();
+  return 0;
+}
+
+static inline int bn_grid(long total) {
+  long g = (total + 256L * 64 - 1) / (256L * 64);  // >= 64 elements per thread
+  if (g > 1024) g = 1024;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+extern "C" int wsr_bn_stats(const void* x, int32_t C, int64_t nvox, float* sums, int32_t dtype, void* stream) {
+  if (!x || !sums || C <= 0 || nvox <= 0) return WSR_EINVAL;
+  if (C > 256 || 256 % C) return WSR_EUNSUPPORTED;
+  const int grid = bn_grid(nvox * C);
+  DISPATCH_T(dtype,
+             hipLaunchKernelGGL(bn_stats_kernel<BF16>, dim3(grid), dim3(256), 0, as_stream(stream),
+                                (const unsigned short*)x, C, (long)nvox, sums),
+             hipLaunchKernelGGL(bn_stats_kernel<F32>, dim3(grid), dim3(256), 0, as_stream(stream), (const float*)x, C,
+                                (long)nvox, sums));
+  WSR_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int wsr_bn_apply_lrelu(const void* x, void* y, const float* mean, const float* invstd, const float* gamma,
+                                  const float* beta, int32_t C, int64_t nvox, int32_t act, float slope, int32_t dtype,
+                                  void* stream) {
+  if (!x || !y || !mean || !invstd || !gamma || !beta || C <= 0 || nvox <= 0) return WSR_EINVAL;
+  const long total = nvox * C;
+  DISPATCH_T(dtype,
+             hipLaunchKernelGGL(bn_apply_kernel<BF16>, dim3(ew_grid(total)), dim3(EW_BLOCK), 0, as_stream(stream),
+                                (const unsigned short*)x, (unsigned short*)y, mean, invstd, gamma, beta, C, (long)nvox,
+                                act, slope),
+             hipLaunchKernelGGL(bn_apply_kernel<F32>, dim3(ew_grid(total)), dim3(EW_BLOCK), 0, as_stream(stream),
+                                (const float*)x, (float*)y, mean, invstd, gamma, beta, C, (long)nvox, act, slope));
+  WSR_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int wsr_bn_bwd_reduce(void* dy, const void* y, const void* x, const float* mean, const float* invstd,
+                                 int32_t C, int64_t nvox, int32_t act, float slope, float* sums, int32_t dtype,
+                                 void* stream) {
+  if (!dy || !y || !x || !mean || !invstd || !sums || C <= 0 || nvox <= 0) return WSR_EINVAL;
+  if (C > 256 || 256 % C) return WSR_EUNSUPPORTED;
+  const int grid = bn_grid(nvox * C);
+  DISPATCH_T(dtype,
+             hipLaunchKernelGGL(bn_bwd_reduce_kernel<BF16>, dim3(grid), dim3(256), 0, as_stream(stream),
+                                (unsigned short*)dy, (const unsigned short*)y, (const unsigned short*)x, mean, invstd, C,
+                                (long)nvox, act, slope, sums),
+             hipLaunchKernelGGL(bn_bwd_reduce_kernel<F32>, dim3(grid), dim3(256), 0, as_stream(stream), (float*)dy,
+                                (const float*)y, (const float*)x, mean, invstd, C, (long)nvox, act, slope, sums));
+  WSR_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int wsr_bn_bwd_apply(const void* g, const void* x, void* dx, const float* mean, const float* invstd,
+                                const float* gamma, const float* sums, float inv_n, int32_t C, int64_t nvox,
+                                int32_t dtype, void* stream) {
+  if (!g || !x || !dx || !mean || !invstd || !gamma || C <= 0 || nvox <= 0) return WSR_EINVAL;
+  const long total = nvox * C;
+  DISPATCH_T(dtype,
+             hipLaunchKernelGGL(bn_bwd_apply_kernel<BF16>, dim3(ew_grid(total)), dim3(EW_BLOCK), 0, as_stream(stream),
+                                (const unsigned short*)g, (const unsigned short*)x, (unsigned short*)dx, mean, invstd,
+                                gamma, sums, inv_n, C, (long)nvox),
+             hipLaunchKernelGGL(bn_bwd_apply_kernel<F32>, dim3(ew_grid(total)), dim3(EW_BLOCK), 0, as_stream(stream),
+                                (const float*)g, (const float*)x, (float*)dx, mean, invstd, gamma, sums, inv_n, C,
+                                (long)nvox));
+  WSR_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int wsr_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
+                             float beta2, float eps, float weight_decay, int32_t step, void* stream) {
+  if (!p || !g || !m || !v || n <= 0 || step <= 0) return WSR_EINVAL;
+  const double bc1 = 1.0 - pow((double)beta1, (double)step);
+  const double bc2 = 1.0 - pow((double)beta2, (double)step);
+  hipLaunchKernelGGL(adam_kernel, dim3(ew_grid(n)), dim3(EW_BLOCK), 0, as_stream(stream), p, g, m, v, (long)n,
+                     (float)(lr / bc1), beta1, beta2, eps, weight_decay, (float)sqrt(bc2));
+  WSR_LAUNCH_CHECK();
+  return 0;
+}

@@ -1,0 +1,227 @@
+"""Thin torch-tensor front end over the C-ABI (device pointers + current stream).
+
+Activations are ``(B, X, Y, Z, ctot)`` contiguous tensors ("NDHWC"), fp32 or
+bf16; filters are packed ``[rows][taps][k]`` tensors produced by
+:func:`pack_filter`.  Every function launches on the *current* torch stream and
+returns immediately; nothing here allocates behind the caller's back except
+where a fresh output tensor is the documented result.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import Optional, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import ConvDesc, Epilogue, check
+
+Tensor = torch.Tensor
+
+
+def dtype_id(dt: torch.dtype) -> int:
+    if dt == torch.float32:
+        return _lib.WSR_F32
+    if dt == torch.bfloat16:
+        return _lib.WSR_BF16
+    raise TypeError(f"unsupported activation dtype {dt}")
+
+
+def piece_elems(dt: torch.dtype) -> int:
+    """Channels per 16-byte piece (granularity of channel windows on the MFMA path)."""
+    return 4 if dt == torch.float32 else 8
+
+
+def pad_channels(c: int, dt: torch.dtype) -> int:
+    e = piece_elems(dt)
+    return (c + e - 1) // e * e
+
+
+def _stream() -> C.c_void_p:
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t: Optional[Tensor]) -> C.c_void_p:
+    return C.c_void_p(0 if t is None else t.data_ptr())
+
+
+def _need_cuda(*ts: Tensor) -> None:
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("windsr_hip kernels need device tensors (no CPU fallback)")
+
+
+@dataclass(frozen=True)
+class ConvGeom:
+    """Static description of a conv layer (reference ``nn.Conv3d`` arguments)."""
+
+    cin: int
+    cout: int
+    kernel: Tuple[int, int, int]
+    stride: Tuple[int, int, int] = (1, 1, 1)
+    pad: Tuple[int, int, int] = (1, 1, 1)
+    upsample: bool = False  # nearest x(2,2,1) in front (torch_blocks.py:345-347)
+
+    @property
+    def taps(self) -> int:
+        return self.kernel[0] * self.kernel[1] * self.kernel[2]
+
+    def out_extent(self, xi: int, yi: int, zi: int) -> Tuple[int, int, int]:
+        u = 2 if self.upsample else 1
+        k, s, p = self.kernel, self.stride, self.pad
+        return ((xi * u + 2 * p[0] - k[0]) // s[0] + 1, (yi * u + 2 * p[1] - k[1]) // s[1] + 1,
+                (zi + 2 * p[2] - k[2]) // s[2] + 1)
+
+
+def make_desc(g: ConvGeom, dt: torch.dtype, B: int, in_xyz, in_ctot: int, in_off: int, out_ctot: int,
+              out_off: int, cin: Optional[int] = None, cout: Optional[int] = None) -> ConvDesc:
+    xo, yo, zo = g.out_extent(*in_xyz)
+    d = ConvDesc()
+    d.dtype = dtype_id(dt)
+    d.B = B
+    d.Xi, d.Yi, d.Zi = in_xyz
+    d.Xo, d.Yo, d.Zo = xo, yo, zo
+    d.Cin, d.in_ctot, d.in_off = (g.cin if cin is None else cin), in_ctot, in_off
+    d.Cout, d.out_ctot, d.out_off = (g.cout if cout is None else cout), out_ctot, out_off
+    d.KX, d.KY, d.KZ = g.kernel
+    d.sx, d.sy, d.sz = g.stride
+    d.px, d.py, d.pz = g.pad
+    d.upsample_xy = 1 if g.upsample else 0
+    return d
+
+
+def conv_fwd(desc: ConvDesc, x: Tensor, w: Tensor, y: Tensor, *, bias: Optional[Tensor] = None,
+             chan_scale: Optional[Tensor] = None, res: Optional[Tensor] = None, res_off: int = 0,
+             alpha: float = 1.0, beta: float = 0.0, act: bool = False, slope: float = 0.2,
+             out_planar: bool = False) -> Tensor:
+    _need_cuda(x, w, y, bias, chan_scale, res)
+    ep = Epilogue()
+    ep.bias, ep.chan_scale, ep.res = _p(bias), _p(chan_scale), _p(res)
+    ep.res_ctot = res.shape[-1] if res is not None else 0
+    ep.res_off = res_off
+    ep.alpha, ep.beta = alpha, beta
+    ep.act, ep.slope = int(act), slope
+    ep.out_planar = int(out_planar)
+    check(_lib.lib().wsr_conv3d_fwd(C.byref(desc), _p(x), _p(w), _p(y), C.byref(ep), _stream()), "conv3d_fwd")
+    return y
+
+
+def conv_dgrad(desc: ConvDesc, dy: Tensor, wt: Tensor, dx: Tensor, *, accumulate: bool = False,
+               dx_planar: bool = False) -> Tensor:
+    _need_cuda(dy, wt, dx)
+    check(_lib.lib().wsr_conv3d_dgrad(C.byref(desc), _p(dy), _p(wt), _p(dx), int(accumulate), int(dx_planar),
+                                      _stream()), "conv3d_dgrad")
+    return dx
+
+
+def conv_wgrad(desc: ConvDesc, x: Tensor, dy: Tensor, dw: Tensor) -> Tensor:
+    """``dw`` (fp32 ``[Cout][taps][Cin]``) is accumulated into."""
+    _need_cuda(x, dy, dw)
+    if dw.dtype != torch.float32:
+        raise TypeError("filter gradients are fp32")
+    check(_lib.lib().wsr_conv3d_wgrad(C.byref(desc), _p(x), _p(dy), _p(dw), _stream()), "conv3d_wgrad")
+    return dw
+
+
+def pack_filter(w: Tensor, dt: torch.dtype, *, transpose: bool = False, kpad: Optional[int] = None,
+                out: Optional[Tensor] = None) -> Tensor:
+    """fp32 master ``(Cout, Cin, KX, KY, KZ)`` -> compute copy ``[rows][taps][kpad]`` of ``dt``."""
+    _need_cuda(w)
+    cout, cin = w.shape[:2]
+    taps = w[0, 0].numel()
+    if not w.is_contiguous() or w.dtype != torch.float32:
+        raise ValueError("pack_filter wants a contiguous fp32 (Cout, Cin, KX, KY, KZ) tensor")
+    k = cout if transpose else cin
+    kpad = pad_channels(k, dt) if kpad is None else kpad
+    rows = cin if transpose else cout
+    if out is None:
+        out = torch.empty((rows, taps, kpad), dtype=dt, device=w.device)
+    check(_lib.lib().wsr_pack_filter(_p(w), _p(out), dtype_id(dt), cout, taps, cin, int(transpose), kpad, _stream()),
+          "pack_filter")
+    return out
+
+
+def unpack_wgrad(src: Tensor, dst: Tensor, scale: float = 1.0) -> None:
+    """master-layout grad ``(Cout, Cin, KX, KY, KZ)`` += scale * packed ``[Cout][taps][kpad]``."""
+    cout, taps, kpad = src.shape
+    if dst.dtype != torch.float32 or not dst.is_contiguous() or dst.shape[0] != cout:
+        raise ValueError("unpack_wgrad wants a contiguous fp32 master-layout gradient")
+    check(_lib.lib().wsr_unpack_wgrad(_p(src), _p(dst), cout, taps, dst.shape[1], kpad, scale, _stream()),
+          "unpack_wgrad")
+
+
+def lrelu_bwd_(g: Tensor, g_off: int, y: Tensor, y_off: int, C_: int, slope: float) -> None:
+    nvox = g.numel() // g.shape[-1]
+    check(_lib.lib().wsr_lrelu_bwd_inplace(_p(g), g.shape[-1], g_off, _p(y), y.shape[-1], y_off, C_, nvox, slope,
+                                           dtype_id(g.dtype), _stream()), "lrelu_bwd")
+
+
+def chan_axpby(dst: Tensor, d_off: int, src: Tensor, s_off: int, C_: int, alpha: float = 1.0,
+               beta: float = 0.0) -> None:
+    nvox = dst.numel() // dst.shape[-1]
+    check(_lib.lib().wsr_chan_axpby(_p(dst), dst.shape[-1], d_off, _p(src), src.shape[-1], s_off, C_, nvox, alpha,
+                                    beta, dtype_id(dst.dtype), _stream()), "chan_axpby")
+
+
+def upsample2_bwd(dy: Tensor, dx: Tensor) -> Tensor:
+    B, X, Y, Z, C_ = dx.shape
+    check(_lib.lib().wsr_upsample2_bwd(_p(dy), _p(dx), B, X, Y, Z, C_, dtype_id(dx.dtype), _stream()),
+          "upsample2_bwd")
+    return dx
+
+
+def planar_to_ndhwc(src: Tensor, dst: Tensor, d_off: int = 0, c_fill: Optional[int] = None) -> Tensor:
+    """fp32 (B, C, X, Y, Z) contiguous -> channel window of an NDHWC tensor."""
+    _need_cuda(src, dst)
+    if src.dtype != torch.float32 or not src.is_contiguous():
+        raise ValueError("planar tensors are contiguous fp32 (B, C, X, Y, Z)")
+    B, C_ = src.shape[:2]
+    vpb = src[0, 0].numel()
+    c_fill = C_ if c_fill is None else c_fill
+    check(_lib.lib().wsr_planar_to_ndhwc(_p(src), _p(dst), B, C_, vpb, dst.shape[-1], d_off, c_fill,
+                                         dtype_id(dst.dtype), _stream()), "planar_to_ndhwc")
+    return dst
+
+
+def ndhwc_to_planar(src: Tensor, C_: int, s_off: int = 0) -> Tensor:
+    B, X, Y, Z, ctot = src.shape
+    dst = torch.empty((B, C_, X, Y, Z), dtype=torch.float32, device=src.device)
+    check(_lib.lib().wsr_ndhwc_to_planar(_p(src), _p(dst), B, C_, X * Y * Z, ctot, s_off, dtype_id(src.dtype),
+                                         _stream()), "ndhwc_to_planar")
+    return dst
+
+
+def bn_stats(x: Tensor, sums: Tensor) -> None:
+    C_ = x.shape[-1]
+    check(_lib.lib().wsr_bn_stats(_p(x), C_, x.numel() // C_, _p(sums), dtype_id(x.dtype), _stream()), "bn_stats")
+
+
+def bn_apply_lrelu(x: Tensor, y: Tensor, mean: Tensor, invstd: Tensor, gamma: Tensor, beta: Tensor, act: bool,
+                   slope: float) -> None:
+    C_ = x.shape[-1]
+    check(_lib.lib().wsr_bn_apply_lrelu(_p(x), _p(y), _p(mean), _p(invstd), _p(gamma), _p(beta), C_,
+                                        x.numel() // C_, int(act), slope, dtype_id(x.dtype), _stream()), "bn_apply")
+
+
+def bn_bwd_reduce(dy: Tensor, y: Tensor, x: Tensor, mean: Tensor, invstd: Tensor, act: bool, slope: float,
+                  sums: Tensor) -> None:
+    C_ = x.shape[-1]
+    check(_lib.lib().wsr_bn_bwd_reduce(_p(dy), _p(y), _p(x), _p(mean), _p(invstd), C_, x.numel() // C_, int(act),
+                                       slope, _p(sums), dtype_id(x.dtype), _stream()), "bn_bwd_reduce")
+
+
+def bn_bwd_apply(g: Tensor, x: Tensor, dx: Tensor, mean: Tensor, invstd: Tensor, gamma: Tensor,
+                 sums: Optional[Tensor], inv_n: float) -> None:
+    C_ = x.shape[-1]
+    check(_lib.lib().wsr_bn_bwd_apply(_p(g), _p(x), _p(dx), _p(mean), _p(invstd), _p(gamma), _p(sums), inv_n, C_,
+                                      x.numel() // C_, dtype_id(x.dtype), _stream()), "bn_bwd_apply")
+
+
+def adam_step(p: Tensor, g: Tensor, m: Tensor, v: Tensor, lr: float, beta1: float, beta2: float, eps: float,
+              weight_decay: float, step: int) -> None:
+    for t in (p, g, m, v):
+        if t.dtype != torch.float32 or not t.is_contiguous():
+            raise ValueError("adam_step wants flat contiguous fp32 buffers")
+    check(_lib.lib().wsr_adam_step(_p(p), _p(g), _p(m), _p(v), p.numel(), lr, beta1, beta2, eps, weight_decay, step,
+                                   _stream()), "adam_step")

@@ -1,0 +1,157 @@
+/*
+ * windsr_hip.h - C ABI of the MI355X (gfx950) kernels behind the 3D-conv GAN
+ * train-step hot path of GAN_SR_wind_field.
+ *
+ * The reference has no FFI layer for this path: its convolutions execute inside
+ * PyTorch/ATen.  Each entry point below names the reference call site (file:line
+ * under the reference tree) whose ATen work it replaces.  All pointers are DEVICE
+ * pointers unless stated otherwise; the caller owns every buffer; kernels never
+ * allocate, never synchronise and run on the hipStream_t passed as `stream`
+ * (NULL = the default stream).  Every function returns 0 on success, a negative
+ * WSR_E* code for bad arguments or the positive hipError_t of a failed launch.
+ *
+ * Activation layout ("NDHWC"): element (b, x, y, z, c) of a tensor with `ctot`
+ * channels per voxel lives at ((((b*X + x)*Y + y)*Z + z)*ctot + c); a conv may
+ * read/write a channel window [off, off+C) of such a buffer, which is how the
+ * dense-block concatenations (torch_blocks.py:212-214, Generator_3D...py:228)
+ * are done without a copy.  "Planar" tensors are the reference's own fp32
+ * (B, C, X, Y, Z) contiguous tensors (network inputs / outputs).
+ * Packed (compute) filter layout: [Cout][KX][KY][KZ][Cin] (Cin fastest), made by
+ * wsr_pack_filter from the master weights, which keep nn.Conv3d's own logical
+ * layout (Cout, Cin, KX, KY, KZ) so checkpoints / init / Adam are untouched.
+ */
+#ifndef WINDSR_HIP_H
+#define WINDSR_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define WSR_ABI_VERSION 1
+
+enum wsr_dtype { WSR_F32 = 0, WSR_BF16 = 1 };
+
+enum wsr_error {
+  WSR_OK = 0,
+  WSR_EINVAL = -1,      /* inconsistent geometry / null pointer            */
+  WSR_EUNSUPPORTED = -2 /* shape outside what the kernels were built for   */
+};
+
+/* Geometry of one 3-D convolution.  X/Y/Z naming follows the reference
+ * (tensor dims 2,3,4; Z = vertical levels, contiguous, never up-scaled). */
+typedef struct wsr_conv {
+  int32_t dtype;                 /* wsr_dtype of activations and packed filters */
+  int32_t B;                     /* batch                                         */
+  int32_t Xi, Yi, Zi;            /* stored input extent                           */
+  int32_t Xo, Yo, Zo;            /* output extent                                 */
+  int32_t Cin, in_ctot, in_off;  /* input channel window                          */
+  int32_t Cout, out_ctot, out_off;
+  int32_t KX, KY, KZ;
+  int32_t sx, sy, sz;            /* stride                                        */
+  int32_t px, py, pz;            /* zero padding                                  */
+  int32_t upsample_xy;           /* 1: input is read through nearest x(2,2,1)
+                                    up-sampling (torch_blocks.py:345-347)        */
+} wsr_conv_t;
+
+/* Fused epilogue:  v = conv (+ bias[c]);  v = lrelu(v, slope) if act;
+ *                  v *= chan_scale[b*Cout + c] if chan_scale (Dropout3d mask);
+ *                  y = alpha*v (+ beta*res[...,res_off + c] if res).          */
+typedef struct wsr_epilogue {
+  const float* bias;        /* [Cout] or NULL                                   */
+  const float* chan_scale;  /* [B*Cout] or NULL                                 */
+  const void* res;          /* NDHWC tensor of `dtype`, or NULL                 */
+  int32_t res_ctot, res_off;
+  float alpha, beta;
+  int32_t act;              /* 0 none, 1 leaky-relu                             */
+  float slope;
+  int32_t out_planar;       /* 1: y is fp32 planar (B, Cout, Xo, Yo, Zo)        */
+} wsr_epilogue_t;
+
+int wsr_abi_version(void);
+const char* wsr_error_string(int code);
+
+/* ---- convolution ------------------------------------------------------------
+ * aten::conv3d forward of nn.Conv3d (torch_blocks.py:17,278; Generator_3D...py:105)
+ * + the LeakyReLU / cat / residual / Dropout3d / Upsample ops fused around it
+ * (torch_blocks.py:35,214,290,330,46,347; Generator_3D...py:104,228).          */
+int wsr_conv3d_fwd(const wsr_conv_t* c, const void* x, const void* w, void* y,
+                   const wsr_epilogue_t* ep, void* stream);
+
+/* aten::convolution_backward, input gradient.  `wt` is the filter re-packed as
+ * [Cin][KX][KY][KZ][Cout] (wsr_pack_filter with transpose=1).  dx gets channel
+ * window [in_off, in_off+Cin) of an `in_ctot` buffer at the conv's *stored*
+ * input resolution unless upsample_xy, in which case dx is at 2Xi x 2Yi and
+ * wsr_upsample2_bwd folds it.  accumulate=1: dx += result.  dx_planar=1: dx
+ * is an fp32 planar (B, Cin, X, Y, Z) tensor (gradient w.r.t. a network input).  */
+int wsr_conv3d_dgrad(const wsr_conv_t* c, const void* dy, const void* wt, void* dx,
+                     int accumulate, int dx_planar, void* stream);
+
+/* aten::convolution_backward, filter gradient: dw[Cout][taps][Cin] fp32 (packed
+ * order) is ACCUMULATED into (caller zeroes it when a fresh gradient is wanted;
+ * wsr_unpack_wgrad moves it to the master layout).                             */
+int wsr_conv3d_wgrad(const wsr_conv_t* c, const void* x, const void* dy, float* dw, void* stream);
+
+/* ---- filter packing ----------------------------------------------------------
+ * master fp32 (Cout, Cin, KX, KY, KZ) contiguous -> compute copy of `dtype`:
+ *   transpose=0: [Cout][taps][kpad]  (channels >= Cin zero-filled)
+ *   transpose=1: [Cin][taps][kpad]   (channels >= Cout zero-filled; dgrad operand)
+ * kpad lets 1/3/4-channel tensors (LR fields, terrain height, D input, SR output:
+ * Generator_3D...py:78-85,105-110,120-127; Discriminator_3D.py:67) use the
+ * 16-byte-piece MFMA path.                                                     */
+int wsr_pack_filter(const float* w, void* out, int32_t dtype, int32_t Cout, int32_t taps,
+                    int32_t Cin, int32_t transpose, int32_t kpad, void* stream);
+/* Filter gradient back to the master layout:
+ * dst (Cout, Cin, taps) += scale * src [Cout][taps][kpad] (fp32).              */
+int wsr_unpack_wgrad(const float* src, float* dst, int32_t Cout, int32_t taps, int32_t Cin,
+                     int32_t kpad, float scale, void* stream);
+
+/* ---- elementwise / normalisation ---------------------------------------------
+ * leaky_relu_backward from the saved OUTPUT sign, in place on a channel window
+ * (torch_blocks.py:35 autograd):  g *= (y > 0 ? 1 : slope).                    */
+int wsr_lrelu_bwd_inplace(void* g, int32_t g_ctot, int32_t g_off, const void* y, int32_t y_ctot,
+                          int32_t y_off, int32_t C, int64_t nvox, float slope, int32_t dtype,
+                          void* stream);
+/* copy / axpby on channel windows: dst = alpha*src (+ beta*dst)                */
+int wsr_chan_axpby(void* dst, int32_t d_ctot, int32_t d_off, const void* src, int32_t s_ctot,
+                   int32_t s_off, int32_t C, int64_t nvox, float alpha, float beta, int32_t dtype,
+                   void* stream);
+/* backward of nearest x(2,2,1) up-sampling: dx[b,x,y,z,c] = sum of the 4 dy    */
+int wsr_upsample2_bwd(const void* dy, void* dx, int32_t B, int32_t Xi, int32_t Yi, int32_t Zi,
+                      int32_t C, int32_t dtype, void* stream);
+/* planar fp32 (B,C,X,Y,Z) <-> NDHWC `dtype` window; c_fill >= C channels are
+ * written, those beyond C with zeros                                           */
+int wsr_planar_to_ndhwc(const float* src, void* dst, int32_t B, int32_t C, int64_t vox_per_b,
+                        int32_t d_ctot, int32_t d_off, int32_t c_fill, int32_t dtype, void* stream);
+int wsr_ndhwc_to_planar(const void* src, float* dst, int32_t B, int32_t C, int64_t vox_per_b,
+                        int32_t s_ctot, int32_t s_off, int32_t dtype, void* stream);
+
+/* BatchNorm3d (torch_blocks.py:20-25) on NDHWC tensors, fp32 statistics.
+ * stats: sums[2*C] += {sum x, sum x^2} (caller zeroes).                        */
+int wsr_bn_stats(const void* x, int32_t C, int64_t nvox, float* sums, int32_t dtype, void* stream);
+/* y = lrelu((x-mean)*invstd*gamma + beta); mean/invstd fp32 [C]                 */
+int wsr_bn_apply_lrelu(const void* x, void* y, const float* mean, const float* invstd,
+                       const float* gamma, const float* beta, int32_t C, int64_t nvox, int32_t act,
+                       float slope, int32_t dtype, void* stream);
+/* backward, pass 1: g = dy * lrelu'(y) (written in place into dy);
+ * sums[2*C] += {sum g, sum g*xhat}.                                            */
+int wsr_bn_bwd_reduce(void* dy, const void* y, const void* x, const float* mean, const float* invstd,
+                      int32_t C, int64_t nvox, int32_t act, float slope, float* sums, int32_t dtype,
+                      void* stream);
+/* pass 2 (training): dx = gamma*invstd*(g - sum_g/n - xhat*sum_gxhat/n); eval:
+ * dx = gamma*invstd*g (sums == NULL).                                          */
+int wsr_bn_bwd_apply(const void* g, const void* x, void* dx, const float* mean, const float* invstd,
+                     const float* gamma, const float* sums, float inv_n, int32_t C, int64_t nvox,
+                     int32_t dtype, void* stream);
+
+/* ---- optimizer ---------------------------------------------------------------
+ * torch.optim.Adam single-tensor step over a flat fp32 buffer
+ * (wind_field_GAN_3D.py:151-162,460,566), bias-corrected, L2 weight decay.     */
+int wsr_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
+                  float beta2, float eps, float weight_decay, int32_t step, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* WINDSR_HIP_H */

@@ -1,0 +1,271 @@
+"""Parity of the individual HIP kernels (through the C-ABI) against the golden
+fixtures produced by the reference and against fp64 CPU restatements.
+
+Tolerances (rel-L2 over the whole tensor):
+  fp32 path : 1e-5 outputs / input grads, 2e-5 filter grads (float atomics)
+  bf16 path : 1e-2 against the fp32 goldens (operands rounded to 8 bits);
+              4e-3 against an fp32 CPU conv of the *same* bf16-rounded operands.
+"""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import rel_l2
+from cases import CONV_CASES
+
+pytestmark = pytest.mark.gpu
+
+T = torch.from_numpy
+DEV = "cuda:0"
+TOL = {torch.float32: (1e-5, 2e-5), torch.bfloat16: (1e-2, 1e-2)}
+
+
+def ops():
+    from gan_sr_wind_field_amd import hip_ops
+
+    return hip_ops
+
+
+def to_ndhwc(x, ctot, off, dt):
+    """logical (B,C,X,Y,Z) cpu -> NDHWC window of a (B,X,Y,Z,ctot) device buffer (rest = NaN canary... zeros for pads)."""
+    B, C_, X, Y, Z = x.shape
+    buf = torch.zeros((B, X, Y, Z, ctot), dtype=dt, device=DEV)
+    buf[..., off:off + C_] = x.permute(0, 2, 3, 4, 1).to(DEV).to(dt)
+    return buf
+
+
+def from_ndhwc(buf, off, C_):
+    return buf[..., off:off + C_].permute(0, 4, 1, 2, 3).float().cpu()
+
+
+def packed_master(w):
+    """master weights stay in nn.Conv3d's logical layout; just move to the device."""
+    return w.contiguous().to(DEV)
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("case", CONV_CASES, ids=[c[0] for c in CONV_CASES])
+def test_conv_fwd_dgrad_wgrad(golden, hip, dt, case):
+    o = ops()
+    name, cin, cout, k, s, p, bias, act, xyz, B = case
+    g = golden("conv_cases.npz")
+    x, w, y_ref, gy, dx_ref, dw_ref = (T(g[f"{name}.{n}"]) for n in ("x", "w", "y", "gy", "dx", "dw"))
+    b = T(g[f"{name}.b"]).to(DEV) if bias else None
+    tol_out, tol_w = TOL[dt]
+    e = o.piece_elems(dt)
+    cin_p, cout_p = o.pad_channels(cin, dt), o.pad_channels(cout, dt)
+    in_off, out_off = e, 2 * e  # exercise channel windows
+    in_ctot, out_ctot = cin_p + 2 * e, cout_p + 3 * e
+    geom = o.ConvGeom(cin_p, cout, k, s, p)
+    xb = to_ndhwc(x, in_ctot, in_off, dt)
+    wm = packed_master(w)
+    wp = o.pack_filter(wm, dt, kpad=cin_p)
+    d = o.make_desc(geom, dt, B, xyz, in_ctot, in_off, out_ctot, out_off)
+    yb = torch.full((B, d.Xo, d.Yo, d.Zo, out_ctot), 7.0, dtype=dt, device=DEV)
+    o.conv_fwd(d, xb, wp, yb, bias=b, act=act, slope=0.2)
+    torch.cuda.synchronize()
+    y = from_ndhwc(yb, out_off, cout)
+    assert rel_l2(y, y_ref) < tol_out
+    # nothing outside the window was touched
+    assert float((yb[..., :out_off].float() - 7.0).abs().max()) == 0.0
+    assert float((yb[..., out_off + cout:].float() - 7.0).abs().max()) == 0.0
+    if dt == torch.bfloat16:  # tight check against the same rounded operands
+        xr, wr = x.bfloat16().float(), w.bfloat16().float()
+        y2 = F.conv3d(xr, wr, b.cpu() if bias else None, s, p)
+        y2 = F.leaky_relu(y2, 0.2) if act else y2
+        assert rel_l2(y, y2) < 4e-3
+
+    # ---- backward: g = gy * lrelu'(y) in place, then dgrad / wgrad ---------------
+    gb = to_ndhwc(gy, out_ctot, out_off, dt)
+    if act:
+        # bf16: take the mask from the golden y - rounding flips the sign of ~0.2 % of
+        # the near-zero activations, which is a 5x change of those gradient elements
+        ymask = yb if dt == torch.float32 else to_ndhwc(y_ref, out_ctot, out_off, dt)
+        o.lrelu_bwd_(gb, out_off, ymask, out_off, cout_p, 0.2)
+    wt = o.pack_filter(wm, dt, transpose=True, kpad=cout_p)
+    dgeom = o.ConvGeom(cin, cout_p, k, s, p)
+    dd = o.make_desc(dgeom, dt, B, xyz, in_ctot, in_off, out_ctot, out_off)
+    dxb = torch.full((B,) + tuple(xyz) + (in_ctot,), 3.0, dtype=dt, device=DEV)
+    o.conv_dgrad(dd, gb, wt, dxb)
+    dx = from_ndhwc(dxb, in_off, cin)
+    assert rel_l2(dx, dx_ref) < tol_out
+    assert float((dxb[..., :in_off].float() - 3.0).abs().max()) == 0.0
+    # accumulate mode: dx += result
+    o.conv_dgrad(dd, gb, wt, dxb, accumulate=True)
+    assert rel_l2(from_ndhwc(dxb, in_off, cin), 2 * dx_ref) < tol_out
+    # planar fp32 gradient (used for network inputs)
+    dxp = torch.zeros((B, cin) + tuple(xyz), dtype=torch.float32, device=DEV)
+    dd2 = o.make_desc(o.ConvGeom(cin, cout_p, k, s, p), dt, B, xyz, cin, 0, out_ctot, out_off)
+    o.conv_dgrad(dd2, gb, wt, dxp, dx_planar=True)
+    assert rel_l2(dxp.cpu(), dx_ref) < tol_out
+
+    dwp = torch.zeros((cout, geom.taps, cin_p), dtype=torch.float32, device=DEV)
+    o.conv_wgrad(d, xb, gb, dwp)
+    dw = torch.ones((cout, cin) + tuple(k), dtype=torch.float32, device=DEV)
+    o.unpack_wgrad(dwp, dw, scale=0.5)
+    assert rel_l2((dw.cpu() - 1.0) * 2.0, dw_ref) < tol_w
+    if bias:
+        db = gb[..., out_off:out_off + cout].float().sum(dim=(0, 1, 2, 3)).cpu()
+        assert rel_l2(db, T(g[f"{name}.db"])) < tol_out
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_upconv_fused_upsample(golden, hip, dt):
+    """nearest x(2,2,1) folded into the conv gather; backward = dgrad at fine res + 2x2 fold."""
+    o = ops()
+    g = golden("blocks.npz")
+    x, w, y_ref, gy, dx_ref, dw_ref = (T(g[f"up.{n}"]) for n in ("x", "w", "y", "gy", "dx", "dw"))
+    tol_out, tol_w = TOL[dt]
+    B, C_, X, Y, Z = x.shape
+    geom = o.ConvGeom(8, 8, (3, 3, 3), (1, 1, 1), (1, 1, 1), upsample=True)
+    xb = to_ndhwc(x, 8, 0, dt)
+    wm = packed_master(w)
+    d = o.make_desc(geom, dt, B, (X, Y, Z), 8, 0, 8, 0)
+    yb = torch.empty((B, 2 * X, 2 * Y, Z, 8), dtype=dt, device=DEV)
+    o.conv_fwd(d, xb, o.pack_filter(wm, dt), yb, act=True, slope=0.2)
+    assert rel_l2(from_ndhwc(yb, 0, 8), y_ref) < tol_out
+    gb = to_ndhwc(gy, 8, 0, dt)
+    o.lrelu_bwd_(gb, 0, yb if dt == torch.float32 else to_ndhwc(y_ref, 8, 0, dt), 0, 8, 0.2)
+    fine = torch.empty((B, 2 * X, 2 * Y, Z, 8), dtype=dt, device=DEV)
+    o.conv_dgrad(d, gb, o.pack_filter(wm, dt, transpose=True), fine)
+    dxb = torch.empty((B, X, Y, Z, 8), dtype=dt, device=DEV)
+    o.upsample2_bwd(fine, dxb)
+    assert rel_l2(from_ndhwc(dxb, 0, 8), dx_ref) < (tol_out if dt == torch.float32 else 1.5e-2)
+    dwp = torch.zeros((8, 27, 8), dtype=torch.float32, device=DEV)
+    o.conv_wgrad(d, xb, gb, dwp)
+    dw = torch.zeros((8, 8, 3, 3, 3), dtype=torch.float32, device=DEV)
+    o.unpack_wgrad(dwp, dw)
+    assert rel_l2(dw.cpu(), dw_ref) < tol_w
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_epilogue_residual_dropout_planar(hip, dt):
+    """bias + LReLU + channel scale + alpha*v + beta*res, NDHWC and planar outputs."""
+    o = ops()
+    gen = torch.Generator().manual_seed(5)
+    B, cin, cout, xyz = 2, 16, 24, (5, 4, 6)
+    x = torch.randn((B, cin) + xyz, generator=gen)
+    w = torch.randn((cout, cin, 3, 3, 3), generator=gen) * 0.1
+    b = torch.randn(cout, generator=gen)
+    res = torch.randn((B, cout) + xyz, generator=gen)
+    cs = torch.rand((B, cout), generator=gen)
+    if dt == torch.bfloat16:
+        x, w, res = x.bfloat16().float(), w.bfloat16().float(), res.bfloat16().float()
+    ref = F.leaky_relu(F.conv3d(x, w, b, 1, 1), 0.2) * cs.view(B, cout, 1, 1, 1) * 0.2 + 0.5 * res
+    geom = o.ConvGeom(cin, cout, (3, 3, 3))
+    d = o.make_desc(geom, dt, B, xyz, cin, 0, cout, 0)
+    xb, rb = to_ndhwc(x, cin, 0, dt), to_ndhwc(res, cout, 0, dt)
+    yb = torch.empty((B,) + xyz + (cout,), dtype=dt, device=DEV)
+    wp = o.pack_filter(packed_master(w), dt)
+    o.conv_fwd(d, xb, wp, yb, bias=b.to(DEV), chan_scale=cs.to(DEV).contiguous(), res=rb, alpha=0.2, beta=0.5,
+               act=True, slope=0.2)
+    assert rel_l2(from_ndhwc(yb, 0, cout), ref) < (1e-5 if dt == torch.float32 else 6e-3)
+    yp = torch.empty((B, cout) + xyz, dtype=torch.float32, device=DEV)
+    o.conv_fwd(d, xb, wp, yp, bias=b.to(DEV), act=False, out_planar=True)
+    assert rel_l2(yp.cpu(), F.conv3d(x, w, b, 1, 1)) < (1e-5 if dt == torch.float32 else 4e-3)
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_layout_and_window_helpers(hip, dt):
+    o = ops()
+    gen = torch.Generator().manual_seed(9)
+    x = torch.randn((2, 3, 4, 5, 6), generator=gen)
+    buf = torch.full((2, 4, 5, 6, 16), 9.0, dtype=dt, device=DEV)
+    o.planar_to_ndhwc(x.to(DEV), buf, d_off=4, c_fill=8)
+    got = buf[..., 4:7].permute(0, 4, 1, 2, 3).float().cpu()
+    assert rel_l2(got, x) < (1e-7 if dt == torch.float32 else 4e-3)
+    assert float(buf[..., 7:12].float().abs().max()) == 0.0 and float((buf[..., :4].float() - 9).abs().max()) == 0.0
+    back = o.ndhwc_to_planar(buf, 3, 4).cpu()
+    assert rel_l2(back, got) == 0.0
+    # axpby on windows
+    a = torch.randn((2, 4, 5, 6, 16), generator=gen).to(DEV).to(dt)
+    bsrc = torch.randn((2, 4, 5, 6, 8), generator=gen).to(DEV).to(dt)
+    exp = a.float().clone()
+    exp[..., 8:16] = 0.5 * bsrc.float() + 2.0 * exp[..., 8:16]
+    o.chan_axpby(a, 8, bsrc, 0, 8, alpha=0.5, beta=2.0)
+    assert rel_l2(a.float().cpu(), exp.cpu()) < (1e-6 if dt == torch.float32 else 4e-3)
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("C_", [4, 32, 256])
+def test_batchnorm_kernels(hip, dt, C_):
+    """bn_stats / apply / backward vs torch's CPU batch_norm autograd (training mode)."""
+    o = ops()
+    gen = torch.Generator().manual_seed(C_)
+    shape = (2, 6, 5, 7, C_)
+    x = (torch.randn(shape, generator=gen) * 1.5 + 0.3)
+    gamma = 1 + 0.1 * torch.randn(C_, generator=gen)
+    beta = 0.1 * torch.randn(C_, generator=gen)
+    gy = torch.randn(shape, generator=gen)
+    if dt == torch.bfloat16:
+        x, gy = x.bfloat16().float(), gy.bfloat16().float()
+    xl = x.permute(0, 4, 1, 2, 3).double().requires_grad_(True)
+    gl, bl = gamma.double().requires_grad_(True), beta.double().requires_grad_(True)
+    yl = F.leaky_relu(F.batch_norm(xl, None, None, gl, bl, True, 0.1, 1e-5), 0.2)
+    (yl * gy.permute(0, 4, 1, 2, 3).double()).sum().backward()
+    n = x.numel() // C_
+    xb = x.to(DEV).to(dt)
+    sums = torch.zeros(2 * C_, device=DEV)
+    o.bn_stats(xb, sums)
+    mean = sums[:C_] / n
+    var = sums[C_:] / n - mean * mean
+    assert rel_l2(mean.cpu(), xl.detach().mean(dim=(0, 2, 3, 4)).float()) < 1e-4
+    invstd = torch.rsqrt(var + 1e-5)
+    yb = torch.empty_like(xb)
+    g_d, b_d = gamma.to(DEV), beta.to(DEV)
+    o.bn_apply_lrelu(xb, yb, mean, invstd, g_d, b_d, True, 0.2)
+    tol = 2e-5 if dt == torch.float32 else 6e-3
+    assert rel_l2(yb.float().cpu(), yl.detach().permute(0, 2, 3, 4, 1).float()) < tol
+    gb = gy.to(DEV).to(dt)
+    s2 = torch.zeros(2 * C_, device=DEV)
+    o.bn_bwd_reduce(gb, yb, xb, mean, invstd, True, 0.2, s2)
+    assert rel_l2(s2[:C_].cpu(), bl.grad.float()) < (1e-4 if dt == torch.float32 else 1e-2)
+    assert rel_l2(s2[C_:].cpu(), gl.grad.float()) < (1e-4 if dt == torch.float32 else 1e-2)
+    dxb = torch.empty_like(xb)
+    o.bn_bwd_apply(gb, xb, dxb, mean, invstd, g_d, s2, 1.0 / n)
+    assert rel_l2(dxb.float().cpu(), xl.grad.permute(0, 2, 3, 4, 1).float()) < (1e-4 if dt == torch.float32 else 1.5e-2)
+
+
+def test_adam_matches_torch(hip):
+    o = ops()
+    gen = torch.Generator().manual_seed(1)
+    p0 = torch.randn(10007, generator=gen)
+    ref = p0.clone().requires_grad_(True)
+    opt = torch.optim.Adam([ref], lr=8e-5, betas=(0.9, 0.999), weight_decay=0.01)
+    p = p0.to(DEV)
+    m, v = torch.zeros_like(p), torch.zeros_like(p)
+    for step in range(1, 6):
+        gr = torch.randn(10007, generator=gen)
+        ref.grad = gr.clone()
+        opt.step()
+        o.adam_step(p, gr.to(DEV), m, v, 8e-5, 0.9, 0.999, 1e-8, 0.01, step)
+    assert rel_l2(p.cpu(), ref.detach()) < 1e-6
+    assert float((p.cpu() - p0).abs().max()) > 1e-5
+
+
+def test_big_shapes_properties(hip):
+    """Full-size layer shapes: linearity of the conv in x and agreement of the
+    bf16 and fp32 paths (no CPU reference at these sizes)."""
+    o = ops()
+    gen = torch.Generator(device=DEV).manual_seed(3)
+    B, xyz, cin, cout = 1, (32, 32, 16), 224, 32
+    geom = o.ConvGeom(cin, cout, (3, 3, 3))
+    w = torch.randn((cout, cin, 3, 3, 3), generator=gen, device=DEV) * 0.02
+    x1 = torch.randn((B,) + xyz + (256,), generator=gen, device=DEV)
+    x2 = torch.randn((B,) + xyz + (256,), generator=gen, device=DEV)
+    outs = {}
+    for dt in (torch.float32, torch.bfloat16):
+        d = o.make_desc(geom, dt, B, xyz, 256, 0, 256, 224)
+        wp = o.pack_filter(w, dt)
+        ys = []
+        for xin in (x1, x2, x1 + x2):
+            buf = xin.to(dt).clone()
+            o.conv_fwd(d, buf, wp, buf, act=False)  # writes channels 224..255 of the same dense buffer
+            ys.append(buf[..., 224:].float())
+        outs[dt] = ys
+    f = outs[torch.float32]
+    assert rel_l2(f[0] + f[1], f[2]) < 1e-5
+    assert rel_l2(outs[torch.bfloat16][0], f[0]) < 1e-2
