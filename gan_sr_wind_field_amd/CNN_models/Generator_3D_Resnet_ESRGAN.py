@@ -1,0 +1,103 @@
+"""Generator_3D: ESRGAN-style RRDB generator for 3-D wind fields on MI355X.
+
+Same constructor signature, attribute names (``model``, ``hr_convs``,
+``terrain_convs``, ``max_norm``) and ``state_dict`` keys as the reference
+(CNN_models/Generator_3D_Resnet_ESRGAN.py:23-229); the sub-modules are built in
+the reference's order so a seeded construction + ``init_weights`` reproduces the
+reference's initial weights.  ``forward(x, Z)`` runs the fused HIP program
+(engine.GeneratorProgram); there is no ATen convolution and no CPU path.
+
+``use_mixed_precision`` - parsed but unused by the reference (its AMP lines are
+commented out, :65) - selects the compute dtype here: False -> fp32 MFMA (exact
+fp32 products/accumulation), True -> bf16 operands with fp32 accumulation and an
+fp32 output / loss.
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+import torch.nn as nn
+
+from .. import engine
+from ..tools import loggingclass as lc
+from .torch_blocks import RRDB, SkipConnectionBlock, create_conv_lrelu_layer, create_UpConv_block
+
+
+class Generator_3D(nn.Module, lc.GlobalLoggingClass):
+    def __init__(self, in_channels: int, out_channels: int, number_of_features: int, number_of_RRDBs: int,
+                 upscale: int = 4, hr_kern_size: int = 3, number_of_RDB_convs: int = 5, RDB_gc: int = 32,
+                 lff_kern_size: int = 1, RDB_residual_scaling: float = 0.2, RRDB_residual_scaling: float = 0.2,
+                 act_type: str = "leakyrelu", number_of_z_layers: int = 10, conv_mode: str = "3D",
+                 use_mixed_precision: bool = False, device="cpu", terrain_number_of_features: int = 16,
+                 dropout_probability: float = 0.0, max_norm: float = 1.0):
+        super().__init__()
+        if act_type == "leakyrelu":
+            slope = 0.2
+        elif act_type == "relu":
+            slope = 0.0
+        else:
+            self.status_logs.append(f"Generator: warning: activation type {act_type} has not been implemented "
+                                    "- defaulting to leaky ReLU (0.2)")
+            slope = 0.2
+        if conv_mode != "3D":
+            if conv_mode in ("2D", "horizontal_3D"):
+                raise NotImplementedError(f"conv_mode {conv_mode}: only 3D runs on the MI355X path")
+            raise ValueError(f"Conv mode {conv_mode} not implemented")
+        self.slope = slope
+        self.max_norm = max_norm
+        self.compute_dtype = engine.compute_dtype_of(use_mixed_precision)
+        nf, tf = number_of_features, terrain_number_of_features
+        hr_pad = (hr_kern_size - 1) // 2
+        dropout = nn.Dropout3d(p=0.0 if dropout_probability is None else dropout_probability)
+
+        # construction order == reference order (RNG parity of the default nn.Conv3d init)
+        feature_conv = create_conv_lrelu_layer(in_channels, nf, 3, padding=1, lrelu=False)
+        lr_conv = create_conv_lrelu_layer(nf, nf, 3, padding=1, lrelu_negative_slope=slope, lrelu=False)
+        hr_convs = [
+            create_conv_lrelu_layer(nf + tf, nf + tf, kernel_size=hr_kern_size, padding=hr_pad,
+                                    lrelu_negative_slope=slope),
+            dropout,
+            nn.Conv3d(nf + tf, out_channels, kernel_size=hr_kern_size, padding=hr_pad),
+        ]
+        terrain_convs = [
+            create_conv_lrelu_layer(1, tf, 3, padding=1, lrelu=True),
+            create_conv_lrelu_layer(tf, tf, 3, padding=1, lrelu=False),
+        ]
+        rrdbs = [RRDB(nf, RDB_gc, number_of_RDB_convs, lff_kern_size, lrelu_negative_slope=slope,
+                      RDB_residual_scaling=RDB_residual_scaling, RRDB_residual_scaling=RRDB_residual_scaling,
+                      mode=conv_mode) for _ in range(number_of_RRDBs)]
+        shortcut = SkipConnectionBlock(nn.Sequential(*rrdbs, lr_conv))
+        n_up = math.floor(math.log2(upscale))
+        if 2 ** n_up != upscale:
+            self.status_logs.append(f"ESRDnet: warning: upsampling only supported for factors 2^n. "
+                                    f"Defaulting {upscale} to {2 ** n_up}")
+        upsampler = [create_UpConv_block(nf, nf, scale=2, lrelu_negative_slope=slope,
+                                         number_of_z_layers=number_of_z_layers, mode=conv_mode)
+                     for _ in range(n_up)]
+        self.model = nn.Sequential(feature_conv, shortcut, *upsampler)
+        self.hr_convs = nn.Sequential(*hr_convs)
+        self.terrain_convs = nn.Sequential(*terrain_convs)
+        self._program = None
+        self.status_logs.append("Generator: finished init")
+
+    def program(self) -> "engine.GeneratorProgram":
+        if self._program is None or self._program.dt != self.compute_dtype:
+            self._program = engine.GeneratorProgram(self, self.compute_dtype)
+        return self._program
+
+    def forward(self, x: torch.Tensor, Z: torch.Tensor, dropout_scale: torch.Tensor = None) -> torch.Tensor:
+        """(B, Cin, n, n, nz), (B, 1, s*n, s*n, nz) -> (B, Cout, s*n, s*n, nz) fp32."""
+        if not x.is_cuda:
+            raise RuntimeError("Generator_3D runs on the MI355X HIP kernels only: move the model and its inputs to "
+                               "a cuda device (there is no CPU fallback)")
+        return engine.run_generator(self.program(), x, Z, self.training, dropout_scale)
+
+    def __deepcopy__(self, memo):
+        import copy
+        cls = self.__class__
+        new = cls.__new__(cls)
+        memo[id(self)] = new
+        for k, v in self.__dict__.items():
+            setattr(new, k, None if k == "_program" else copy.deepcopy(v, memo))
+        return new

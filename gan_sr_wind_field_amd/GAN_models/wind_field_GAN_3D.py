@@ -1,0 +1,401 @@
+"""wind_field_GAN_3D: the ESRGAN-style 3-D wind-field GAN train step on MI355X.
+
+Public surface = the reference's (GAN_models/wind_field_GAN_3D.py:26-814):
+``wind_field_GAN_3D(cfg)``, ``feed_xy_niter``, ``optimize_parameters``,
+``validation``, ``update_learning_rate``, the ``get_*_dict_ref`` getters with the
+same keys, ``save_model`` / ``load_model`` (BaseGAN), ``G`` / ``D`` attributes and
+the free functions ``calculate_PSNR``, ``compute_PSNR_for_SR_and_trilinear``,
+``get_norm_factors_of_gradients``.  G and D are the HIP-backed networks of
+``CNN_models``; the loss algebra (a few dozen reductions over the (B,3,X,Y,Z)
+output) is fp32 torch code on the device, the optimizer is ``torch.optim.Adam``
+exactly as in the reference.
+
+Data parallelism (one process per GPU, ``torch.distributed``) is an extension:
+when a process group is attached (``dist.attach``) the batch-global quantities of
+the step - RaGAN logit means, the four gradient normalisers, BatchNorm statistics
+- are reduced across ranks so an N-rank step equals the single-GPU step on the
+concatenated batch, and G/D gradients are all-reduced in buckets.
+"""
+from __future__ import annotations
+
+import copy
+import math
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.optim.lr_scheduler as lr_scheduler
+
+from ..CNN_models.Discriminator_3D import Discriminator_3D
+from ..CNN_models.Generator_3D_Resnet_ESRGAN import Generator_3D
+from ..process_data import calculate_gradient_of_wind_field
+from ..tools import initialization, trainingtricks
+from .baseGAN import BaseGAN
+
+_G_LOSS_KEYS = ("total", "adversarial", "pix", "xy_gradient", "z_gradient", "divergence", "xy_divergence",
+                "feature_D")
+
+
+def _zeros_dict(keys):
+    return {k: torch.zeros(1) for k in keys}
+
+
+class wind_field_GAN_3D(BaseGAN):
+    def __init__(self, cfg):
+        super().__init__(cfg)
+        self.optimizers, self.schedulers = [], []
+        self.train_G_loss_dict = _zeros_dict(_G_LOSS_KEYS)
+        self.validation_G_loss_dict = _zeros_dict(_G_LOSS_KEYS)
+        self.D_loss_dict = _zeros_dict(("train_loss", "validation_loss"))
+        self.hist_dict = {
+            "val_grad_G_first_layer": torch.zeros(1), "val_grad_G_last_layer": torch.zeros(1),
+            "val_grad_D_first_layer": torch.tensor(-1.0), "val_grad_D_last_layer": torch.tensor(-1.0),
+            "val_weight_G_first_layer": torch.zeros(1), "val_weight_G_last_layer": torch.zeros(1),
+            "val_weight_D_first_layer": torch.tensor(-1.0), "val_weight_D_last_layer": torch.tensor(-1.0),
+            "SR_pix_distribution": torch.zeros(1), "D_pred_HR": torch.zeros(1), "D_pred_SR": torch.zeros(1),
+        }
+        self.metrics_dict = _zeros_dict(("val_PSNR", "Trilinear_PSNR", "pix_loss_unscaled", "trilinear_pix_loss"))
+        self.device_check = ""
+        self.batch_size = 1
+        dev = getattr(cfg, "device", self.device)
+        self.max_diff_squared = torch.tensor(4.0, device=dev)  # HR is in [-1, 1]
+        self.epsilon_PSNR = torch.tensor(1e-8, device=dev)
+        self.feature_extractor = None
+        self.dp = None  # set by dist.attach()
+
+        cfg_G, cfg_gan = cfg.generator, cfg.gan_config
+        # The ini's use_mixed_precision flags are parsed but - as in the reference, whose AMP
+        # lines are commented out - do not change the arithmetic; [DEFAULT] compute_dtype does.
+        bf16 = getattr(cfg, "compute_dtype", "fp32") == "bf16"
+        in_ch = (cfg_G.in_num_ch + cfg_gan.include_pressure + cfg_gan.include_z_channel
+                 + cfg_gan.include_above_ground_channel)
+        self.G = Generator_3D(
+            in_ch, cfg_G.out_num_ch, cfg_G.num_features, cfg_G.num_RRDB, upscale=cfg.scale,
+            hr_kern_size=cfg_G.hr_kern_size, number_of_RDB_convs=cfg_G.num_RDB_convs,
+            RDB_gc=cfg_G.RDB_growth_chan, lff_kern_size=cfg_G.lff_kern_size,
+            RDB_residual_scaling=cfg_G.RDB_res_scaling, RRDB_residual_scaling=cfg_G.RRDB_res_scaling,
+            act_type=cfg_G.act_type, device=self.device, number_of_z_layers=cfg_gan.number_of_z_layers,
+            conv_mode=cfg_gan.conv_mode, use_mixed_precision=bf16,
+            terrain_number_of_features=cfg_G.terrain_number_of_features,
+            dropout_probability=cfg_G.dropout_probability, max_norm=cfg_G.max_norm,
+        ).to(self.device, non_blocking=True)
+        initialization.init_weights(self.G, scale=cfg_G.weight_init_scale)
+        self.conv_mode = cfg_G.conv_mode
+        self.use_D_feature_extractor_cost = cfg_gan.use_D_feature_extractor_cost
+        if not cfg.is_train:
+            return
+
+        cfg_D, cfg_t = cfg.discriminator, cfg.training
+        self.D = Discriminator_3D(
+            cfg_D.in_num_ch, cfg_D.num_features, feat_kern_size=cfg_D.feat_kern_size,
+            normalization_type=cfg_D.norm_type, act_type=cfg_D.act_type, mode=cfg_D.layer_mode,
+            device=self.device, number_of_z_layers=cfg_gan.number_of_z_layers, conv_mode=cfg_gan.conv_mode,
+            use_mixed_precision=bf16, enable_slicing=cfg_gan.enable_slicing,
+            dropout_probability=cfg_D.dropout_probability,
+        ).to(self.device, non_blocking=True)
+        initialization.init_weights(self.D, scale=cfg_D.weight_init_scale)
+
+        self.optimizer_G = torch.optim.Adam(self.G.parameters(), lr=cfg_t.learning_rate_g,
+                                            weight_decay=cfg_t.adam_weight_decay_g,
+                                            betas=(cfg_t.adam_beta1_g, 0.999))
+        self.optimizer_D = torch.optim.Adam(self.D.parameters(), lr=cfg_t.learning_rate_d,
+                                            weight_decay=cfg_t.adam_weight_decay_d,
+                                            betas=(cfg_t.adam_beta1_d, 0.999))
+        self.optimizers += [self.optimizer_G, self.optimizer_D]
+        if cfg_t.multistep_lr_steps:
+            self.scheduler_G = lr_scheduler.MultiStepLR(self.optimizer_G, cfg_t.multistep_lr_steps,
+                                                        gamma=cfg_t.lr_gamma)
+            self.scheduler_D = lr_scheduler.MultiStepLR(self.optimizer_D, cfg_t.multistep_lr_steps,
+                                                        gamma=cfg_t.lr_gamma)
+            self.schedulers += [self.scheduler_G, self.scheduler_D]
+
+        mse = nn.MSELoss
+        self.gradient_xy_criterion = mse().to(dev)
+        self.gradient_z_criterion = mse().to(dev)
+        self.divergence_criterion = mse().to(dev)
+        self.xy_divergence_criterion = mse().to(dev)
+        self.feature_D_criterion = mse().to(dev)
+        crit = cfg_t.pixel_criterion
+        if crit is None or crit == "none":
+            self.pixel_criterion = None
+        elif crit == "l1":
+            self.pixel_criterion = nn.L1Loss().to(dev)
+        elif crit == "l2":
+            self.pixel_criterion = nn.MSELoss().to(dev)
+        else:
+            raise NotImplementedError(f"Only l1 and l2 (MSE) loss have been implemented for pixel loss, not {crit}")
+        if cfg_t.gan_type in ("relativistic", "relativisticavg"):
+            self.criterion = nn.BCEWithLogitsLoss().to(dev)
+        else:
+            raise NotImplementedError(f"Only relativistic and relativisticavg GAN are implemented, not {cfg_t.gan_type}")
+
+    # ------------------------------------------------------------------ inputs
+    def feed_xy_niter(self, x: torch.Tensor, y: torch.Tensor, niter: torch.Tensor, d_g_train_ratio: int,
+                      d_g_train_period: int):
+        self.x, self.y, self.niter = x, y, niter
+        self.d_g_train_ratio, self.d_g_train_period = d_g_train_ratio, d_g_train_period
+
+    # ------------------------------------------------------------ batch-global ops
+    def _mean(self, t: torch.Tensor) -> torch.Tensor:
+        """mean over the (global) batch - the RaGAN average logit"""
+        return torch.mean(t) if self.dp is None else self.dp.batch_mean(t)
+
+    def _noise(self, sigma: float, shape, it):
+        return trainingtricks.instance_noise(torch.tensor(sigma, device=self.device), shape, it, self.niter,
+                                             device=self.device)
+
+    # ------------------------------------------------------------------ D passes
+    def D_forward(self, HR: torch.Tensor, fake_HR: torch.Tensor, it: torch.Tensor, train_D: bool):
+        """Returns (y_pred, fake_y_pred).  train_D: D.train(), sigma_base 1, fake detached;
+        else D.eval(), sigma_base 2, real logits detached (reference :221-304)."""
+        if self.device_check == "":
+            # the reference builds a debug string here whose last term draws one noise tensor (:228-246)
+            self.device_check = str(HR.device) + str(self._noise(2.0, HR.size(), it).device)
+        noise_on = self.cfg.training.use_instance_noise
+        if train_D:
+            self.D.train()
+            real_in = HR + self._noise(1.0, HR.size(), it) if noise_on else HR
+            y_pred = self.D(real_in).squeeze()
+            fake = fake_HR.detach()
+            fake_in = fake + self._noise(1.0, HR.size(), it) if noise_on else fake
+            fake_y_pred = self.D(fake_in).squeeze()
+        else:
+            self.D.eval()
+            real_in = HR + self._noise(2.0, HR.size(), it) if noise_on else HR
+            y_pred = self.D(real_in).squeeze().detach()
+            fake_in = fake_HR + self._noise(2.0, HR.size(), it) if noise_on else fake_HR
+            fake_y_pred = self.D(fake_in).squeeze()
+        return y_pred, fake_y_pred
+
+    # ------------------------------------------------------------------ G losses
+    def log_G_losses(self, fake_HR, losses: dict, training_iteration: bool):
+        target = self.train_G_loss_dict if training_iteration else self.validation_G_loss_dict
+        for k in _G_LOSS_KEYS:
+            target[k] = losses[k]
+        if not training_iteration:
+            self.metrics_dict["pix_loss_unscaled"] = losses["pix"] / self.cfg.training.pixel_loss_weight
+            self.hist_dict["SR_pix_distribution"] = fake_HR.detach().cpu().numpy()
+
+    def calculate_optimize_and_log_G_loss(self, HR, fake_HR, Z, y_pred, fake_y_pred, training_iteration: bool):
+        t = self.cfg.training
+        if t.gan_type == "relativistic":
+            adv = self.criterion(fake_y_pred - y_pred, self.HR_labels)
+        elif t.gan_type == "relativisticavg":
+            adv = (self.criterion(fake_y_pred - self._mean(y_pred), self.HR_labels)
+                   + self.criterion(y_pred - self._mean(fake_y_pred), self.fake_HR_labels)) / 2.0
+        else:
+            raise NotImplementedError(f"Only relativistic and relativisticavg GAN are implemented, not {t.gan_type}")
+
+        feat = torch.zeros(1, device=self.device)
+        if self.feature_extractor is not None:
+            feat = self.feature_D_criterion(self.feature_extractor(HR).detach(), self.feature_extractor(fake_HR))
+        pix = torch.zeros(1, device=self.device)
+        if self.pixel_criterion:
+            pix = self.pixel_criterion(HR, fake_HR)
+
+        g_hr = calculate_gradient_of_wind_field(HR[:, :3], self.x, self.y, Z)
+        g_sr = calculate_gradient_of_wind_field(fake_HR[:, :3], self.x, self.y, Z)
+        n_xy, n_z, n_div, n_div2 = get_norm_factors_of_gradients(g_hr, g_sr, self.dp)
+        l_xy = self.gradient_xy_criterion(g_sr[:, :6] / n_xy, g_hr[:, :6] / n_xy)
+        l_z = self.gradient_z_criterion(g_sr[:, 6:] / n_z, g_hr[:, 6:] / n_z)
+        l_div = self.divergence_criterion((g_hr[:, 0] + g_hr[:, 4] + g_hr[:, 8]) / n_div,
+                                          (g_sr[:, 0] + g_sr[:, 4] + g_sr[:, 8]) / n_div)
+        l_div2 = self.xy_divergence_criterion((g_hr[:, 0] + g_hr[:, 4]) / n_div2,
+                                              (g_sr[:, 0] + g_sr[:, 4]) / n_div2)
+
+        L = {
+            "adversarial": adv * t.adversarial_loss_weight,
+            "feature_D": feat * t.feature_D_loss_weight,
+            "pix": pix * t.pixel_loss_weight,
+            "xy_gradient": l_xy * t.gradient_xy_loss_weight,
+            "z_gradient": l_z * t.gradient_z_loss_weight,
+            "divergence": l_div * t.divergence_loss_weight,
+            "xy_divergence": l_div2 * t.xy_divergence_loss_weight,
+        }
+        physics = torch.stack([L["divergence"], L["xy_divergence"], L["z_gradient"], L["xy_gradient"]])
+        if bool(torch.logical_or(physics.isnan(), physics.isinf()).any()):  # ONE host sync (reference: up to 8)
+            total = L["adversarial"] + L["pix"] + L["feature_D"]
+        else:
+            total = (L["adversarial"] + L["pix"] + L["xy_gradient"] + L["z_gradient"] + L["divergence"]
+                     + L["xy_divergence"] + L["feature_D"])
+        L["total"] = total
+        if training_iteration:
+            total.backward()
+            if not bool(total.isnan() or total.isinf()):
+                self.optimizer_G.step()
+        self.log_G_losses(fake_HR, L, training_iteration)
+        return total
+
+    def update_G(self, LR, HR, Z, it, training_iteration: bool):
+        if training_iteration:
+            self.G.train()
+            fake_HR = self.G(LR, Z)
+            for p in self.D.parameters():
+                p.requires_grad = False
+            self.G.zero_grad(set_to_none=True)
+            y_pred, fake_y_pred = self.D_forward(HR, fake_HR, it, train_D=False)
+            self.calculate_optimize_and_log_G_loss(HR, fake_HR, Z, y_pred, fake_y_pred, True)
+        else:
+            self.G.eval()
+            with torch.no_grad():
+                fake_HR = self.G(LR, Z)
+                y_pred, fake_y_pred = self.D_forward(HR, fake_HR, it, train_D=False)
+                self.calculate_optimize_and_log_G_loss(HR, fake_HR, Z, y_pred, fake_y_pred, False)
+        return fake_HR
+
+    # ------------------------------------------------------------------ D update
+    def log_D_losses(self, loss_D, y_pred, fake_y_pred, training_epoch):
+        if training_epoch:
+            self.D_loss_dict["train_loss"] = loss_D
+        else:
+            self.D_loss_dict["validation_loss"] = loss_D
+            self.hist_dict["D_pred_HR"] = torch.sigmoid(y_pred.detach()).cpu().numpy()[np.newaxis]
+            self.hist_dict["D_pred_SR"] = torch.sigmoid(fake_y_pred.detach()).cpu().numpy()[np.newaxis]
+
+    def update_D(self, HR: torch.Tensor, fake_HR: torch.Tensor, it, training_epoch: bool):
+        if training_epoch:
+            for p in self.D.parameters():
+                p.requires_grad = True
+            self.optimizer_D.zero_grad(set_to_none=True)
+            y_pred, fake_y_pred = self.D_forward(HR, fake_HR, it, train_D=True)
+        else:
+            with torch.no_grad():  # NB D is put in train mode here too, as in the reference (:541-543)
+                y_pred, fake_y_pred = self.D_forward(HR, fake_HR, it, train_D=True)
+        gan_type = self.cfg.training.gan_type
+        if gan_type == "relativistic":
+            loss_D = self.criterion(y_pred - fake_y_pred, self.HR_labels)
+        elif gan_type == "relativisticavg":
+            loss_D = (self.criterion(y_pred - self._mean(fake_y_pred), self.HR_labels)
+                      + self.criterion(fake_y_pred - self._mean(y_pred), self.fake_HR_labels)) / 2.0
+            if torch.all(self.HR_labels == 0.9):
+                loss_D -= 0.1985
+        else:
+            raise NotImplementedError(f"Only relativistic and relativisticavg GAN are implemented, not {gan_type}")
+        if training_epoch:
+            loss_D.backward()
+            self.optimizer_D.step()
+        self.log_D_losses(loss_D, y_pred, fake_y_pred, training_epoch)
+
+    # ------------------------------------------------------------------ the step
+    def compute_losses_and_optimize(self, LR, HR, Z, it, training_iteration: bool = False):
+        self.batch_size = HR.size(0)
+        it_int = int(it)
+        it = torch.tensor(it, device=self.device)
+        self.make_new_labels(it)
+        t = self.cfg.training
+        if self.use_D_feature_extractor_cost and it_int % t.feature_D_update_period == 0:
+            self.feature_extractor = copy.deepcopy(self.D.features)
+            for p in self.feature_extractor.parameters():
+                p.requires_grad = False
+        if training_iteration:
+            period = it_int // self.d_g_train_period
+            if period % (self.d_g_train_ratio + 1) == 0:
+                self.update_G(LR, HR, Z, it, True)
+            else:
+                with torch.no_grad():
+                    self.G.eval()
+                    fake_HR = self.G(LR, Z)
+                self.update_D(HR, fake_HR, it, True)
+            return
+        fake_HR = self.update_G(LR, HR, Z, it, False)
+        self.update_D(HR, fake_HR, it, False)
+        self.metrics_dict["val_PSNR"], self.metrics_dict["Trilinear_PSNR"] = compute_PSNR_for_SR_and_trilinear(
+            LR, HR, fake_HR, self.max_diff_squared, self.epsilon_PSNR, interpolate=True, device=self.device,
+            scale=self.cfg.scale)
+        self.metrics_dict["trilinear_pix_loss"] = self.pixel_criterion(HR, _trilinear(LR, self.cfg.scale))
+
+    def optimize_parameters(self, LR, HR, Z, it):
+        self.compute_losses_and_optimize(LR, HR, Z, it, training_iteration=True)
+
+    def validation(self, LR, HR, Z, it):
+        self.compute_losses_and_optimize(LR, HR, Z, it, training_iteration=False)
+
+    def make_new_labels(self, it):
+        """Real / fake label vectors of this iteration (reference :627-678)."""
+        t = self.cfg.training
+        pred_real, pred_fake = (False, True) if t.flip_labels else (True, False)
+        real = torch.tensor(1.0, device=self.device)
+        fake = torch.tensor(0.0, device=self.device)
+        if t.use_one_sided_label_smoothing and t.flip_labels:
+            fake = torch.tensor(0.1, device=self.device) - 0.1 * it / self.niter
+        elif t.use_one_sided_label_smoothing:
+            real = torch.tensor(0.9, device=self.device) + 0.1 * it / self.niter
+        extra = {} if t.use_noisy_labels else {"noise_stddev": 0.0}
+        self.HR_labels = trainingtricks.noisy_labels(pred_real, self.batch_size, true_label_val=real,
+                                                     false_label_val=fake, device=self.device, **extra).squeeze()
+        self.fake_HR_labels = trainingtricks.noisy_labels(pred_fake, self.batch_size, true_label_val=real,
+                                                          false_label_val=fake, device=self.device, **extra).squeeze()
+
+    # ------------------------------------------------------------------ getters
+    def get_G_train_loss_dict_ref(self):
+        return self.train_G_loss_dict
+
+    def get_G_val_loss_dict_ref(self):
+        return self.validation_G_loss_dict
+
+    def get_D_loss_dict_ref(self):
+        return self.D_loss_dict
+
+    def get_hist_dict_ref(self):
+        return self.hist_dict
+
+    def get_metrics_dict_ref(self):
+        return self.metrics_dict
+
+    def update_learning_rate(self):
+        for s in self.schedulers:
+            s.step()
+
+    def count_params(self):
+        return (sum(p.numel() for p in self.G.parameters()), sum(p.numel() for p in self.D.parameters()))
+
+    def count_trainable_params(self):
+        return (sum(p.numel() for p in self.G.parameters() if p.requires_grad),
+                sum(p.numel() for p in self.D.parameters() if p.requires_grad))
+
+    def __str__(self):
+        g, d = self.count_params()
+        gt, dt = self.count_trainable_params()
+        return (f"*---------------*\nGenerator:\n{g} params, {gt} trainable\n\n{self.G}\n\n"
+                f"*---------------*\nDiscriminator:\n{d} params, {dt} trainable\n\n{self.D}\n")
+
+
+# ---------------------------------------------------------------------- metrics
+def _trilinear(LR, scale):
+    return nn.functional.interpolate(LR[:, :3], scale_factor=(scale, scale, 1), mode="trilinear",
+                                     align_corners=True)
+
+
+def calculate_PSNR(HR: torch.Tensor, fake_HR: torch.Tensor, max_diff_squared=torch.tensor(4.0),
+                   epsilon_PSNR=torch.tensor(1e-8), device=torch.device("cpu")):
+    """10 log10(max^2 / (MSE + eps)), MSE averaged over B*X*Y*Z - channels are summed (reference :730-742)."""
+    w, h, l = HR.shape[2], HR.shape[3], HR.shape[4]
+    mse = torch.sum((HR - fake_HR) ** 2) / (w * h * l * HR.shape[0])
+    return torch.tensor(10, device=device) * math.log10(max_diff_squared / (mse + epsilon_PSNR))
+
+
+def compute_PSNR_for_SR_and_trilinear(LR, HR, fake_HR, max_diff_squared, epsilon_PSNR, interpolate: bool = False,
+                                      device=torch.device("cpu"), scale: int = 4):
+    val = calculate_PSNR(HR, fake_HR, max_diff_squared, epsilon_PSNR, device=device)
+    if not interpolate:
+        return val
+    return val, calculate_PSNR(HR, _trilinear(LR, scale), max_diff_squared, epsilon_PSNR, device=device)
+
+
+def get_norm_factors_of_gradients(HR_wind_gradient: torch.Tensor, SR_wind_gradient: torch.Tensor, dp=None):
+    """[xy-gradient, z-gradient, divergence, xy-divergence] normalisers = max(HR_max, SR_max / 100).
+
+    Batch-global maxima; the z-gradient maximum is taken WITHOUT abs, like the
+    reference (:780-781).  Under data parallelism the 8 maxima are max-reduced
+    across ranks in one collective.
+    """
+    def stats(g):
+        div3 = g[:, 0] + g[:, 4] + g[:, 8]
+        div2 = g[:, 0] + g[:, 4]
+        return torch.stack([g[:, :6].abs().max(), g[:, 6:].max(), div3.abs().max(), div2.abs().max()])
+
+    m = torch.stack([stats(HR_wind_gradient), stats(SR_wind_gradient)])
+    if dp is not None:
+        m = dp.global_max(m.detach())
+    out = torch.max(m[0], m[1] / 100)
+    return [out[0], out[1], out[2], out[3]]

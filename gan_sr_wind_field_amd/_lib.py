@@ -64,11 +64,11 @@ def lib() -> C.CDLL:
     L.wsr_error_string.argtypes = [C.c_int]
     sig = {
         "wsr_conv3d_fwd": [C.POINTER(ConvDesc), vp, vp, vp, C.POINTER(Epilogue), vp],
-        "wsr_conv3d_dgrad": [C.POINTER(ConvDesc), vp, vp, vp, C.c_int, C.c_int, vp],
+        "wsr_conv3d_dgrad": [C.POINTER(ConvDesc), vp, vp, vp, f32, C.c_int, C.c_int, vp],
         "wsr_conv3d_wgrad": [C.POINTER(ConvDesc), vp, vp, vp, vp],
         "wsr_pack_filter": [vp, vp, i32, i32, i32, i32, i32, i32, vp],
-        "wsr_unpack_wgrad": [vp, vp, i32, i32, i32, i32, f32, vp],
-        "wsr_lrelu_bwd_inplace": [vp, i32, i32, vp, i32, i32, i32, i64, f32, i32, vp],
+        "wsr_unpack_wgrad": [vp, vp, i32, i32, i32, i32, f32, i32, vp],
+        "wsr_lrelu_bwd_inplace": [vp, i32, i32, vp, i32, i32, i32, i64, f32, vp, i64, i32, vp],
         "wsr_chan_axpby": [vp, i32, i32, vp, i32, i32, i32, i64, f32, f32, i32, vp],
         "wsr_upsample2_bwd": [vp, vp, i32, i32, i32, i32, i32, i32, vp],
         "wsr_planar_to_ndhwc": [vp, vp, i32, i32, i64, i32, i32, i32, i32, vp],

@@ -32,6 +32,11 @@ def safe_list_from_string(text, target_type: type) -> list:
 
 
 def _read(section, key: str, kind: str):
+    if section.get(key) is None:
+        # missing key or bare key.  (The reference crashes on a bare bool/int key, which
+        # makes its own asINI() dump unloadable whenever a value was None; returning
+        # None keeps every loadable file identical and makes the round trip total.)
+        return [] if kind == "intlist" else None
     if kind == _B:
         return section.getboolean(key)
     if kind == _I:

@@ -338,7 +338,7 @@ extern "C" int wsr_conv3d_fwd(const wsr_conv_t* c, const void* x, const void* w,
 // dgrad: the "output" of the gather GEMM is dx (Cin channels at the conv's input
 // resolution, or at the up-sampled resolution when upsample_xy), the reduction
 // runs over (tap, Cout) of dy.
-extern "C" int wsr_conv3d_dgrad(const wsr_conv_t* c, const void* dy, const void* wt, void* dx,
+extern "C" int wsr_conv3d_dgrad(const wsr_conv_t* c, const void* dy, const void* wt, void* dx, float alpha,
                                 int accumulate, int dx_planar, void* stream) {
   if (!conv_geom_ok(c) || !dy || !wt || !dx) return WSR_EINVAL;
   const int ux = c->upsample_xy ? 2 : 1;
@@ -346,7 +346,7 @@ extern "C" int wsr_conv3d_dgrad(const wsr_conv_t* c, const void* dy, const void*
   a.in = (const char*)dy;
   a.w = (const char*)wt;
   a.out = (char*)dx;
-  a.alpha = 1.f;
+  a.alpha = alpha;
   a.out_planar = dx_planar ? 1 : 0;
   if (accumulate) {
     if (dx_planar) return WSR_EUNSUPPORTED;

@@ -37,21 +37,23 @@ __global__ void pack_filter_kernel(const float* __restrict__ w, typename T::elem
 
 // dst [Cout][Cin][taps] (logical nn.Conv3d layout) += src [Cout][taps][kpad]
 __global__ void unpack_wgrad_kernel(const float* __restrict__ src, float* __restrict__ dst, int Cout, int taps, int Cin,
-                                    int kpad, float scale) {
+                                    int kpad, float scale, int accumulate) {
   const long total = (long)Cout * Cin * taps;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     const int tap = (int)(i % taps);
     const long nc = i / taps;
     const int c = (int)(nc % Cin);
     const int n = (int)(nc / Cin);
-    dst[i] += scale * src[((long)n * taps + tap) * kpad + c];
+    const float v = scale * src[((long)n * taps + tap) * kpad + c];
+    dst[i] = accumulate ? dst[i] + v : v;
   }
 }
 
 // ---- channel-window elementwise ---------------------------------------------------
 template <class T>
 __global__ void lrelu_bwd_kernel(typename T::elem* g, int g_ctot, int g_off, const typename T::elem* y, int y_ctot,
-                                 int y_off, int C, long nvox, float slope) {
+                                 int y_off, int C, long nvox, float slope, const float* __restrict__ chan_scale,
+                                 long vox_per_b) {
   const int c4 = C >> 2;
   const long total = nvox * c4;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
@@ -60,10 +62,13 @@ __global__ void lrelu_bwd_kernel(typename T::elem* g, int g_ctot, int g_off, con
     typename T::elem* gp = g + v * g_ctot + g_off + c;
     float4 gv = ld4<T>(gp);
     const float4 yv = ld4<T>(y + v * y_ctot + y_off + c);
-    gv.x *= yv.x > 0.f ? 1.f : slope;
-    gv.y *= yv.y > 0.f ? 1.f : slope;
-    gv.z *= yv.z > 0.f ? 1.f : slope;
-    gv.w *= yv.w > 0.f ? 1.f : slope;
+    float4 m = make_float4(yv.x > 0.f ? 1.f : slope, yv.y > 0.f ? 1.f : slope, yv.z > 0.f ? 1.f : slope,
+                           yv.w > 0.f ? 1.f : slope);
+    if (chan_scale) {  // Dropout3d keep factors [B][C]; y = lrelu(pre)*scale, so a dropped channel gets 0
+      const float* cs = chan_scale + (v / vox_per_b) * C + c;
+      m.x *= cs[0]; m.y *= cs[1]; m.z *= cs[2]; m.w *= cs[3];
+    }
+    gv.x *= m.x; gv.y *= m.y; gv.z *= m.z; gv.w *= m.w;
     st4<T>(gp, gv);
   }
 }
@@ -287,25 +292,27 @@ extern "C" int wsr_pack_filter(const float* w, void* out, int32_t dtype, int32_t
 }
 
 extern "C" int wsr_unpack_wgrad(const float* src, float* dst, int32_t Cout, int32_t taps, int32_t Cin, int32_t kpad,
-                                float scale, void* stream) {
+                                float scale, int32_t accumulate, void* stream) {
   if (!src || !dst || Cout <= 0 || taps <= 0 || Cin <= 0 || kpad < Cin) return WSR_EINVAL;
   hipLaunchKernelGGL(unpack_wgrad_kernel, dim3(ew_grid((long)Cout * Cin * taps)), dim3(EW_BLOCK), 0,
-                     as_stream(stream), src, dst, Cout, taps, Cin, kpad, scale);
+                     as_stream(stream), src, dst, Cout, taps, Cin, kpad, scale, accumulate);
   WSR_LAUNCH_CHECK();
   return 0;
 }
 
 extern "C" int wsr_lrelu_bwd_inplace(void* g, int32_t g_ctot, int32_t g_off, const void* y, int32_t y_ctot,
-                                     int32_t y_off, int32_t C, int64_t nvox, float slope, int32_t dtype, void* stream) {
-  if (!g || !y || C <= 0 || nvox <= 0) return WSR_EINVAL;
+                                     int32_t y_off, int32_t C, int64_t nvox, float slope, const float* chan_scale,
+                                     int64_t vox_per_b, int32_t dtype, void* stream) {
+  if (!g || !y || C <= 0 || nvox <= 0 || (chan_scale && vox_per_b <= 0)) return WSR_EINVAL;
   if ((C | g_ctot | g_off | y_ctot | y_off) & 3) return WSR_EUNSUPPORTED;
   const long total = nvox * (C >> 2);
   DISPATCH_T(dtype,
              hipLaunchKernelGGL(lrelu_bwd_kernel<BF16>, dim3(ew_grid(total)), dim3(EW_BLOCK), 0, as_stream(stream),
                                 (unsigned short*)g, g_ctot, g_off, (const unsigned short*)y, y_ctot, y_off, C,
-                                (long)nvox, slope),
+                                (long)nvox, slope, chan_scale, (long)vox_per_b),
              hipLaunchKernelGGL(lrelu_bwd_kernel<F32>, dim3(ew_grid(total)), dim3(EW_BLOCK), 0, as_stream(stream),
-                                (float*)g, g_ctot, g_off, (const float*)y, y_ctot, y_off, C, (long)nvox, slope));
+                                (float*)g, g_ctot, g_off, (const float*)y, y_ctot, y_off, C, (long)nvox, slope,
+                                chan_scale, (long)vox_per_b));
   WSR_LAUNCH_CHECK();
   return 0;
 }

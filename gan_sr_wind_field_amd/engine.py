@@ -1,0 +1,629 @@
+"""Fused HIP programs for Generator_3D and Discriminator_3D.features.
+
+A *program* walks the parameter containers of a network once per call and issues
+C-ABI kernel launches on the current HIP stream:
+
+* activations live in NDHWC buffers of the compute dtype (fp32 or bf16);
+* a residual dense block is one ``nf + 4*gc``-channel buffer whose channel windows
+  the convs read and append to (no ``torch.cat``, reference torch_blocks.py:212-214);
+* LeakyReLU, bias, ``*scale + x`` residuals, the Dropout3d channel mask, the
+  nearest x(2,2,1) up-sampling and the final planar fp32 store are conv
+  prologues / epilogues;
+* backward is hand-derived (dgrad / wgrad kernels, LeakyReLU masks recomputed
+  from the saved outputs) and returns all parameter gradients as views of ONE flat
+  fp32 buffer, which is also the data-parallel all-reduce bucket space.
+
+The programs are wrapped in ``torch.autograd.Function`` so the reference-style
+train step (``loss.backward()``, ``torch.optim.Adam``) drives them unchanged.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Callable, Dict, List, Optional, Sequence, Tuple
+
+import torch
+from torch import nn
+
+from . import hip_ops as ops
+from .hip_ops import ConvGeom
+
+Tensor = torch.Tensor
+
+
+def compute_dtype_of(flag) -> torch.dtype:
+    """Map the reference's ``use_mixed_precision`` ctor flag / a dtype / a string."""
+    if isinstance(flag, torch.dtype):
+        return flag
+    if isinstance(flag, str):
+        return {"fp32": torch.float32, "f32": torch.float32, "bf16": torch.bfloat16}[flag.lower()]
+    return torch.bfloat16 if flag else torch.float32
+
+
+class FilterCache:
+    """Packed (and transposed) compute copies of the fp32 master filters, re-packed
+    only when a parameter changed (optimizer step / load_state_dict)."""
+
+    def __init__(self):
+        self._c: Dict[tuple, tuple] = {}
+
+    def get(self, p: Tensor, dt: torch.dtype, transpose: bool, kpad: int, rows_pad: int) -> Tensor:
+        key = (id(p), dt, transpose, kpad, rows_pad)
+        stamp = (p._version, p.data_ptr(), p.device)
+        hit = self._c.get(key)
+        if hit is not None and hit[0] == stamp:
+            return hit[1]
+        w = p.detach()
+        if w.dim() == 2:  # never used for Linear; guard
+            raise ValueError("filters are 5-D")
+        w = w.contiguous()
+        rows = w.shape[1] if transpose else w.shape[0]
+        taps = w[0, 0].numel()
+        if rows_pad > rows:
+            out = torch.zeros((rows_pad, taps, kpad), dtype=dt, device=w.device)
+        else:
+            out = torch.empty((rows, taps, kpad), dtype=dt, device=w.device)
+        ops.pack_filter(w, dt, transpose=transpose, kpad=kpad, out=out)
+        self._c[key] = (stamp, out)
+        return out
+
+    def clear(self):
+        self._c.clear()
+
+
+@dataclass
+class ConvSite:
+    """One convolution of a program: parameter + static geometry."""
+
+    name: str                 # state_dict key prefix (without .weight)
+    weight: nn.Parameter
+    bias: Optional[nn.Parameter]
+    kernel: Tuple[int, int, int]
+    stride: Tuple[int, int, int] = (1, 1, 1)
+    pad: Tuple[int, int, int] = (1, 1, 1)
+    upsample: bool = False
+
+    @property
+    def cin(self) -> int:
+        return self.weight.shape[1]
+
+    @property
+    def cout(self) -> int:
+        return self.weight.shape[0]
+
+    @property
+    def taps(self) -> int:
+        return self.kernel[0] * self.kernel[1] * self.kernel[2]
+
+
+def site_from_conv(name: str, conv: nn.Conv3d, upsample: bool = False) -> ConvSite:
+    return ConvSite(name, conv.weight, conv.bias, tuple(conv.kernel_size), tuple(conv.stride),
+                    tuple(conv.padding), upsample)
+
+
+class GradSpace:
+    """Flat fp32 gradient buffer of a program; parameter gradients are views.
+
+    Slots are laid out in *backward production order* so that contiguous ranges
+    become final early and can be all-reduced while the rest of backward runs.
+    """
+
+    def __init__(self, params: Sequence[nn.Parameter]):
+        self.params = list(params)
+        self.offsets: Dict[int, Tuple[int, int]] = {}
+        off = 0
+        for p in self.params:
+            n = p.numel()
+            self.offsets[id(p)] = (off, n)
+            off += (n + 63) // 64 * 64  # 256-byte aligned slots
+        self.total = off
+
+    def new(self, device) -> Tensor:
+        return torch.empty(self.total, dtype=torch.float32, device=device)
+
+    def view(self, flat: Tensor, p: nn.Parameter) -> Tensor:
+        off, n = self.offsets[id(p)]
+        return flat[off:off + n].view(p.shape)
+
+
+class ProgramBase:
+    def __init__(self, dt: torch.dtype):
+        self.dt = dt
+        self.e = ops.piece_elems(dt)
+        self.filters = FilterCache()
+        #: optional hook(flat_grad, lo, hi) called when grad range [lo, hi) is final
+        self.grad_ready_hook: Optional[Callable[[Tensor, int, int], None]] = None
+
+    def cp(self, c: int) -> int:
+        """channel count padded to whole 16-byte pieces"""
+        return (c + self.e - 1) // self.e * self.e
+
+    # ---- conv helpers --------------------------------------------------------
+    def _w(self, s: ConvSite) -> Tensor:
+        return self.filters.get(s.weight, self.dt, False, self.cp(s.cin), s.cout)
+
+    def _wt(self, s: ConvSite) -> Tensor:
+        return self.filters.get(s.weight, self.dt, True, self.cp(s.cout), self.cp(s.cin))
+
+    def _desc(self, s: ConvSite, B: int, in_xyz, in_ctot: int, in_off: int, out_ctot: int, out_off: int,
+              cin: Optional[int] = None, cout: Optional[int] = None):
+        g = ConvGeom(s.cin, s.cout, s.kernel, s.stride, s.pad, s.upsample)
+        return ops.make_desc(g, self.dt, B, in_xyz, in_ctot, in_off, out_ctot, out_off, cin=cin, cout=cout)
+
+    def conv(self, s: ConvSite, x: Tensor, x_off: int, y: Tensor, y_off: int, **ep) -> None:
+        """forward conv reading window [x_off, x_off+cp(cin)) of x, writing [y_off, y_off+cout) of y"""
+        B = x.shape[0]
+        planar = ep.get("out_planar", False)
+        d = self._desc(s, B, tuple(x.shape[1:4]), x.shape[-1], x_off, s.cout if planar else y.shape[-1],
+                       0 if planar else y_off, cin=self.cp(s.cin))
+        bias = s.bias.detach() if s.bias is not None else None
+        ops.conv_fwd(d, x, self._w(s), y, bias=bias, **ep)
+
+    def dgrad(self, s: ConvSite, g: Tensor, g_off: int, dx: Tensor, dx_off: int, in_xyz, *, alpha: float = 1.0,
+              accumulate: bool = False, dx_planar: bool = False) -> None:
+        """dx[window] (+)= alpha * conv^T(g[window]);  in_xyz = stored input extent of the conv"""
+        B = g.shape[0]
+        cin = s.cin if dx_planar else self.cp(s.cin)
+        d = self._desc(s, B, tuple(in_xyz), s.cin if dx_planar else dx.shape[-1], 0 if dx_planar else dx_off,
+                       g.shape[-1], g_off, cin=cin, cout=self.cp(s.cout))
+        ops.conv_dgrad(d, g, self._wt(s), dx, alpha=alpha, accumulate=accumulate, dx_planar=dx_planar)
+
+    def wgrad(self, s: ConvSite, x: Tensor, x_off: int, g: Tensor, g_off: int, flat: Tensor, space: GradSpace,
+              scratch: Tensor, scale: float = 1.0) -> None:
+        """master-layout gradient slot of s.weight = scale * wgrad(x[window], g[window])"""
+        B = x.shape[0]
+        cin_p = self.cp(s.cin)
+        d = self._desc(s, B, tuple(x.shape[1:4]), x.shape[-1], x_off, g.shape[-1], g_off, cin=cin_p)
+        n = s.cout * s.taps * cin_p
+        dwp = scratch[:n]
+        dwp.zero_()
+        ops.conv_wgrad(d, x, g, dwp)
+        ops.unpack_wgrad(dwp.view(s.cout, s.taps, cin_p), space.view(flat, s.weight), scale=scale, accumulate=False)
+
+    @staticmethod
+    def wgrad_scratch_elems(sites: Sequence[ConvSite], e: int) -> int:
+        return max(s.cout * s.taps * ((s.cin + e - 1) // e * e) for s in sites)
+
+    def _empty(self, shape, like: Tensor, zero: bool = False) -> Tensor:
+        f = torch.zeros if zero else torch.empty
+        return f(shape, dtype=self.dt, device=like.device)
+
+
+# =============================================================================
+# Generator
+# =============================================================================
+class GeneratorProgram(ProgramBase):
+    """Forward / backward of ``Generator_3D`` (reference Generator_3D_Resnet_ESRGAN.py:225-229)."""
+
+    def __init__(self, G: nn.Module, dt: torch.dtype):
+        super().__init__(dt)
+        m = G.model
+        self.slope = G.slope
+        self.dropout_p = G.hr_convs[1].p
+        self.feature = site_from_conv("model.0.0", m[0][0])
+        trunk = m[1].module
+        self.rrdbs: List[List[Tuple[List[ConvSite], ConvSite, float]]] = []
+        self.rrdb_scales: List[float] = []
+        n_rrdb = len(trunk) - 1
+        for r in range(n_rrdb):
+            rr = trunk[r]
+            rdbs = []
+            for d, rdb in enumerate(rr.RDBs):
+                convs = [site_from_conv(f"model.1.module.{r}.RDBs.{d}.conv{i}.conv.0", getattr(rdb, f"conv{i}").conv[0])
+                         for i in range(rdb.number_of_convs)]
+                lff = site_from_conv(f"model.1.module.{r}.RDBs.{d}.LFF", rdb.LFF)
+                rdbs.append((convs, lff, float(rdb.residual_scaling)))
+            self.rrdbs.append(rdbs)
+            self.rrdb_scales.append(float(rr.RRDB_residual_scaling))
+        self.lr_conv = site_from_conv(f"model.1.module.{n_rrdb}.0", trunk[n_rrdb][0])
+        self.ups = [site_from_conv(f"model.{2 + u}.1.0", m[2 + u][1][0], upsample=True) for u in range(len(m) - 2)]
+        self.terrain0 = site_from_conv("terrain_convs.0.0", G.terrain_convs[0][0])
+        self.terrain1 = site_from_conv("terrain_convs.1.0", G.terrain_convs[1][0])
+        self.hr0 = site_from_conv("hr_convs.0.0", G.hr_convs[0][0])
+        self.hr1 = site_from_conv("hr_convs.2", G.hr_convs[2])
+        self.nf = self.feature.cout
+        self.gc = self.rrdbs[0][0][0][0].cout if self.rrdbs and self.rrdbs[0][0][0] else 0
+        self.tf = self.terrain1.cout
+        if self.nf % self.e or (self.gc % self.e):
+            raise ValueError(f"num_features ({self.nf}) and RDB_growth_chan ({self.gc}) must be multiples of "
+                             f"{self.e} for compute dtype {dt}")
+        # backward production order (first produced first) for the flat gradient space
+        order: List[nn.Parameter] = [self.hr1.weight, self.hr1.bias, self.hr0.weight, self.terrain1.weight,
+                                     self.terrain0.weight]
+        order += [u.weight for u in reversed(self.ups)]
+        order.append(self.lr_conv.weight)
+        for rdbs in reversed(self.rrdbs):
+            for convs, lff, _ in reversed(rdbs):
+                order += [lff.weight, lff.bias] + [c.weight for c in reversed(convs)]
+        order.append(self.feature.weight)
+        self.space = GradSpace(order)
+        self.param_list = order
+        self.all_sites = ([self.feature, self.lr_conv, self.terrain0, self.terrain1, self.hr0, self.hr1] + self.ups
+                          + [c for rdbs in self.rrdbs for convs, lff, _ in rdbs for c in convs + [lff]])
+        self._scratch_elems = self.wgrad_scratch_elems(self.all_sites, self.e)
+
+    # ---- forward -------------------------------------------------------------------
+    def forward(self, x: Tensor, Z: Tensor, training: bool, save: bool, drop_scale: Optional[Tensor]):
+        """x (B, Cin, X, Y, nz), Z (B, 1, sX, sY, nz) planar fp32 -> (B, 3, sX, sY, nz) fp32 (+ saved state)"""
+        B, _, X, Y, nz = x.shape
+        nf, gc, tf, sl = self.nf, self.gc, self.tf, self.slope
+        x = x.contiguous().float()
+        Z = Z.contiguous().float()
+        cin_p = self.cp(self.feature.cin)
+        x_nd = self._empty((B, X, Y, nz, cin_p), x)
+        ops.planar_to_ndhwc(x, x_nd, 0, cin_p)
+        nconv = len(self.rrdbs[0][0][0]) if self.rrdbs else 0
+        dense = nf + nconv * gc
+        total_rdbs = sum(len(r) for r in self.rrdbs)
+        first = self._empty((B, X, Y, nz, dense if total_rdbs else nf), x)
+        self.conv(self.feature, x_nd, 0, first, 0)
+        buf = first
+        bufs: List[Tensor] = []
+        seen = 0
+        for rdbs, rr_scale in zip(self.rrdbs, self.rrdb_scales):
+            rr_in = buf
+            for convs, lff, rdb_scale in rdbs:
+                for i, c in enumerate(convs):
+                    self.conv(c, buf, 0, buf, nf + i * gc, act=True, slope=sl)
+                seen += 1
+                nb = self._empty((B, X, Y, nz, nf if seen == total_rdbs else dense), x)
+                # x + rdb_scale * (LFF(dense) + b)
+                self.conv(lff, buf, 0, nb, 0, alpha=rdb_scale, res=buf, res_off=0, beta=1.0)
+                bufs.append(buf)
+                buf = nb
+            # RRDB residual: out = rr_scale * chain + x_rr
+            ops.chan_axpby(buf, 0, rr_in, 0, nf, alpha=1.0, beta=rr_scale)
+        t_last = buf
+        s = self._empty((B, X, Y, nz, nf), x)
+        self.conv(self.lr_conv, t_last, 0, s, 0, res=first, res_off=0, beta=1.0)
+        sX, sY = X * (2 ** len(self.ups)), Y * (2 ** len(self.ups))
+        cat_c = self.cp(nf + tf)
+        hcat = self._empty((B, sX, sY, nz, cat_c), x, zero=cat_c != nf + tf)
+        cur = s
+        up_io: List[Tuple[Tensor, Tensor]] = []
+        for u, site in enumerate(self.ups):
+            last = u == len(self.ups) - 1
+            out = hcat if last else self._empty((B, cur.shape[1] * 2, cur.shape[2] * 2, nz, nf), x)
+            self.conv(site, cur, 0, out, 0, act=True, slope=sl)
+            up_io.append((cur, out))
+            cur = out
+        if not self.ups:
+            ops.chan_axpby(hcat, 0, s, 0, nf)
+        z_p = self.cp(1)
+        z_nd = self._empty((B, sX, sY, nz, z_p), x)
+        ops.planar_to_ndhwc(Z, z_nd, 0, z_p)
+        tf_p = self.cp(tf)
+        t0 = self._empty((B, sX, sY, nz, tf_p), x, zero=tf_p != tf)
+        self.conv(self.terrain0, z_nd, 0, t0, 0, act=True, slope=sl)
+        self.conv(self.terrain1, t0, 0, hcat, nf)
+        h = self._empty((B, sX, sY, nz, cat_c), x, zero=cat_c != nf + tf)
+        self.conv(self.hr0, hcat, 0, h, 0, act=True, slope=sl, chan_scale=drop_scale)
+        out = torch.empty((B, self.hr1.cout, sX, sY, nz), dtype=torch.float32, device=x.device)
+        self.conv(self.hr1, h, 0, out, 0, out_planar=True)
+        saved = None
+        if save:
+            saved = dict(x_nd=x_nd, first=first, bufs=bufs, t_last=t_last, s=s, up_io=up_io, hcat=hcat, z_nd=z_nd,
+                         t0=t0, h=h, drop=drop_scale, lr_xyz=(X, Y, nz), hr_xyz=(sX, sY, nz))
+        return out, saved
+
+    # ---- backward ------------------------------------------------------------------
+    def backward(self, saved: dict, g_out: Tensor) -> Tensor:
+        """g_out (B, 3, sX, sY, nz) fp32 -> flat fp32 gradient buffer (see ``self.space``)."""
+        nf, gc, tf, sl = self.nf, self.gc, self.tf, self.slope
+        dev = g_out.device
+        B = g_out.shape[0]
+        X, Y, nz = saved["lr_xyz"]
+        sX, sY, _ = saved["hr_xyz"]
+        flat = self.space.new(dev)
+        scratch = torch.empty(self._scratch_elems, dtype=torch.float32, device=dev)
+        sp = self.space
+        done = 0
+
+        def ready(*params):
+            nonlocal done
+            if self.grad_ready_hook is None:
+                return
+            hi = max(sp.offsets[id(p)][0] + (sp.offsets[id(p)][1] + 63) // 64 * 64 for p in params)
+            if hi > done:
+                self.grad_ready_hook(flat, done, hi)
+                done = hi
+
+        g_out = g_out.contiguous().float()
+        # ---- hr1 (k5, bias, planar out)
+        co_p = self.cp(self.hr1.cout)
+        g3 = self._empty((B, sX, sY, nz, co_p), g_out)
+        ops.planar_to_ndhwc(g_out, g3, 0, co_p)
+        h, hcat = saved["h"], saved["hcat"]
+        self.wgrad(self.hr1, h, 0, g3, 0, flat, sp, scratch)
+        sp.view(flat, self.hr1.bias).copy_(g_out.sum(dim=(0, 2, 3, 4)))
+        cat_c = h.shape[-1]
+        gh = self._empty(h.shape, g_out)
+        self.dgrad(self.hr1, g3, 0, gh, 0, (sX, sY, nz))
+        ready(self.hr1.weight, self.hr1.bias)
+        del g3
+        # ---- hr0 (k5 + LReLU + Dropout3d mask)
+        ops.lrelu_bwd_(gh, 0, h, 0, cat_c, sl, chan_scale=self._drop_padded(saved["drop"], cat_c))
+        self.wgrad(self.hr0, hcat, 0, gh, 0, flat, sp, scratch)
+        ghcat = self._empty(hcat.shape, g_out)
+        self.dgrad(self.hr0, gh, 0, ghcat, 0, (sX, sY, nz))
+        ready(self.hr0.weight)
+        del gh
+        # ---- terrain branch (channels nf.. of the concat)
+        t0, z_nd = saved["t0"], saved["z_nd"]
+        self.wgrad(self.terrain1, t0, 0, ghcat, nf, flat, sp, scratch)
+        gt0 = self._empty(t0.shape, g_out)
+        self.dgrad(self.terrain1, ghcat, nf, gt0, 0, (sX, sY, nz))
+        ops.lrelu_bwd_(gt0, 0, t0, 0, t0.shape[-1], sl)
+        self.wgrad(self.terrain0, z_nd, 0, gt0, 0, flat, sp, scratch)
+        ready(self.terrain1.weight, self.terrain0.weight)
+        del gt0
+        # ---- up-convs, last to first.  g lives in window [0, nf) of gbuf
+        gbuf = ghcat
+        for site, (inp, outp) in zip(reversed(self.ups), reversed(saved["up_io"])):
+            ops.lrelu_bwd_(gbuf, 0, outp, 0, nf, sl)
+            self.wgrad(site, inp, 0, gbuf, 0, flat, sp, scratch)
+            fine = self._empty((B, inp.shape[1] * 2, inp.shape[2] * 2, nz, nf), g_out)
+            self.dgrad(site, gbuf, 0, fine, 0, tuple(inp.shape[1:4]))
+            gin = self._empty(inp.shape, g_out)
+            ops.upsample2_bwd(fine, gin)
+            ready(site.weight)
+            del fine
+            gbuf = gin
+        if not self.ups:
+            gs = self._empty((B, X, Y, nz, nf), g_out)
+            ops.chan_axpby(gs, 0, ghcat, 0, nf)
+            gbuf = gs
+        del ghcat
+        gs = gbuf  # grad of s = f + lr_conv(t_last)
+        # ---- lr_conv
+        self.wgrad(self.lr_conv, saved["t_last"], 0, gs, 0, flat, sp, scratch)
+        g = self._empty((B, X, Y, nz, nf), g_out)
+        self.dgrad(self.lr_conv, gs, 0, g, 0, (X, Y, nz))
+        ready(self.lr_conv.weight)
+        # ---- trunk
+        bufs = saved["bufs"]
+        bi = len(bufs)
+        dense = bufs[0].shape[-1] if bufs else nf
+        gd = self._empty((B, X, Y, nz, dense), g_out) if bufs else None
+        for rdbs, rr_scale in zip(reversed(self.rrdbs), reversed(self.rrdb_scales)):
+            g_skip = g  # d(out)/d(x_rr) through the RRDB shortcut
+            go = self._empty(g.shape, g_out)
+            ops.chan_axpby(go, 0, g, 0, nf, alpha=rr_scale)
+            for convs, lff, rdb_scale in reversed(rdbs):
+                bi -= 1
+                buf = bufs[bi]
+                # LFF (1x1x1, bias): out = rdb_scale * (LFF(buf) + b) + x
+                self.wgrad(lff, buf, 0, go, 0, flat, sp, scratch, scale=rdb_scale)
+                sp.view(flat, lff.bias).copy_(go.float().sum(dim=(0, 1, 2, 3)) * rdb_scale)
+                self.dgrad(lff, go, 0, gd, 0, (X, Y, nz), alpha=rdb_scale)
+                for i in reversed(range(len(convs))):
+                    off = nf + i * gc
+                    ops.lrelu_bwd_(gd, off, buf, off, gc, sl)
+                    self.wgrad(convs[i], buf, 0, gd, off, flat, sp, scratch)
+                    self.dgrad(convs[i], gd, off, gd, 0, (X, Y, nz), accumulate=True)
+                ops.chan_axpby(go, 0, gd, 0, nf, alpha=1.0, beta=1.0)  # + grad through the dense input
+                ready(lff.weight, lff.bias, *[c.weight for c in convs])
+            ops.chan_axpby(go, 0, g_skip, 0, nf, alpha=1.0, beta=1.0)
+            g = go
+        # ---- feature conv: total grad of f = trunk path + skip path
+        ops.chan_axpby(g, 0, gs, 0, nf, alpha=1.0, beta=1.0)
+        self.wgrad(self.feature, saved["x_nd"], 0, g, 0, flat, sp, scratch)
+        ready(self.feature.weight)
+        return flat
+
+    def _drop_padded(self, drop: Optional[Tensor], c: int) -> Optional[Tensor]:
+        if drop is None or drop.shape[1] == c:
+            return drop
+        out = torch.zeros((drop.shape[0], c), dtype=torch.float32, device=drop.device)
+        out[:, :drop.shape[1]] = drop
+        return out
+
+
+class _GeneratorFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, Z, prog: GeneratorProgram, training: bool, save: bool, drop_scale, *params):
+        out, saved = prog.forward(x, Z, training, save, drop_scale)
+        ctx.prog, ctx.saved = prog, saved
+        return out
+
+    @staticmethod
+    def backward(ctx, g_out):
+        prog, saved = ctx.prog, ctx.saved
+        if saved is None:
+            raise RuntimeError("Generator_3D backward without saved activations")
+        flat = prog.backward(saved, g_out)
+        ctx.saved = None
+        grads = tuple(prog.space.view(flat, p) if p.requires_grad else None for p in prog.param_list)
+        return (None, None, None, None, None, None) + grads
+
+
+def run_generator(prog: GeneratorProgram, x: Tensor, Z: Tensor, training: bool,
+                  drop_scale: Optional[Tensor] = None) -> Tensor:
+    """``drop_scale`` (B, nf+tf) overrides the Dropout3d RNG (tests share one mask with the oracle)."""
+    if drop_scale is None and training and prog.dropout_p > 0:
+        keep = 1.0 - prog.dropout_p
+        drop_scale = torch.bernoulli(torch.full((x.shape[0], prog.hr0.cout), keep, device=x.device)) / keep
+    # autograd disables grad mode inside Function.forward, so decide here whether to keep activations
+    save = torch.is_grad_enabled() and any(p.requires_grad for p in prog.param_list)
+    return _GeneratorFn.apply(x, Z, prog, training, save, drop_scale, *prog.param_list)
+
+
+# =============================================================================
+# Discriminator feature pyramid
+# =============================================================================
+@dataclass
+class DLayer:
+    conv: ConvSite
+    bn: Optional[nn.BatchNorm3d]
+    act: bool
+
+
+class DiscriminatorProgram(ProgramBase):
+    """conv (+BatchNorm3d) + LeakyReLU pyramid of ``Discriminator_3D.features``
+    (reference Discriminator_3D.py:66-169, torch_blocks.py:372-521)."""
+
+    #: set by dist.py: all-reduce (sum) of a small fp32 tensor across the DP group, or None
+    stat_allreduce: Optional[Callable[[Tensor], None]] = None
+
+    def __init__(self, layers: Sequence[DLayer], slope: float, dt: torch.dtype):
+        super().__init__(dt)
+        self.layers = list(layers)
+        self.slope = slope
+        order: List[nn.Parameter] = []
+        for l in reversed(self.layers):
+            if l.bn is not None:
+                order += [l.bn.weight, l.bn.bias]
+            order.append(l.conv.weight)
+        self.space = GradSpace(order)
+        self.param_list = order
+        self._scratch_elems = self.wgrad_scratch_elems([l.conv for l in self.layers], self.e)
+        for l in self.layers:
+            if l.bn is not None and (l.conv.cout > 256 or 256 % l.conv.cout or l.conv.cout % self.e):
+                raise ValueError(f"BatchNorm3d kernels need a channel count dividing 256 and a multiple of {self.e} "
+                                 f"for {dt}; got {l.conv.cout}")
+
+    def forward(self, x: Tensor, training: bool, save: bool):
+        """x (B, C, X, Y, Z) planar fp32 -> NDHWC feature tensor (+ saved state)"""
+        sl = self.slope
+        B = x.shape[0]
+        x = x.contiguous().float()
+        c0 = self.cp(self.layers[0].conv.cin)
+        h = self._empty((B,) + tuple(x.shape[2:]) + (c0,), x)
+        ops.planar_to_ndhwc(x, h, 0, c0)
+        recs = []
+        for l in self.layers:
+            s = l.conv
+            g = ConvGeom(s.cin, s.cout, s.kernel, s.stride, s.pad)
+            oxyz = g.out_extent(*h.shape[1:4])
+            cp_out = self.cp(s.cout)
+            y = self._empty((B,) + oxyz + (cp_out,), x, zero=cp_out != s.cout)
+            if l.bn is None:
+                self.conv(s, h, 0, y, 0, act=l.act, slope=sl)
+                recs.append(dict(inp=h, y=None, a=y, mean=None, invstd=None))
+                h = y
+                continue
+            self.conv(s, h, 0, y, 0)
+            bn = l.bn
+            C_ = s.cout
+            n = y.numel() // y.shape[-1]
+            if training:
+                sums = torch.zeros(2 * C_, dtype=torch.float32, device=x.device)
+                ops.bn_stats(y, sums)
+                count = float(n)
+                if self.stat_allreduce is not None:
+                    packed = torch.cat((sums, sums.new_tensor([count])))
+                    self.stat_allreduce(packed)
+                    sums, count = packed[:-1], float(packed[-1])
+                mean = sums[:C_] / count
+                var = (sums[C_:] / count - mean * mean).clamp_min_(0.0)
+                invstd = torch.rsqrt(var + bn.eps)
+                with torch.no_grad():  # nn.BatchNorm3d bookkeeping (momentum, unbiased running var)
+                    if bn.track_running_stats:
+                        bn.num_batches_tracked += 1
+                        mom = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked)
+                        bn.running_mean.mul_(1 - mom).add_(mean, alpha=mom)
+                        bn.running_var.mul_(1 - mom).add_(var * (count / max(count - 1.0, 1.0)), alpha=mom)
+            else:
+                mean = bn.running_mean.detach().float()
+                invstd = torch.rsqrt(bn.running_var.detach().float() + bn.eps)
+                count = float(n)
+            a = self._empty(y.shape, x)
+            ops.bn_apply_lrelu(y, a, mean, invstd, bn.weight.detach(), bn.bias.detach(), l.act, sl)
+            recs.append(dict(inp=h, y=y, a=a, mean=mean, invstd=invstd, count=count, training=training))
+            h = a
+        saved = dict(recs=recs, in_shape=tuple(x.shape)) if save else None
+        return h, saved
+
+    def backward(self, saved: dict, g_feat: Tensor, need_dx: bool, need_dw: bool):
+        """g_feat NDHWC (compute dtype) -> (dx planar fp32 | None, flat grads | None)"""
+        sl = self.slope
+        dev = g_feat.device
+        flat = self.space.new(dev) if need_dw else None
+        scratch = torch.empty(self._scratch_elems, dtype=torch.float32, device=dev) if need_dw else None
+        sp = self.space
+        done = 0
+        g = g_feat.contiguous()
+        dx = None
+        recs = saved["recs"]
+        for li in reversed(range(len(self.layers))):
+            l, r = self.layers[li], recs[li]
+            s = l.conv
+            C_ = s.cout
+            if l.bn is None:
+                if l.act:
+                    ops.lrelu_bwd_(g, 0, r["a"], 0, g.shape[-1], sl)
+                gy = g
+            else:
+                bn = l.bn
+                gy = self._empty(r["y"].shape, g)
+                if r["training"]:
+                    sums = torch.zeros(2 * C_, dtype=torch.float32, device=dev)
+                    ops.bn_bwd_reduce(g, r["a"], r["y"], r["mean"], r["invstd"], l.act, sl, sums)
+                    if need_dw:
+                        sp.view(flat, bn.bias).copy_(sums[:C_])
+                        sp.view(flat, bn.weight).copy_(sums[C_:])
+                    if self.stat_allreduce is not None:
+                        sums = sums.clone()
+                        self.stat_allreduce(sums)
+                    ops.bn_bwd_apply(g, r["y"], gy, r["mean"], r["invstd"], bn.weight.detach(), sums,
+                                     1.0 / r["count"])
+                else:
+                    if l.act:
+                        ops.lrelu_bwd_(g, 0, r["a"], 0, g.shape[-1], sl)
+                    if need_dw:  # eval-mode BN: d beta = sum g, d gamma = sum g * xhat
+                        sums = torch.zeros(2 * C_, dtype=torch.float32, device=dev)
+                        ops.bn_bwd_reduce(g, r["a"], r["y"], r["mean"], r["invstd"], False, sl, sums)
+                        sp.view(flat, bn.bias).copy_(sums[:C_])
+                        sp.view(flat, bn.weight).copy_(sums[C_:])
+                    ops.bn_bwd_apply(g, r["y"], gy, r["mean"], r["invstd"], bn.weight.detach(), None, 0.0)
+            inp = r["inp"]
+            if need_dw:
+                self.wgrad(s, inp, 0, gy, 0, flat, sp, scratch)
+                if self.grad_ready_hook is not None:
+                    hi = sp.offsets[id(s.weight)][0] + (s.weight.numel() + 63) // 64 * 64
+                    self.grad_ready_hook(flat, done, hi)
+                    done = hi
+            if li > 0:
+                gin = self._empty(inp.shape, g)
+                self.dgrad(s, gy, 0, gin, 0, tuple(inp.shape[1:4]))
+                g = gin
+            elif need_dx:
+                dx = torch.empty(saved["in_shape"], dtype=torch.float32, device=dev)
+                self.dgrad(s, gy, 0, dx, 0, tuple(inp.shape[1:4]), dx_planar=True)
+        return dx, flat
+
+
+class _DiscriminatorFeaturesFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, prog: DiscriminatorProgram, training: bool, save: bool, *params):
+        feat, saved = prog.forward(x, training, save)
+        ctx.prog, ctx.saved = prog, saved
+        ctx.feat_c = prog.layers[-1].conv.cout
+        # logical (B, C, X, Y, Z) fp32 view for the (tiny) classifier head
+        return feat[..., :ctx.feat_c].permute(0, 4, 1, 2, 3).float()
+
+    @staticmethod
+    def backward(ctx, g_out):
+        prog, saved = ctx.prog, ctx.saved
+        if saved is None:
+            raise RuntimeError("Discriminator_3D.features backward without saved activations")
+        need_dx = ctx.needs_input_grad[0]
+        need_dw = any(ctx.needs_input_grad[4:])
+        c = ctx.feat_c
+        cp_ = prog.cp(c)
+        g = g_out.permute(0, 2, 3, 4, 1)
+        if cp_ != c:
+            gp = torch.zeros(g.shape[:-1] + (cp_,), dtype=prog.dt, device=g.device)
+            gp[..., :c] = g
+            g = gp
+        else:
+            g = g.to(prog.dt).contiguous()
+        dx, flat = prog.backward(saved, g, need_dx, need_dw)
+        ctx.saved = None
+        grads = tuple(prog.space.view(flat, p) if (need_dw and ctx.needs_input_grad[4 + i]) else None
+                      for i, p in enumerate(prog.param_list))
+        return (dx, None, None, None) + grads
+
+
+def run_discriminator_features(prog: DiscriminatorProgram, x: Tensor, training: bool) -> Tensor:
+    save = torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in prog.param_list))
+    return _DiscriminatorFeaturesFn.apply(x, prog, training, save, *prog.param_list)

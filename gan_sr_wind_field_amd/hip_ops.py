@@ -107,11 +107,11 @@ def conv_fwd(desc: ConvDesc, x: Tensor, w: Tensor, y: Tensor, *, bias: Optional[
     return y
 
 
-def conv_dgrad(desc: ConvDesc, dy: Tensor, wt: Tensor, dx: Tensor, *, accumulate: bool = False,
-               dx_planar: bool = False) -> Tensor:
+def conv_dgrad(desc: ConvDesc, dy: Tensor, wt: Tensor, dx: Tensor, *, alpha: float = 1.0,
+               accumulate: bool = False, dx_planar: bool = False) -> Tensor:
     _need_cuda(dy, wt, dx)
-    check(_lib.lib().wsr_conv3d_dgrad(C.byref(desc), _p(dy), _p(wt), _p(dx), int(accumulate), int(dx_planar),
-                                      _stream()), "conv3d_dgrad")
+    check(_lib.lib().wsr_conv3d_dgrad(C.byref(desc), _p(dy), _p(wt), _p(dx), alpha, int(accumulate),
+                                      int(dx_planar), _stream()), "conv3d_dgrad")
     return dx
 
 
@@ -142,19 +142,21 @@ def pack_filter(w: Tensor, dt: torch.dtype, *, transpose: bool = False, kpad: Op
     return out
 
 
-def unpack_wgrad(src: Tensor, dst: Tensor, scale: float = 1.0) -> None:
-    """master-layout grad ``(Cout, Cin, KX, KY, KZ)`` += scale * packed ``[Cout][taps][kpad]``."""
+def unpack_wgrad(src: Tensor, dst: Tensor, scale: float = 1.0, accumulate: bool = True) -> None:
+    """master-layout grad ``(Cout, Cin, KX, KY, KZ)`` (+)= scale * packed ``[Cout][taps][kpad]``."""
     cout, taps, kpad = src.shape
     if dst.dtype != torch.float32 or not dst.is_contiguous() or dst.shape[0] != cout:
         raise ValueError("unpack_wgrad wants a contiguous fp32 master-layout gradient")
-    check(_lib.lib().wsr_unpack_wgrad(_p(src), _p(dst), cout, taps, dst.shape[1], kpad, scale, _stream()),
-          "unpack_wgrad")
+    check(_lib.lib().wsr_unpack_wgrad(_p(src), _p(dst), cout, taps, dst.shape[1], kpad, scale, int(accumulate),
+                                      _stream()), "unpack_wgrad")
 
 
-def lrelu_bwd_(g: Tensor, g_off: int, y: Tensor, y_off: int, C_: int, slope: float) -> None:
+def lrelu_bwd_(g: Tensor, g_off: int, y: Tensor, y_off: int, C_: int, slope: float,
+               chan_scale: Optional[Tensor] = None) -> None:
     nvox = g.numel() // g.shape[-1]
     check(_lib.lib().wsr_lrelu_bwd_inplace(_p(g), g.shape[-1], g_off, _p(y), y.shape[-1], y_off, C_, nvox, slope,
-                                           dtype_id(g.dtype), _stream()), "lrelu_bwd")
+                                           _p(chan_scale), nvox // g.shape[0], dtype_id(g.dtype), _stream()),
+          "lrelu_bwd")
 
 
 def chan_axpby(dst: Tensor, d_off: int, src: Tensor, s_off: int, C_: int, alpha: float = 1.0,

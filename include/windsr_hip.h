@@ -83,9 +83,9 @@ int wsr_conv3d_fwd(const wsr_conv_t* c, const void* x, const void* w, void* y,
  * [Cin][KX][KY][KZ][Cout] (wsr_pack_filter with transpose=1).  dx gets channel
  * window [in_off, in_off+Cin) of an `in_ctot` buffer at the conv's *stored*
  * input resolution unless upsample_xy, in which case dx is at 2Xi x 2Yi and
- * wsr_upsample2_bwd folds it.  accumulate=1: dx += result.  dx_planar=1: dx
+ * wsr_upsample2_bwd folds it.  dx = alpha*result (+ dx if accumulate).  dx_planar=1: dx
  * is an fp32 planar (B, Cin, X, Y, Z) tensor (gradient w.r.t. a network input).  */
-int wsr_conv3d_dgrad(const wsr_conv_t* c, const void* dy, const void* wt, void* dx,
+int wsr_conv3d_dgrad(const wsr_conv_t* c, const void* dy, const void* wt, void* dx, float alpha,
                      int accumulate, int dx_planar, void* stream);
 
 /* aten::convolution_backward, filter gradient: dw[Cout][taps][Cin] fp32 (packed
@@ -103,16 +103,17 @@ int wsr_conv3d_wgrad(const wsr_conv_t* c, const void* x, const void* dy, float* 
 int wsr_pack_filter(const float* w, void* out, int32_t dtype, int32_t Cout, int32_t taps,
                     int32_t Cin, int32_t transpose, int32_t kpad, void* stream);
 /* Filter gradient back to the master layout:
- * dst (Cout, Cin, taps) += scale * src [Cout][taps][kpad] (fp32).              */
+ * dst (Cout, Cin, taps) = scale * src [Cout][taps][kpad] (+ dst if accumulate).  */
 int wsr_unpack_wgrad(const float* src, float* dst, int32_t Cout, int32_t taps, int32_t Cin,
-                     int32_t kpad, float scale, void* stream);
+                     int32_t kpad, float scale, int32_t accumulate, void* stream);
 
 /* ---- elementwise / normalisation ---------------------------------------------
  * leaky_relu_backward from the saved OUTPUT sign, in place on a channel window
- * (torch_blocks.py:35 autograd):  g *= (y > 0 ? 1 : slope).                    */
+ * (torch_blocks.py:35 autograd):  g *= (y > 0 ? 1 : slope), optionally also
+ * times the Dropout3d keep factor chan_scale[b*C + c] (Generator_3D...py:104).  */
 int wsr_lrelu_bwd_inplace(void* g, int32_t g_ctot, int32_t g_off, const void* y, int32_t y_ctot,
-                          int32_t y_off, int32_t C, int64_t nvox, float slope, int32_t dtype,
-                          void* stream);
+                          int32_t y_off, int32_t C, int64_t nvox, float slope,
+                          const float* chan_scale, int64_t vox_per_b, int32_t dtype, void* stream);
 /* copy / axpby on channel windows: dst = alpha*src (+ beta*dst)                */
 int wsr_chan_axpby(void* dst, int32_t d_ctot, int32_t d_off, const void* src, int32_t s_ctot,
                    int32_t s_off, int32_t C, int64_t nvox, float alpha, float beta, int32_t dtype,

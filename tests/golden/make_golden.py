@@ -306,8 +306,23 @@ def gen_init_manifest():
     save("init_manifest.npz", **arrays)
 
 
+def gen_config_golden():
+    """Parsed values + INI round trip of the reference Config on its shipped local ini."""
+    import json
+    cfg = RefConfig(os.path.join(REF, "config", "wind_field_GAN_3D_config_local.ini"))
+    sections = {"DEFAULT": {k: v for k, v in vars(cfg).items()}}
+    for name in ("env", "gan_config", "generator", "discriminator", "training", "dataset_train", "dataset_val",
+                 "dataset_test"):
+        sections[name] = dict(vars(getattr(cfg, name)))
+    with open(os.path.join(HERE, "config_golden.json"), "w") as f:
+        json.dump({"sections": sections, "asINI": cfg.asINI()}, f, indent=1, default=str)
+    print("wrote config_golden.json")
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["conv", "blocks", "G", "D", "physics", "trace", "init"]
+    which = sys.argv[1:] or ["conv", "blocks", "G", "D", "physics", "trace", "init", "config"]
+    if "config" in which:
+        gen_config_golden()
     if "conv" in which:
         gen_conv_cases()
     if "blocks" in which:

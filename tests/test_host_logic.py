@@ -1,0 +1,228 @@
+"""CPU tests of the host side: config drop-in, seeded init, state_dict manifest,
+the C-ABI library's exports, and the train-step control flow of the product's
+``wind_field_GAN_3D`` driven with oracle-backed networks against loss traces
+recorded from the real reference.
+"""
+import ctypes
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN, REPO, rel_l2
+
+PKG = os.path.join(REPO, "gan_sr_wind_field_amd")
+LOCAL_INI = os.path.join(PKG, "config", "wind_field_GAN_3D_config_local.ini")
+
+
+def test_config_matches_reference_values(tmp_path):
+    from gan_sr_wind_field_amd.config.config import Config
+
+    gold = json.load(open(os.path.join(GOLDEN, "config_golden.json")))["sections"]
+    cfg = Config(LOCAL_INI)
+    mine = {"DEFAULT": dict(vars(cfg))}
+    for name in ("env", "gan_config", "generator", "discriminator", "training", "dataset_train", "dataset_val",
+                 "dataset_test"):
+        mine[name] = dict(vars(getattr(cfg, name)))
+    for sec, vals in gold.items():
+        for k, v in vals.items():
+            if (sec, k) in (("env", "root_path"),):
+                continue
+            assert k in mine[sec], (sec, k)
+            got = mine[sec][k]
+            assert got == v or str(got) == str(v), (sec, k, got, v)
+        # same attribute ORDER too (it is what asINI() prints)
+        keys = [k for k in mine[sec] if k in vals]
+        assert keys == list(vals.keys()), sec
+    # bare keys -> None ; blank gpu_id -> CPU
+    assert cfg.env.generator_load_path is None and cfg.gpu_id == 0
+    # INI round trip (config.py docstring promise): str(cfg) re-parses to the same values
+    p = tmp_path / "round.ini"
+    p.write_text(cfg.asINI())
+    again = Config(str(p))
+    assert vars(again.training) == vars(cfg.training)
+    assert vars(again.generator) == vars(cfg.generator)
+    assert again.scale == cfg.scale and again.gpu_id == cfg.gpu_id
+
+
+def test_config_asini_text_layout():
+    """Section headers / None-as-bare-key formatting equal the reference's asINI()."""
+    from gan_sr_wind_field_amd.config.config import Config
+
+    gold = json.load(open(os.path.join(GOLDEN, "config_golden.json")))["asINI"]
+    text = Config(LOCAL_INI).asINI()
+    heads = re.findall(r"^\[(\w+)\]$", text, re.M)
+    assert heads == re.findall(r"^\[(\w+)\]$", gold, re.M)
+    for sec in ("GAN", "GENERATOR", "DISCRIMINATOR", "TRAINING", "DATASETTRAIN", "DATASETVAL", "DATASETTEST"):
+        a = text.split(f"[{sec}]\n")[1].split("\n\n")[0]
+        b = gold.split(f"[{sec}]\n")[1].split("\n\n")[0]
+        assert a == b, sec
+
+
+def test_shipped_inis_parse():
+    from gan_sr_wind_field_amd.config.config import Config
+
+    c = Config(os.path.join(PKG, "config", "wind_field_GAN_3D_config_cluster.ini"))
+    assert c.dataset_train.batch_size == 32 and c.training.niter == 150000
+    u = Config(os.path.join(PKG, "config", "wind_field_GAN_3D_config_upscale8.ini"))
+    assert u.scale == 8 and u.gan_config.enable_slicing is False
+
+
+def test_abi_library_exports_every_declared_symbol():
+    """libwindsr_hip.so loads and exports each function include/windsr_hip.h declares."""
+    from gan_sr_wind_field_amd import _lib
+
+    header = open(os.path.join(REPO, "include", "windsr_hip.h")).read()
+    declared = set(re.findall(r"\b(wsr_[a-z0-9_]+)\s*\(", header))
+    declared -= {"wsr_conv", "wsr_epilogue"}
+    assert len(declared) >= 17
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    for name in sorted(declared):
+        assert hasattr(lib, name), f"{name} declared in windsr_hip.h but not exported"
+    assert set(_lib.EXPORTS) == declared
+    assert _lib.lib().wsr_abi_version() == 1
+    assert b"invalid" in _lib.lib().wsr_error_string(-1)
+
+
+def test_no_cpu_fallback():
+    """The product networks refuse CPU tensors instead of silently using ATen."""
+    from gan_sr_wind_field_amd.CNN_models.Generator_3D_Resnet_ESRGAN import Generator_3D
+    from gan_sr_wind_field_amd.CNN_models.Discriminator_3D import Discriminator_3D
+
+    G = Generator_3D(4, 3, 16, 1, upscale=4, hr_kern_size=5, RDB_gc=8, terrain_number_of_features=8)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        G(torch.zeros(1, 4, 4, 4, 4), torch.zeros(1, 1, 16, 16, 4))
+    D = Discriminator_3D(3, 4, number_of_z_layers=4, enable_slicing=True)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        D(torch.zeros(1, 3, 64, 64, 4))
+    with pytest.raises(RuntimeError):
+        G.model[1](torch.zeros(1))  # blocks are recipes, not standalone layers
+
+
+def test_product_never_imports_oracle():
+    for root, _, files in os.walk(PKG):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(root, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", src, re.M), f
+                assert "/root/reference" not in src, f
+
+
+def test_seeded_init_and_manifest_match_reference(golden):
+    """Same seed -> same initial weights as the reference (construction order, apply
+    order and the scripted-RDB_Conv init quirk), same keys and shapes."""
+    from gan_sr_wind_field_amd.CNN_models.Discriminator_3D import Discriminator_3D
+    from gan_sr_wind_field_amd.CNN_models.Generator_3D_Resnet_ESRGAN import Generator_3D
+    from gan_sr_wind_field_amd.tools import initialization
+
+    g = golden("init_manifest.npz")
+    torch.manual_seed(2001)
+    G = Generator_3D(4, 3, 128, 16, upscale=4, hr_kern_size=5, number_of_RDB_convs=5, RDB_gc=32, lff_kern_size=1,
+                     terrain_number_of_features=16, dropout_probability=0.1)
+    initialization.init_weights(G, scale=0.1)
+    D = Discriminator_3D(3, 32, feat_kern_size=3, number_of_z_layers=10, enable_slicing=True,
+                         dropout_probability=0.2)
+    initialization.init_weights(D, scale=0.2)
+    for net, tag in ((G, "G"), (D, "D")):
+        sd = net.state_dict()
+        assert list(sd.keys()) == [str(k) for k in g[f"{tag}.keys"]]
+        assert [str(tuple(v.shape)) for v in sd.values()] == [str(s) for s in g[f"{tag}.shapes"]]
+        sums = np.array([float(v.double().abs().sum()) for v in sd.values()])
+        np.testing.assert_allclose(sums, g[f"{tag}.abs_sum"], rtol=1e-12)
+        first = np.array([float(v.reshape(-1)[0]) if v.numel() else 0.0 for v in sd.values()])
+        np.testing.assert_allclose(first, g[f"{tag}.first"], rtol=0, atol=0)
+    assert sum(p.numel() for p in G.parameters()) == int(g["G.n_params"])
+    assert sum(p.numel() for p in D.parameters()) == int(g["D.n_params"])
+
+
+def _make_gan(monkeypatch, use_noise, dropout):
+    from gan_sr_wind_field_amd.config.config import Config
+    from gan_sr_wind_field_amd.GAN_models import wind_field_GAN_3D as mod
+    import oracle_nets
+    from oracle import nets as onets
+
+    monkeypatch.setattr(mod, "Generator_3D", oracle_nets.OracleGenerator)
+    monkeypatch.setattr(mod, "Discriminator_3D", oracle_nets.OracleDiscriminator)
+    cfg = Config(LOCAL_INI)
+    cfg.is_train, cfg.is_test, cfg.is_use = True, False, False
+    cfg.gpu_id = None
+    cfg.device = torch.device("cpu")
+    cfg.generator.num_features, cfg.generator.num_RRDB, cfg.generator.RDB_growth_chan = 16, 1, 8
+    cfg.generator.terrain_number_of_features = 4
+    cfg.generator.dropout_probability = dropout
+    cfg.discriminator.num_features = 4
+    cfg.discriminator.dropout_probability = dropout
+    cfg.gan_config.number_of_z_layers = 4
+    cfg.training.use_instance_noise = use_noise
+    cfg.training.niter = 150000
+    cfg.training.d_g_train_period = 2
+    torch.manual_seed(2001)
+    gan = mod.wind_field_GAN_3D(cfg)
+    gs = onets.GSpec(in_channels=4, nf=16, n_rrdb=1, gc=8, tf=4, hr_kern=5, upscale=4, dropout_p=dropout)
+    ds = onets.DSpec(bf=4, nz=4, enable_slicing=True, dropout_p=dropout)
+    gan.G.load_state_dict(onets.deterministic_state(onets.g_param_shapes(gs), seed=41, scale=0.5))
+    gan.D.load_state_dict(onets.deterministic_state(onets.d_param_shapes(ds), seed=43, scale=1.0))
+    return gan, cfg
+
+
+@pytest.mark.parametrize("tag,use_noise,dropout", [("plain", False, 0.0), ("noise", True, 0.1)])
+def test_gan_step_reproduces_reference_trace(monkeypatch, golden, tag, use_noise, dropout):
+    """Product wind_field_GAN_3D (+Config, labels, noise, losses, Adam, MultiStepLR, G/D
+    alternation) with oracle nets == loss / weight trace of the reference, it = 1..6."""
+    from oracle.gan import synthetic_batch
+
+    g = golden(f"gan_trace_{tag}.npz")
+    gan, cfg = _make_gan(monkeypatch, use_noise, dropout)
+    LR, HR, Z, x, y = synthetic_batch(2, 16, 4, 4, seed=2001)
+    gan.feed_xy_niter(x, y, torch.tensor(cfg.training.niter), cfg.training.d_g_train_ratio,
+                      cfg.training.d_g_train_period)
+    torch.manual_seed(4242)
+    keys = ["total", "adversarial", "pix", "xy_gradient", "z_gradient", "divergence", "xy_divergence", "feature_D"]
+    for row, it in enumerate(g["its"]):
+        gan.optimize_parameters(LR, HR, Z, int(it))
+        if int(it) > 2 * cfg.training.d_g_train_period:
+            gan.update_learning_rate()
+        got = [float(gan.get_G_train_loss_dict_ref()[k]) for k in keys]
+        np.testing.assert_allclose(got, g["G_losses"][row], rtol=2e-4, atol=1e-7, err_msg=f"it={it}")
+        np.testing.assert_allclose(float(gan.get_D_loss_dict_ref()["train_loss"]), g["D_loss"][row], rtol=2e-4,
+                                   atol=1e-6, err_msg=f"it={it}")
+        sdG, sdD = gan.G.state_dict(), gan.D.state_dict()
+        wg = [float(sdG[k].double().abs().sum())
+              for k in ("model.0.0.weight", "hr_convs.2.weight", "model.1.module.0.RDBs.1.LFF.bias")]
+        wd = [float(sdD[k].double().abs().sum())
+              for k in ("features.0.0.0.weight", "classifier.2.weight", "features.1.1.1.running_var")]
+        np.testing.assert_allclose(wg, g["wsum_g"][row], rtol=1e-5, err_msg=f"it={it}")
+        np.testing.assert_allclose(wd, g["wsum_d"][row], rtol=1e-5, err_msg=f"it={it}")
+        assert abs(gan.optimizer_G.param_groups[0]["lr"] - g["lr"][row]) < 1e-12
+    assert gan.get_new_status_logs() and gan.get_new_status_logs() == []
+
+
+def test_validation_and_checkpoint_roundtrip(monkeypatch, tmp_path):
+    from oracle.gan import synthetic_batch
+
+    gan, cfg = _make_gan(monkeypatch, False, 0.0)
+    LR, HR, Z, x, y = synthetic_batch(2, 16, 4, 4, seed=2001)
+    gan.feed_xy_niter(x, y, torch.tensor(150000), 1, 2)
+    gan.optimize_parameters(LR, HR, Z, 1)
+    rm_before = gan.D.state_dict()["features.1.1.1.running_mean"].clone()
+    gan.validation(LR, HR, Z, 1)
+    # D runs in train mode during validation (reference quirk): BN running stats move
+    assert not torch.equal(rm_before, gan.D.state_dict()["features.1.1.1.running_mean"])
+    m = gan.get_metrics_dict_ref()
+    assert all(np.isfinite(float(m[k])) for k in ("val_PSNR", "Trilinear_PSNR", "pix_loss_unscaled",
+                                                  "trilinear_pix_loss"))
+    assert float(gan.get_G_val_loss_dict_ref()["total"]) > 0
+    cfg.env.this_runs_folder = str(tmp_path)
+    gan.save_model(str(tmp_path), epoch=3, it=7)
+    assert sorted(os.listdir(tmp_path)) == ["D_7.pth", "G_7.pth", "state_7.pth"]
+    before = {k: v.clone() for k, v in gan.G.state_dict().items()}
+    gan.optimize_parameters(LR, HR, Z, 2)
+    epoch, it = gan.load_model(str(tmp_path / "G_7.pth"), str(tmp_path / "D_7.pth"), str(tmp_path / "state_7.pth"))
+    assert (epoch, it) == (3, 7)
+    for k, v in gan.G.state_dict().items():
+        assert torch.equal(v, before[k]), k
+    assert gan.load_model(None, "None", "null") == (None, None)
+    assert "Generator:" in str(gan)
