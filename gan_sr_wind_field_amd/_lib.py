@@ -73,7 +73,7 @@ def lib() -> C.CDLL:
         "wsr_upsample2_bwd": [vp, vp, i32, i32, i32, i32, i32, i32, vp],
         "wsr_planar_to_ndhwc": [vp, vp, i32, i32, i64, i32, i32, i32, i32, vp],
         "wsr_ndhwc_to_planar": [vp, vp, i32, i32, i64, i32, i32, i32, vp],
-        "wsr_bn_stats": [vp, i32, i64, vp, i32, vp],
+        "wsr_bn_stats": [vp, i32, i64, vp, vp, i32, vp],
         "wsr_bn_apply_lrelu": [vp, vp, vp, vp, vp, vp, i32, i64, i32, f32, i32, vp],
         "wsr_bn_bwd_reduce": [vp, vp, vp, vp, vp, i32, i64, i32, f32, vp, i32, vp],
         "wsr_bn_bwd_apply": [vp, vp, vp, vp, vp, vp, vp, f32, i32, i64, i32, vp],

@@ -151,13 +151,16 @@ __global__ void ndhwc_to_planar_kernel(const typename T::elem* __restrict__ src,
 // threads sharing a channel, then one float atomic per channel per workgroup.
 template <class T>
 __global__ __launch_bounds__(256) void bn_stats_kernel(const typename T::elem* __restrict__ x, int C, long nvox,
-                                                      float* sums) {
+                                                      const float* __restrict__ shift_c, float* sums) {
+  // sums of d = x - shift[c] and d^2.  Called twice per layer: shift = 0 gives the mean,
+  // shift = mean gives a variance free of the E[x^2] - mean^2 cancellation.
   __shared__ float s1[256], s2[256];
   const long total = nvox * C;
   const long stride = (long)gridDim.x * 256;
+  const float shift = shift_c ? shift_c[threadIdx.x % C] : 0.f;
   float a = 0.f, b = 0.f;
   for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += stride) {
-    const float v = ldf<T>(x + i);
+    const float v = ldf<T>(x + i) - shift;
     a += v;
     b += v * v;
   }
@@ -383,15 +386,16 @@ static inline int bn_grid(long total) {
   return (int)g;
 }
 
-extern "C" int wsr_bn_stats(const void* x, int32_t C, int64_t nvox, float* sums, int32_t dtype, void* stream) {
+extern "C" int wsr_bn_stats(const void* x, int32_t C, int64_t nvox, const float* shift, float* sums, int32_t dtype,
+                            void* stream) {
   if (!x || !sums || C <= 0 || nvox <= 0) return WSR_EINVAL;
   if (C > 256 || 256 % C) return WSR_EUNSUPPORTED;
   const int grid = bn_grid(nvox * C);
   DISPATCH_T(dtype,
              hipLaunchKernelGGL(bn_stats_kernel<BF16>, dim3(grid), dim3(256), 0, as_stream(stream),
-                                (const unsigned short*)x, C, (long)nvox, sums),
+                                (const unsigned short*)x, C, (long)nvox, shift, sums),
              hipLaunchKernelGGL(bn_stats_kernel<F32>, dim3(grid), dim3(256), 0, as_stream(stream), (const float*)x, C,
-                                (long)nvox, sums));
+                                (long)nvox, shift, sums));
   WSR_LAUNCH_CHECK();
   return 0;
 }

@@ -1,0 +1,163 @@
+"""Data parallelism for the GAN train step: one process per GPU over
+``torch.distributed`` (backend "nccl" = RCCL over xGMI on MI355X; "gloo" for tests).
+
+The reference has no distributed code (single ``cuda:{gpu_id}``); this is the
+extension the MI355X build adds.  ``attach(gan)`` makes an N-rank step equal the
+single-GPU step on the concatenated batch:
+
+* G / D filter gradients live in the programs' flat fp32 buffers laid out in backward
+  production order; as ranges become final they are all-reduced (average) in
+  ``bucket_mb`` buckets, asynchronously on the collective's own stream, while the
+  rest of backward keeps the compute stream busy.  xGMI is point-to-point, a ring
+  all-reduce is per-link bound, so buckets are large (default 32 MB: 139 MB of G
+  gradients = 5 collectives) rather than DDP's 25 MB-of-small-tensors default;
+* BatchNorm3d batch statistics (forward sums, backward sums) are sum-reduced
+  (SyncBN), the RaGAN average logits are batch-global means with a matching
+  backward, the four physics-loss normalisers are max-reduced;
+* parameters and BN buffers are broadcast from rank 0 at attach time; RNG streams
+  for dropout / instance noise are offset per rank.
+
+No collective is issued on the data path of a forward conv: samples are independent.
+"""
+from __future__ import annotations
+
+import os
+from typing import List, Optional
+
+import torch
+import torch.distributed as dist
+
+Tensor = torch.Tensor
+
+
+def init_from_env(backend: Optional[str] = None) -> bool:
+    """Initialise the default process group from torchrun's environment.  Returns False
+    (and does nothing) for a single-process run."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world <= 1:
+        return False
+    if not dist.is_initialized():
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        if backend == "nccl":
+            torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+        dist.init_process_group(backend=backend)
+    return True
+
+
+class _BatchMean(torch.autograd.Function):
+    """mean over the global batch: forward all-reduces (sum, count); backward all-reduces
+    the upstream gradient because every rank's loss depends on every rank's logits."""
+
+    @staticmethod
+    def forward(ctx, t: Tensor, group):
+        packed = torch.stack([t.sum().float(), torch.tensor(float(t.numel()), device=t.device)])
+        dist.all_reduce(packed, group=group)
+        ctx.group, ctx.count, ctx.shape, ctx.dtype = group, float(packed[1]), t.shape, t.dtype
+        return (packed[0] / packed[1]).to(t.dtype)
+
+    @staticmethod
+    def backward(ctx, g: Tensor):
+        g = g.clone().float()
+        dist.all_reduce(g, group=ctx.group)
+        # the later gradient average over ranks divides by N once more, exactly as it does
+        # for every other term of the per-rank mean losses
+        return (g / ctx.count).to(ctx.dtype).expand(ctx.shape), None
+
+
+class DataParallel:
+    def __init__(self, group=None, bucket_mb: float = 32.0, sync_bn: bool = True):
+        if not dist.is_initialized():
+            raise RuntimeError("torch.distributed is not initialised (use init_from_env or torchrun)")
+        self.group = group
+        self.world = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+        self.bucket_elems = max(1, int(bucket_mb * 1024 * 1024 / 4))
+        self.sync_bn = sync_bn
+        self._avg_native = dist.get_backend(group) == "nccl"
+        self._pending: List = []      # (work, tensor) of in-flight gradient buckets
+        self._open = {}               # program id -> [flat, lo, hi] of the bucket being filled
+        self.n_collectives = 0        # bookkeeping for tests / DESIGN.md numbers
+
+    # ---- collectives used inside the step ----------------------------------------
+    def batch_mean(self, t: Tensor) -> Tensor:
+        return _BatchMean.apply(t, self.group)
+
+    def global_max(self, t: Tensor) -> Tensor:
+        t = t.clone()
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+        return t
+
+    def stat_allreduce(self, t: Tensor) -> None:
+        dist.all_reduce(t, group=self.group)
+
+    def _avg_async(self, t: Tensor) -> None:
+        if self._avg_native:
+            work = dist.all_reduce(t, op=dist.ReduceOp.AVG, group=self.group, async_op=True)
+        else:
+            work = dist.all_reduce(t, group=self.group, async_op=True)
+        self._pending.append((work, t))
+        self.n_collectives += 1
+
+    # ---- gradient buckets ------------------------------------------------------------
+    def grad_ready(self, key, flat: Tensor, lo: int, hi: int) -> None:
+        """range [lo, hi) of ``flat`` is final; launch a collective once a bucket is full"""
+        cur = self._open.get(key)
+        if cur is None or cur[0] is not flat:
+            cur = [flat, lo, lo]
+            self._open[key] = cur
+        cur[2] = hi
+        if cur[2] - cur[1] >= self.bucket_elems:
+            self._avg_async(flat[cur[1]:cur[2]])
+            cur[1] = cur[2]
+
+    def grad_done(self, key) -> None:
+        """end of a program's backward: flush the partial bucket and wait for all of them"""
+        cur = self._open.pop(key, None)
+        if cur is not None and cur[2] > cur[1]:
+            self._avg_async(cur[0][cur[1]:cur[2]])
+        self.wait()
+
+    def wait(self) -> None:
+        for work, t in self._pending:
+            work.wait()
+            if not self._avg_native:
+                t.div_(self.world)
+        self._pending.clear()
+
+    # ---- wiring --------------------------------------------------------------------------
+    def broadcast_module(self, module: torch.nn.Module) -> None:
+        for t in list(module.parameters()) + list(module.buffers()):
+            dist.broadcast(t.data, src=0, group=self.group)
+
+    def attach(self, gan) -> "DataParallel":
+        """Wire a ``wind_field_GAN_3D`` for data-parallel training."""
+        gan.dp = self
+        self.broadcast_module(gan.G)
+        progG = gan.G.program() if hasattr(gan.G, "program") else None
+        if progG is not None:
+            progG.grad_ready_hook = lambda flat, lo, hi: self.grad_ready("G", flat, lo, hi)
+            progG.grad_done_hook = lambda: self.grad_done("G")
+        if getattr(gan, "D", None) is not None:
+            self.broadcast_module(gan.D)
+            feats = gan.D.features
+            progD = feats.program() if hasattr(feats, "program") else None
+            if progD is not None:
+                progD.grad_ready_hook = lambda flat, lo, hi: self.grad_ready("D", flat, lo, hi)
+                progD.grad_done_hook = lambda: self.grad_done("D")
+                if self.sync_bn:
+                    progD.stat_allreduce = self.stat_allreduce
+            # the classifier head is ordinary torch autograd: reduce its 4 small tensors per step
+            for p in gan.D.classifier.parameters():
+                p.register_post_accumulate_grad_hook(lambda p_: self._avg_async(p_.grad))
+        for opt in getattr(gan, "optimizers", []):
+            opt.register_step_pre_hook(lambda *_: self.wait())
+        # decorrelate dropout / instance-noise streams across ranks
+        torch.manual_seed(torch.initial_seed() + 7919 * self.rank)
+        return self
+
+
+def attach(gan, bucket_mb: float = 32.0, sync_bn: bool = True, group=None) -> DataParallel:
+    return DataParallel(group, bucket_mb, sync_bn).attach(gan)

@@ -132,6 +132,10 @@ class ProgramBase:
         self.filters = FilterCache()
         #: optional hook(flat_grad, lo, hi) called when grad range [lo, hi) is final
         self.grad_ready_hook: Optional[Callable[[Tensor, int, int], None]] = None
+        #: optional hook() called at the end of backward (flush + wait for gradient collectives)
+        self.grad_done_hook: Optional[Callable[[], None]] = None
+        #: optional hook(tag, fn) used by bench.py to time selected launches; fn() issues them
+        self.launch_probe: Optional[Callable[[str, Callable[[], None]], None]] = None
 
     def cp(self, c: int) -> int:
         """channel count padded to whole 16-byte pieces"""
@@ -156,7 +160,11 @@ class ProgramBase:
         d = self._desc(s, B, tuple(x.shape[1:4]), x.shape[-1], x_off, s.cout if planar else y.shape[-1],
                        0 if planar else y_off, cin=self.cp(s.cin))
         bias = s.bias.detach() if s.bias is not None else None
-        ops.conv_fwd(d, x, self._w(s), y, bias=bias, **ep)
+        w = self._w(s)
+        if self.launch_probe is not None:
+            self.launch_probe("fwd:" + s.name, lambda: ops.conv_fwd(d, x, w, y, bias=bias, **ep))
+        else:
+            ops.conv_fwd(d, x, w, y, bias=bias, **ep)
 
     def dgrad(self, s: ConvSite, g: Tensor, g_off: int, dx: Tensor, dx_off: int, in_xyz, *, alpha: float = 1.0,
               accumulate: bool = False, dx_planar: bool = False) -> None:
@@ -165,7 +173,12 @@ class ProgramBase:
         cin = s.cin if dx_planar else self.cp(s.cin)
         d = self._desc(s, B, tuple(in_xyz), s.cin if dx_planar else dx.shape[-1], 0 if dx_planar else dx_off,
                        g.shape[-1], g_off, cin=cin, cout=self.cp(s.cout))
-        ops.conv_dgrad(d, g, self._wt(s), dx, alpha=alpha, accumulate=accumulate, dx_planar=dx_planar)
+        wt = self._wt(s)
+        if self.launch_probe is not None:
+            self.launch_probe("dgrad:" + s.name, lambda: ops.conv_dgrad(d, g, wt, dx, alpha=alpha,
+                                                                        accumulate=accumulate, dx_planar=dx_planar))
+        else:
+            ops.conv_dgrad(d, g, wt, dx, alpha=alpha, accumulate=accumulate, dx_planar=dx_planar)
 
     def wgrad(self, s: ConvSite, x: Tensor, x_off: int, g: Tensor, g_off: int, flat: Tensor, space: GradSpace,
               scratch: Tensor, scale: float = 1.0) -> None:
@@ -176,7 +189,10 @@ class ProgramBase:
         n = s.cout * s.taps * cin_p
         dwp = scratch[:n]
         dwp.zero_()
-        ops.conv_wgrad(d, x, g, dwp)
+        if self.launch_probe is not None:
+            self.launch_probe("wgrad:" + s.name, lambda: ops.conv_wgrad(d, x, g, dwp))
+        else:
+            ops.conv_wgrad(d, x, g, dwp)
         ops.unpack_wgrad(dwp.view(s.cout, s.taps, cin_p), space.view(flat, s.weight), scale=scale, accumulate=False)
 
     @staticmethod
@@ -408,6 +424,8 @@ class GeneratorProgram(ProgramBase):
         ops.chan_axpby(g, 0, gs, 0, nf, alpha=1.0, beta=1.0)
         self.wgrad(self.feature, saved["x_nd"], 0, g, 0, flat, sp, scratch)
         ready(self.feature.weight)
+        if self.grad_done_hook is not None:
+            self.grad_done_hook()
         return flat
 
     def _drop_padded(self, drop: Optional[Tensor], c: int) -> Optional[Tensor]:
@@ -506,15 +524,20 @@ class DiscriminatorProgram(ProgramBase):
             C_ = s.cout
             n = y.numel() // y.shape[-1]
             if training:
-                sums = torch.zeros(2 * C_, dtype=torch.float32, device=x.device)
-                ops.bn_stats(y, sums)
-                count = float(n)
+                # pass 1: sum x -> mean ; pass 2: sum (x - mean)^2 -> variance without cancellation
+                s1 = torch.zeros(2 * C_ + 1, dtype=torch.float32, device=x.device)
+                ops.bn_stats(y, s1)
+                s1[-1] = float(n)
                 if self.stat_allreduce is not None:
-                    packed = torch.cat((sums, sums.new_tensor([count])))
-                    self.stat_allreduce(packed)
-                    sums, count = packed[:-1], float(packed[-1])
-                mean = sums[:C_] / count
-                var = (sums[C_:] / count - mean * mean).clamp_min_(0.0)
+                    self.stat_allreduce(s1)
+                count = float(s1[-1]) if self.stat_allreduce is not None else float(n)
+                mean = s1[:C_] / count
+                s2 = torch.zeros(2 * C_, dtype=torch.float32, device=x.device)
+                ops.bn_stats(y, s2, shift=mean)
+                if self.stat_allreduce is not None:
+                    self.stat_allreduce(s2)
+                dm = s2[:C_] / count
+                var = (s2[C_:] / count - dm * dm).clamp_min_(0.0)
                 invstd = torch.rsqrt(var + bn.eps)
                 with torch.no_grad():  # nn.BatchNorm3d bookkeeping (momentum, unbiased running var)
                     if bn.track_running_stats:
@@ -589,6 +612,8 @@ class DiscriminatorProgram(ProgramBase):
             elif need_dx:
                 dx = torch.empty(saved["in_shape"], dtype=torch.float32, device=dev)
                 self.dgrad(s, gy, 0, dx, 0, tuple(inp.shape[1:4]), dx_planar=True)
+        if need_dw and self.grad_done_hook is not None:
+            self.grad_done_hook()
         return dx, flat
 
 

@@ -194,9 +194,11 @@ def ndhwc_to_planar(src: Tensor, C_: int, s_off: int = 0) -> Tensor:
     return dst
 
 
-def bn_stats(x: Tensor, sums: Tensor) -> None:
+def bn_stats(x: Tensor, sums: Tensor, shift: Optional[Tensor] = None) -> None:
+    """sums[2C] += {sum (x - shift), sum (x - shift)^2} per channel"""
     C_ = x.shape[-1]
-    check(_lib.lib().wsr_bn_stats(_p(x), C_, x.numel() // C_, _p(sums), dtype_id(x.dtype), _stream()), "bn_stats")
+    check(_lib.lib().wsr_bn_stats(_p(x), C_, x.numel() // C_, _p(shift), _p(sums), dtype_id(x.dtype), _stream()),
+          "bn_stats")
 
 
 def bn_apply_lrelu(x: Tensor, y: Tensor, mean: Tensor, invstd: Tensor, gamma: Tensor, beta: Tensor, act: bool,

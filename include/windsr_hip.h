@@ -129,8 +129,11 @@ int wsr_ndhwc_to_planar(const void* src, float* dst, int32_t B, int32_t C, int64
                         int32_t s_ctot, int32_t s_off, int32_t dtype, void* stream);
 
 /* BatchNorm3d (torch_blocks.py:20-25) on NDHWC tensors, fp32 statistics.
- * stats: sums[2*C] += {sum x, sum x^2} (caller zeroes).                        */
-int wsr_bn_stats(const void* x, int32_t C, int64_t nvox, float* sums, int32_t dtype, void* stream);
+ * stats: sums[2*C] += {sum d, sum d^2}, d = x - shift[c] (shift NULL = 0; caller
+ * zeroes sums).  Two calls - shift 0, then shift = mean - give a cancellation-free
+ * variance.                                                                     */
+int wsr_bn_stats(const void* x, int32_t C, int64_t nvox, const float* shift, float* sums,
+                 int32_t dtype, void* stream);
 /* y = lrelu((x-mean)*invstd*gamma + beta); mean/invstd fp32 [C]                 */
 int wsr_bn_apply_lrelu(const void* x, void* y, const float* mean, const float* invstd,
                        const float* gamma, const float* beta, int32_t C, int64_t nvox, int32_t act,
