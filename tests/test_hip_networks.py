@@ -98,6 +98,20 @@ def test_generator_dropout_mask_and_train_mode(hip):
     assert torch.isfinite(out2).all() and not torch.equal(out2, out)
 
 
+def _d_grads_fp64(spec, seed, x_seed, xy, nz):
+    """fp64 oracle gradients of the D test graph (train-mode BN), on the CPU."""
+    sd = onets.deterministic_state(onets.d_param_shapes(spec), seed=seed, scale=1.0)
+    sd = {k: (v.double() if v.is_floating_point() else v).clone() for k, v in sd.items()}
+    for k, v in sd.items():
+        if v.is_floating_point() and "running" not in k:
+            v.requires_grad_(True)
+    gen = torch.Generator().manual_seed(x_seed)
+    x = (torch.rand((2, 3, xy, xy, nz), generator=gen) * 2 - 1).double()
+    out = onets.discriminator_forward(sd, x, spec, training=True)
+    (out * torch.tensor([[1.0], [-0.5]], dtype=torch.float64)).sum().backward()
+    return {k: v.grad for k, v in sd.items() if v.is_floating_point() and v.grad is not None}
+
+
 @pytest.mark.parametrize("slicing,xy,nz", [(True, 64, 4), (False, 128, 3), (False, 128, 21)])
 def test_discriminator_fp32_vs_reference(golden, hip, slicing, xy, nz):
     tag = ("slice" if slicing else "full") + f"_z{nz}"
@@ -116,8 +130,16 @@ def test_discriminator_fp32_vs_reference(golden, hip, slicing, xy, nz):
     # g - mean(g) - xhat*mean(g*xhat) cancellation): 1e-3; the shallower cases sit at ~1e-4
     assert rel_l2(x.grad[:, :, ::4, ::4, :], T(g["dx_sub"])) < 1e-3
     assert abs(float(x.grad.double().abs().sum()) / float(g["dx_abs_sum"]) - 1) < 1e-3
+    # The recorded fp32 reference gradients are themselves up to 5.3e-4 away from an fp64
+    # evaluation of the same graph (features.0.0.0.weight of the z21 case: 9 train-mode BN
+    # backward stages over tiny populations), so each key's tolerance is 2e-4 plus 1.5x the
+    # reference's own fp32-vs-fp64 distance, and the HIP result must also sit within
+    # 2e-4 + that distance of the fp64 oracle.
+    ref64 = _d_grads_fp64(spec, 31 + nz, int(g["x_seed"]), xy, nz)
     for k, p in D.named_parameters():
-        assert rel_l2(p.grad, T(g[f"grad.{k}"])) < 5e-4, k
+        floor = rel_l2(T(g[f"grad.{k}"]).double(), ref64[k])
+        assert rel_l2(p.grad, T(g[f"grad.{k}"])) < 2e-4 + 1.5 * floor, (k, floor)
+        assert rel_l2(p.grad.double().cpu(), ref64[k]) < 2e-4 + floor, (k, floor)
     for k, v in D.state_dict().items():
         if "running_" in k or "num_batches" in k:
             assert rel_l2(v.float(), T(g[f"after.{k}"]).float()) < 1e-5, k
