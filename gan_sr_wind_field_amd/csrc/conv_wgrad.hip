@@ -237,8 +237,21 @@ int dispatch_wgrad(WgradArgs& a, hipStream_t st) {
 
 }  // namespace
 
+int wsr_wgrad_tile_bf16(const wsr_conv_t* c, const void* x, const void* dy, float* dw, int tri_base, int tri_step,
+                        void* stream);  // conv_wgrad_tile.hip
+
+extern "C" int wsr_conv3d_wgrad_tri(const wsr_conv_t* c, const void* x, const void* dy, float* dw, int32_t tri_base,
+                                    int32_t tri_step, void* stream) {
+  if (!conv_geom_ok(c) || !x || !dy || !dw || tri_base <= 0 || tri_step <= 0) return WSR_EINVAL;
+  return wsr_wgrad_tile_bf16(c, x, dy, dw, tri_base, tri_step, stream);
+}
+
 extern "C" int wsr_conv3d_wgrad(const wsr_conv_t* c, const void* x, const void* dy, float* dw, void* stream) {
   if (!conv_geom_ok(c) || !x || !dy || !dw) return WSR_EINVAL;
+  {  // stride-1 bf16 convs with more than one tap: LDS-tile kernel (x / dy read once per tile, not per tap)
+    const int rc = wsr_wgrad_tile_bf16(c, x, dy, dw, 0, 0, stream);
+    if (rc != WSR_EUNSUPPORTED) return rc;
+  }
   const int epp = c->dtype == WSR_BF16 ? 8 : 4;
   if (c->Cin % epp || c->in_ctot % epp || c->in_off % epp) return WSR_EUNSUPPORTED;
   if (c->out_ctot % epp || c->out_off % epp) return WSR_EUNSUPPORTED;

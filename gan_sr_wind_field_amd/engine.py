@@ -195,6 +195,34 @@ class ProgramBase:
             ops.conv_wgrad(d, x, g, dwp)
         ops.unpack_wgrad(dwp.view(s.cout, s.taps, cin_p), space.view(flat, s.weight), scale=scale, accumulate=False)
 
+    def wgrad_dense(self, convs: Sequence[ConvSite], buf: Tensor, gd: Tensor, flat: Tensor, space: GradSpace,
+                    scratch: Tensor) -> None:
+        """Filter gradients of all growth convs of one dense block.  bf16: ONE stacked launch
+        (``wsr_conv3d_wgrad_tri``) - conv i reads channels [0, nf + i*gc) of ``buf`` and its output
+        gradient sits in channels [nf + i*gc, nf + (i+1)*gc) of ``gd``; fp32: one launch per conv."""
+        nf, gc = convs[0].cin, convs[0].cout
+        stacked = (self.dt == torch.bfloat16 and len(convs) > 1 and all(
+            c.kernel == convs[0].kernel and c.stride == (1, 1, 1) and c.pad == convs[0].pad and c.cout == gc
+            and c.cin == nf + i * gc and not c.upsample for i, c in enumerate(convs)))
+        if not stacked:
+            for i, c in enumerate(convs):
+                self.wgrad(c, buf, 0, gd, nf + i * gc, flat, space, scratch)
+            return
+        B = buf.shape[0]
+        cin_w, cout = convs[-1].cin, gc * len(convs)
+        g = ConvGeom(cin_w, cout, convs[0].kernel, (1, 1, 1), convs[0].pad)
+        d = ops.make_desc(g, self.dt, B, tuple(buf.shape[1:4]), buf.shape[-1], 0, gd.shape[-1], nf)
+        taps = convs[0].taps
+        dwp = scratch[:cout * taps * cin_w]
+        dwp.zero_()
+        dw3 = dwp.view(cout, taps, cin_w)
+        if self.launch_probe is not None:
+            self.launch_probe("wgrad_tri:" + convs[0].name, lambda: ops.conv_wgrad_tri(d, buf, gd, dw3, nf, gc))
+        else:
+            ops.conv_wgrad_tri(d, buf, gd, dw3, nf, gc)
+        for i, c in enumerate(convs):
+            ops.unpack_wgrad(dw3[i * gc:(i + 1) * gc], space.view(flat, c.weight), accumulate=False)
+
     @staticmethod
     def wgrad_scratch_elems(sites: Sequence[ConvSite], e: int) -> int:
         return max(s.cout * s.taps * ((s.cin + e - 1) // e * e) for s in sites)
@@ -256,6 +284,9 @@ class GeneratorProgram(ProgramBase):
         self.all_sites = ([self.feature, self.lr_conv, self.terrain0, self.terrain1, self.hr0, self.hr1] + self.ups
                           + [c for rdbs in self.rrdbs for convs, lff, _ in rdbs for c in convs + [lff]])
         self._scratch_elems = self.wgrad_scratch_elems(self.all_sites, self.e)
+        if self.rrdbs and self.rrdbs[0][0][0]:
+            c = self.rrdbs[0][0][0]
+            self._scratch_elems = max(self._scratch_elems, len(c) * c[0].cout * c[0].taps * self.cp(c[-1].cin))
 
     # ---- forward -------------------------------------------------------------------
     def forward(self, x: Tensor, Z: Tensor, training: bool, save: bool, drop_scale: Optional[Tensor]):
@@ -414,8 +445,9 @@ class GeneratorProgram(ProgramBase):
                 for i in reversed(range(len(convs))):
                     off = nf + i * gc
                     ops.lrelu_bwd_(gd, off, buf, off, gc, sl)
-                    self.wgrad(convs[i], buf, 0, gd, off, flat, sp, scratch)
                     self.dgrad(convs[i], gd, off, gd, 0, (X, Y, nz), accumulate=True)
+                # all growth-channel gradients of the block are final now: one stacked wgrad
+                self.wgrad_dense(convs, buf, gd, flat, sp, scratch)
                 ops.chan_axpby(go, 0, gd, 0, nf, alpha=1.0, beta=1.0)  # + grad through the dense input
                 ready(lff.weight, lff.bias, *[c.weight for c in convs])
             ops.chan_axpby(go, 0, g_skip, 0, nf, alpha=1.0, beta=1.0)

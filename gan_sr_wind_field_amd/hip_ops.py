@@ -124,6 +124,16 @@ def conv_wgrad(desc: ConvDesc, x: Tensor, dy: Tensor, dw: Tensor) -> Tensor:
     return dw
 
 
+def conv_wgrad_tri(desc: ConvDesc, x: Tensor, dy: Tensor, dw: Tensor, tri_base: int, tri_step: int) -> Tensor:
+    """Stacked filter gradient of a dense block's growth convs (see ``wsr_conv3d_wgrad_tri``)."""
+    _need_cuda(x, dy, dw)
+    if dw.dtype != torch.float32:
+        raise TypeError("filter gradients are fp32")
+    check(_lib.lib().wsr_conv3d_wgrad_tri(C.byref(desc), _p(x), _p(dy), _p(dw), tri_base, tri_step, _stream()),
+          "conv3d_wgrad_tri")
+    return dw
+
+
 def pack_filter(w: Tensor, dt: torch.dtype, *, transpose: bool = False, kpad: Optional[int] = None,
                 out: Optional[Tensor] = None) -> Tensor:
     """fp32 master ``(Cout, Cin, KX, KY, KZ)`` -> compute copy ``[rows][taps][kpad]`` of ``dt``."""

@@ -92,6 +92,15 @@ int wsr_conv3d_dgrad(const wsr_conv_t* c, const void* dy, const void* wt, void* 
  * order) is ACCUMULATED into (caller zeroes it when a fresh gradient is wanted;
  * wsr_unpack_wgrad moves it to the master layout).                             */
 int wsr_conv3d_wgrad(const wsr_conv_t* c, const void* x, const void* dy, float* dw, void* stream);
+/* Filter gradients of ALL growth convs of a residual dense block in one launch
+ * (torch_blocks.py:256-267: conv i reads channels [0, tri_base + i*tri_step) of the
+ * dense buffer and writes tri_step channels).  c describes the stacked conv: Cin =
+ * the widest input window, Cout = n_convs*tri_step, dy = the stacked output
+ * gradients.  Row n of dw belongs to conv n / tri_step; its entries with
+ * c >= tri_base + (n / tri_step)*tri_step are unspecified.  bf16, stride 1 only
+ * (WSR_EUNSUPPORTED otherwise).                                                 */
+int wsr_conv3d_wgrad_tri(const wsr_conv_t* c, const void* x, const void* dy, float* dw, int32_t tri_base,
+                         int32_t tri_step, void* stream);
 
 /* ---- filter packing ----------------------------------------------------------
  * master fp32 (Cout, Cin, KX, KY, KZ) contiguous -> compute copy of `dtype`:

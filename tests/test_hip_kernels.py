@@ -271,3 +271,69 @@ def test_big_shapes_properties(hip):
     f = outs[torch.float32]
     assert rel_l2(f[0] + f[1], f[2]) < 1e-5
     assert rel_l2(outs[torch.bfloat16][0], f[0]) < 1e-2
+
+
+def _cpu_wgrad(x, gy, k, p):
+    """fp32 CPU filter gradient of a stride-1 conv: x (B,Cin,X,Y,Z), gy (B,Cout,X,Y,Z)."""
+    w = torch.zeros((gy.shape[1], x.shape[1]) + tuple(k), requires_grad=True)
+    F.conv3d(x, w, None, 1, p).backward(gy)
+    return w.grad
+
+
+@pytest.mark.parametrize("name,cin,cout,k,xyz,B,ups", [
+    ("hr0_like", 48, 48, (5, 5, 5), (9, 10, 10), 1, False),   # TN=3 config, ragged tiles, nz = 10 (one z tile)
+    ("hr0_z17", 16, 96, (5, 5, 5), (8, 8, 17), 1, False),      # z tiled by 8 with a ragged last tile
+    ("hr1_like", 144, 3, (5, 5, 5), (8, 9, 6), 2, False),      # 3 real output channels in an 8-wide window
+    ("k3_128", 40, 128, (3, 3, 3), (6, 9, 13), 1, False),      # TN=4 config, two n-chunks, ragged c-chunk
+    ("k3_gc", 64, 32, (3, 3, 3), (5, 8, 9), 2, False),         # TN=2 config
+    ("k3_up", 16, 64, (3, 3, 3), (4, 5, 6), 1, True),          # nearest x(2,2,1) folded into the x tile load
+])
+def test_wgrad_tile_kernel_bf16(hip, name, cin, cout, k, xyz, B, ups):
+    """LDS-tile filter-gradient kernel (bf16) vs an fp32 CPU wgrad of the same rounded operands."""
+    o = ops()
+    dt = torch.bfloat16
+    gen = torch.Generator().manual_seed(len(name) + cin)
+    x = torch.randn((B, cin) + tuple(xyz), generator=gen).bfloat16().float()
+    oxyz = (xyz[0] * 2, xyz[1] * 2, xyz[2]) if ups else xyz
+    gy = torch.randn((B, cout) + tuple(oxyz), generator=gen).bfloat16().float()
+    p = tuple(kk // 2 for kk in k)
+    cout_p = o.pad_channels(cout, dt)
+    geom = o.ConvGeom(cin, cout, k, (1, 1, 1), p, upsample=ups)
+    xb = to_ndhwc(x, cin + 16, 8, dt)
+    gb = to_ndhwc(gy, cout_p + 8, 8, dt)
+    d = o.make_desc(geom, dt, B, xyz, cin + 16, 8, cout_p + 8, 8)
+    dwp = torch.zeros((cout, geom.taps, cin), dtype=torch.float32, device=DEV)
+    o.conv_wgrad(d, xb, gb, dwp)
+    dw = torch.zeros((cout, cin) + tuple(k), dtype=torch.float32, device=DEV)
+    o.unpack_wgrad(dwp, dw)
+    xr = x
+    if ups:
+        xr = x.repeat_interleave(2, dim=2).repeat_interleave(2, dim=3)
+    ref = _cpu_wgrad(xr, gy, k, p)
+    assert rel_l2(dw.cpu(), ref) < 2e-5, name  # fp32 accumulation of exact bf16 products
+
+
+def test_wgrad_dense_block_fused(hip):
+    """One launch for the four growth convs of an RDB: conv i reads channels [0, nf + i*gc) of the
+    dense buffer; block-triangular (n, c) structure (reference torch_blocks.py:256-267)."""
+    o = ops()
+    dt = torch.bfloat16
+    nf, gc, nconv = 16, 8, 4
+    B, xyz = 2, (6, 7, 9)
+    gen = torch.Generator().manual_seed(77)
+    dense = nf + nconv * gc
+    x = torch.randn((B, dense) + xyz, generator=gen).bfloat16().float()
+    g = torch.randn((B, dense) + xyz, generator=gen).bfloat16().float()
+    xb = to_ndhwc(x, dense, 0, dt)
+    gb = to_ndhwc(g, dense, 0, dt)
+    cin_w = nf + (nconv - 1) * gc
+    geom = o.ConvGeom(cin_w, nconv * gc, (3, 3, 3))
+    d = o.make_desc(geom, dt, B, xyz, dense, 0, dense, nf)
+    dwp = torch.zeros((nconv * gc, 27, cin_w), dtype=torch.float32, device=DEV)
+    o.conv_wgrad_tri(d, xb, gb, dwp, nf, gc)
+    for i in range(nconv):
+        ci = nf + i * gc
+        dw = torch.zeros((gc, ci, 3, 3, 3), dtype=torch.float32, device=DEV)
+        o.unpack_wgrad(dwp[i * gc:(i + 1) * gc], dw)
+        ref = _cpu_wgrad(x[:, :ci], g[:, nf + i * gc:nf + (i + 1) * gc], (3, 3, 3), (1, 1, 1))
+        assert rel_l2(dw.cpu(), ref) < 2e-5, i
