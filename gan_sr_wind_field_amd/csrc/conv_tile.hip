@@ -1,0 +1,500 @@
+// Stride-1 3-D convolution (forward and input-gradient) from an LDS-resident halo tile, bf16.
+//
+//   y[v, n] = sum_{tap, c} x[v - pad + tap, c] * w[n, tap, c]
+//
+// A workgroup owns one spatial output tile (TX x TY x TZ voxels) and a group of
+// 16-wide output-channel tiles.  The reduction channels are walked in chunks of
+// CK = 32/TPK channels; per chunk the input tile WITH its halo is staged in LDS
+// once and then re-read at a shifted voxel index for every filter tap, so each
+// activation byte leaves L2/HBM once per chunk instead of once per tap (the 5x5x5
+// 144->144 conv re-uses a staged voxel 125 times).  One MFMA K-step (32) covers
+// TPK taps x CK channels:
+//   TPK = 1 : 32 channels of one tap        (1x1x1 convs)
+//   TPK = 2 : 16 channels of a tap pair     (channel counts that are multiples of 16)
+//   TPK = 4 :  8 channels of four taps      (1/3/4-channel tensors padded to 8)
+// Filters are pre-packed in MFMA-fragment order (wsr_pack_filter_frag), streamed
+// through a double-buffered LDS ring one "stage" (a few K-steps) ahead of the
+// MFMAs, and read back conflict-free as linear 1 KB fragments.
+//
+// LDS activation image: octet-major planes [8-channel octet][halo voxel][16 B],
+// plane stride == 0 (mod 256) so the 16 voxel rows of a fragment, contiguous along
+// z, are bank-conflict free for ds_read_b128 at every tap shift.
+//
+// The MFMA is issued as D = W * X^T: a lane ends up with 4 consecutive output
+// channels of one voxel (8-byte vector stores into the NDHWC channel window).
+// The input-gradient pass is the same kernel over dy with the transposed,
+// tap-flipped filter and pad' = K-1-pad.
+#include "common.h"
+
+namespace {
+
+struct CtArgs {
+  const unsigned short* in;
+  const unsigned short* wf;  // fragment-packed filter: [chunk][kstep][ntile][64 lanes][8]
+  void* out;
+  const float* bias;
+  const float* chan_scale;
+  const unsigned short* res;
+  int res_ctot, res_off;
+  float alpha, beta, slope;
+  int act, out_planar;
+  int B, Xi, Yi, Zi, Xo, Yo, Zo, ups;
+  int in_ctot, in_off, nchunks;   // reduction channels = nchunks * CK, window [in_off, ...)
+  int cin_valid;                  // channels of the window that exist in memory (multiple of 8)
+  int Cout, out_ctot, out_off;
+  int KX, KY, KZ, px, py, pz;
+  int TX, TY, TZ;
+  int tiles_x, tiles_y, tiles_z, ntiles;
+  int nts;          // K-steps per chunk = ceil(taps / TPK)
+  int TS;           // K-steps per weight stage
+  int NT_total;     // 16-wide output-channel tiles
+  int ngroups;      // n-tile groups (grid = ntiles * ngroups)
+  int P;            // activation plane stride (bytes)
+  int off_mtab, off_htab, off_vtab, off_ttab, off_xs, off_ws;
+  int vec_ok;
+};
+
+template <int WM, int WN, int TM, int TN, int TPK>
+__global__ __launch_bounds__(WM * WN * 64) void conv_tile_kernel(const CtArgs a) {
+  constexpr int WAVES = WM * WN, NT = WAVES * 64;
+  constexpr int PL = 4 / TPK;      // octet planes per chunk
+  constexpr int CK = 8 * PL;       // channels per chunk
+  constexpr int NTW = WN * TN;     // n-tiles per workgroup
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+
+  const int Lx = a.TX + a.KX - 1, Ly = a.TY + a.KY - 1, Lz = a.TZ + a.KZ - 1;
+  const int L = Lx * Ly * Lz;
+  const int M = a.TX * a.TY * a.TZ;  // <= MR
+  constexpr int MR = WM * TM * 16;    // MFMA rows of the workgroup
+  const int taps = a.KX * a.KY * a.KZ;
+
+  unsigned* mtab = reinterpret_cast<unsigned*>(smem + a.off_mtab);
+  unsigned short* htab = reinterpret_cast<unsigned short*>(smem + a.off_htab);
+  unsigned* vtab = reinterpret_cast<unsigned*>(smem + a.off_vtab);
+  int* ttab = reinterpret_cast<int*>(smem + a.off_ttab);
+  char* Xs = smem + a.off_xs;
+  char* Ws = smem + a.off_ws;
+
+  int bid = xcd_remap(blockIdx.x, gridDim.x);
+  const int ng = bid % a.ngroups;
+  const int tile = bid / a.ngroups;
+  int r = tile;
+  const int tz = r % a.tiles_z; r /= a.tiles_z;
+  const int ty = r % a.tiles_y; r /= a.tiles_y;
+  const int tx = r % a.tiles_x;
+  const int b = r / a.tiles_x;
+  const int x0 = tx * a.TX, y0 = ty * a.TY, z0 = tz * a.TZ;
+  const int nt0 = ng * NTW;  // first n-tile of this workgroup
+
+  // ---- tables -----------------------------------------------------------------------
+  for (int m = t; m < MR; m += NT) {  // rows >= M (tile volume) are padding: flagged, read voxel 0
+    const int oz = m % a.TZ, q = m / a.TZ;
+    const int oy = q % a.TY, ox = q / a.TY;
+    mtab[m] = m < M ? (ox | (oy << 8) | (oz << 16)) : (1u << 24);
+    htab[m] = m < M ? (unsigned short)((ox * Ly + oy) * Lz + oz) : (unsigned short)0;
+  }
+  for (int v = t; v < L; v += NT) {
+    const int hz = v % Lz, q = v / Lz;
+    const int hy = q % Ly, hx = q / Ly;
+    vtab[v] = hx | (hy << 8) | (hz << 16);
+  }
+  for (int k = t; k < a.nts * TPK; k += NT) {
+    int off = 0;
+    if (k < taps) {
+      const int kz = k % a.KZ, q = k / a.KZ;
+      const int ky = q % a.KY, kx = q / a.KY;
+      off = (kx * Ly + ky) * Lz + kz;
+    }
+    ttab[k] = off;
+  }
+  __syncthreads();
+
+  // ---- per-lane fragment geometry --------------------------------------------------------
+  const int fr = lane & 15, fg = lane >> 4;
+  const int lane_plane = (fg % PL) * a.P;  // byte offset of this lane's octet plane
+  const int lane_tsub = fg / PL;           // which of the K-step's TPK taps this lane's octet belongs to
+  int hb[TM];                              // byte offset of row `fr` of m-tile i in a plane
+#pragma unroll
+  for (int i = 0; i < TM; ++i) hb[i] = (int)htab[(wm * TM + i) * 16 + fr] * 16 + lane_plane;
+
+  f32x4_t acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  const int U = a.ups ? 1 : 0;
+  const int nstages = (a.nts + a.TS - 1) / a.TS;
+  const int stage_units = a.TS * NTW;  // 1 KB fragments per stage
+  constexpr int WREG = 3;              // staged fragments per wave per stage (register ring)
+  const unsigned short* wbase = a.wf + (size_t)nt0 * 512;
+
+  // issue the global loads of weight stage (chunk, st) into registers
+  auto w_load = [&](int chunk, int st, uint4 (&wr)[WREG]) {
+#pragma unroll
+    for (int k = 0; k < WREG; ++k) {
+      const int u = wave + WAVES * k;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (u < stage_units) {
+        const int tsi = u / NTW, nl = u - tsi * NTW;
+        const int ts = st * a.TS + tsi;
+        if (ts < a.nts && nt0 + nl < a.NT_total)
+          v = *reinterpret_cast<const uint4*>(wbase + ((size_t)(chunk * a.nts + ts) * a.NT_total + nl) * 512 + lane * 8);
+      }
+      wr[k] = v;
+    }
+  };
+  auto w_store = [&](int buf, const uint4 (&wr)[WREG]) {
+    char* dst = Ws + buf * stage_units * 1024;
+#pragma unroll
+    for (int k = 0; k < WREG; ++k) {
+      const int u = wave + WAVES * k;
+      if (u < stage_units) *reinterpret_cast<uint4*>(dst + u * 1024 + lane * 16) = wr[k];
+    }
+  };
+
+  uint4 wr[WREG];
+  for (int chunk = 0; chunk < a.nchunks; ++chunk) {
+    w_load(chunk, 0, wr);
+    __syncthreads();  // previous chunk's fragment reads are done
+    // ---- stage the activation chunk with its halo ------------------------------------------
+    for (int i0 = t; i0 < L * PL; i0 += NT * 4) {
+      uint4 vals[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int i = i0 + k * NT;
+        uint4 val = make_uint4(0, 0, 0, 0);
+        if (i < L * PL) {
+          const int v = i / PL, pl = i - v * PL;
+          const unsigned hv = vtab[v];
+          const int gx = x0 - a.px + (int)(hv & 255), gy = y0 - a.py + (int)((hv >> 8) & 255),
+                    gz = z0 - a.pz + (int)(hv >> 16);
+          const int c = chunk * CK + 8 * pl;
+          if ((unsigned)gx < (unsigned)(a.Xi << U) && (unsigned)gy < (unsigned)(a.Yi << U) &&
+              (unsigned)gz < (unsigned)a.Zi && c < a.cin_valid) {
+            const long vox = (((long)b * a.Xi + (gx >> U)) * a.Yi + (gy >> U)) * a.Zi + gz;
+            val = *reinterpret_cast<const uint4*>(a.in + vox * a.in_ctot + a.in_off + c);
+          }
+        }
+        vals[k] = val;
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int i = i0 + k * NT;
+        if (i < L * PL) {
+          const int v = i / PL, pl = i - v * PL;
+          *reinterpret_cast<uint4*>(Xs + pl * a.P + v * 16) = vals[k];
+        }
+      }
+    }
+    w_store(0, wr);
+    __syncthreads();
+
+    for (int st = 0; st < nstages; ++st) {
+      const bool more = st + 1 < nstages;
+      if (more) w_load(chunk, st + 1, wr);  // in flight during this stage's MFMAs
+      const char* wcur = Ws + (st & 1) * stage_units * 1024 + (wn * TN) * 1024 + lane * 16;
+      const int ts_end = min(a.TS, a.nts - st * a.TS);
+      for (int tsi = 0; tsi < ts_end; ++tsi) {
+        const int toff = ttab[(st * a.TS + tsi) * TPK + lane_tsub] * 16;
+        uint4 wfr[TN];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) wfr[j] = *reinterpret_cast<const uint4*>(wcur + (tsi * NTW + j) * 1024);
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+          const uint4 xf = *reinterpret_cast<const uint4*>(Xs + hb[i] + toff);
+#pragma unroll
+          for (int j = 0; j < TN; ++j) mma_chunk<BF16>(acc[i][j], wfr[j], xf);
+        }
+      }
+      if (more) w_store((st + 1) & 1, wr);
+      __syncthreads();
+    }
+  }
+
+  // ---- epilogue: acc[i][j][r] -> channel (nt0 + wn*TN + j)*16 + 4*fg + r, voxel row fr of m-tile i
+  const long vox_per_b = (long)a.Xo * a.Yo * a.Zo;
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    const unsigned mv = mtab[(wm * TM + i) * 16 + fr];
+    const int gx = x0 + (int)(mv & 255), gy = y0 + (int)((mv >> 8) & 255), gz = z0 + (int)((mv >> 16) & 255);
+    if ((mv >> 24) || gx >= a.Xo || gy >= a.Yo || gz >= a.Zo) continue;
+    const long vi = ((long)gx * a.Yo + gy) * a.Zo + gz;
+    const long m = (long)b * vox_per_b + vi;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int co0 = (nt0 + wn * TN + j) * 16 + fg * 4;
+      if (co0 >= a.Cout) continue;
+      float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+      const int nval = (a.Cout - co0) < 4 ? (a.Cout - co0) : 4;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        if (q < nval) {
+          float x = v[q];
+          if (a.bias) x += a.bias[co0 + q];
+          if (a.act) x = x > 0.f ? x : x * a.slope;
+          if (a.chan_scale) x *= a.chan_scale[(long)b * a.Cout + co0 + q];
+          v[q] = x * a.alpha;
+        }
+      }
+      if (a.out_planar) {
+        float* o = reinterpret_cast<float*>(a.out);
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          if (q < nval) o[((long)b * a.Cout + co0 + q) * vox_per_b + vi] = v[q];
+      } else {
+        unsigned short* o = reinterpret_cast<unsigned short*>(a.out) + m * a.out_ctot + a.out_off + co0;
+        const unsigned short* rp = a.res ? a.res + m * a.res_ctot + a.res_off + co0 : nullptr;
+        if (nval == 4 && a.vec_ok) {
+          float4 o4 = make_float4(v[0], v[1], v[2], v[3]);
+          if (rp) {
+            const float4 r4 = ld4<BF16>(rp);
+            o4.x += a.beta * r4.x;
+            o4.y += a.beta * r4.y;
+            o4.z += a.beta * r4.z;
+            o4.w += a.beta * r4.w;
+          }
+          st4<BF16>(o, o4);
+        } else {
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            if (q < nval) {
+              float x = v[q];
+              if (rp) x += a.beta * ldf<BF16>(rp + q);
+              stf<BF16>(o + q, x);
+            }
+        }
+      }
+    }
+  }
+}
+
+static inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+template <int WM, int WN, int TM, int TN, int TPK>
+int launch_ct(CtArgs& a, hipStream_t st) {
+  constexpr int WAVES = WM * WN, NTW = WN * TN;
+  const int taps = a.KX * a.KY * a.KZ;
+  constexpr int M = WM * TM * 16;  // table sizes follow the MFMA rows; the tile volume may be smaller
+  if (a.TX * a.TY * a.TZ > M) return WSR_EUNSUPPORTED;
+  const int L = (a.TX + a.KX - 1) * (a.TY + a.KY - 1) * (a.TZ + a.KZ - 1);
+  if (L > 65535) return WSR_EUNSUPPORTED;
+  a.nts = (taps + TPK - 1) / TPK;
+  a.NT_total = (a.Cout + 15) / 16;
+  a.ngroups = (a.NT_total + NTW - 1) / NTW;
+  int TS = (WAVES * 3) / NTW;  // the register ring holds 3 fragments per wave per stage
+  if (TS < 1) return WSR_EUNSUPPORTED;
+  if (TS > a.nts) TS = a.nts;
+  if (TS > 8) TS = 8;
+  a.TS = TS;
+  constexpr int PL = 4 / TPK;
+  a.P = round_up(L * 16, 256);
+  a.off_mtab = 0;
+  a.off_htab = M * 4;
+  a.off_vtab = round_up(a.off_htab + M * 2, 16);
+  a.off_ttab = a.off_vtab + L * 4;
+  a.off_xs = round_up(a.off_ttab + a.nts * TPK * 4, 256);
+  a.off_ws = a.off_xs + PL * a.P;
+  const size_t lds = (size_t)a.off_ws + (size_t)2 * TS * NTW * 1024;
+  if (lds > 160 * 1024) return WSR_EUNSUPPORTED;
+  a.tiles_x = (a.Xo + a.TX - 1) / a.TX;
+  a.tiles_y = (a.Yo + a.TY - 1) / a.TY;
+  a.tiles_z = (a.Zo + a.TZ - 1) / a.TZ;
+  a.ntiles = a.B * a.tiles_x * a.tiles_y * a.tiles_z;
+  auto kern = conv_tile_kernel<WM, WN, TM, TN, TPK>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       160 * 1024);
+    if (e != hipSuccess) return (int)e;
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(kern, dim3((unsigned)(a.ntiles * a.ngroups)), dim3(WAVES * 64), lds, st, a);
+  WSR_LAUNCH_CHECK();
+  return 0;
+}
+
+// choose the spatial tile: at most M voxels, z (the contiguous axis) kept whole when it is short
+static void pick_tile(CtArgs& a, int M) {
+  int tz;
+  if (a.Zo <= 16) tz = a.Zo;
+  else if (a.Zo % 16 == 0 || a.Zo > 64) tz = 16;
+  else tz = 8;
+  while (tz > M) tz >>= 1;
+  const int rest = M / tz;
+  int tx = 1, ty = 1;
+  if ((rest & (rest - 1)) == 0) {
+    while (tx * ty < rest) {  // power of two: balanced split, y first
+      if (ty <= tx) ty <<= 1; else tx <<= 1;
+    }
+  } else {
+    while ((tx + 1) * (tx + 1) <= rest) ++tx;
+    ty = rest / tx;
+  }
+  a.TX = tx; a.TY = ty; a.TZ = tz;
+}
+
+template <int TPK>
+int dispatch_ct(CtArgs& a, hipStream_t st) {
+  const int N = a.Cout;
+  if (N <= 16) { pick_tile(a, 512); return launch_ct<8, 1, 4, 1, TPK>(a, st); }
+  if (N <= 32) { pick_tile(a, 512); return launch_ct<4, 1, 8, 2, TPK>(a, st); }
+  if (N <= 64) { pick_tile(a, 256); return launch_ct<4, 1, 4, 4, TPK>(a, st); }
+  if (N <= 128) { pick_tile(a, 256); return launch_ct<4, 2, 4, 4, TPK>(a, st); }
+  if (N == 144) { pick_tile(a, 512); return launch_ct<8, 1, 4, 9, TPK>(a, st); }
+  if (N <= 160) { pick_tile(a, 256); return launch_ct<4, 2, 4, 5, TPK>(a, st); }
+  if (N <= 192) { pick_tile(a, 256); return launch_ct<4, 2, 4, 6, TPK>(a, st); }
+  if (N <= 224) { pick_tile(a, 256); return launch_ct<4, 2, 4, 7, TPK>(a, st); }
+  if (N <= 256) { pick_tile(a, 256); return launch_ct<4, 2, 4, 8, TPK>(a, st); }
+  return WSR_EUNSUPPORTED;
+}
+
+// ---- fragment-order filter packing ----------------------------------------------------------
+// out[chunk][kstep][ntile][lane][e]: lane (i = lane&15, g = lane>>4), octet g -> tap kstep*TPK + g/PL,
+// channel chunk*CK + (g%PL)*8 + e.  transpose = 0: rows n = Cout, reduction c = Cin (forward);
+// transpose = 1: rows n = Cin, reduction c = Cout, taps flipped (input gradient).
+__global__ void pack_frag_kernel(const float* __restrict__ w, unsigned short* __restrict__ out, int Cout, int Cin,
+                                 int KX, int KY, int KZ, int transpose, int TPK, int nchunks, int nts, int NT_total) {
+  const int PL = 4 / TPK, CK = 8 * PL;
+  const int taps = KX * KY * KZ;
+  const long total = (long)nchunks * nts * NT_total * 512;
+  const int rows = transpose ? Cin : Cout, red = transpose ? Cout : Cin;
+  for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const int e = (int)(idx & 7);
+    const int lane = (int)((idx >> 3) & 63);
+    long q = idx >> 9;
+    const int nt = (int)(q % NT_total); q /= NT_total;
+    const int ts = (int)(q % nts);
+    const int chunk = (int)(q / nts);
+    const int i = lane & 15, g = lane >> 4;
+    const int tap = ts * TPK + g / PL;
+    const int c = chunk * CK + (g % PL) * 8 + e;
+    const int n = nt * 16 + i;
+    float v = 0.f;
+    if (tap < taps && c < red && n < rows) {
+      if (!transpose) {
+        v = w[((long)n * Cin + c) * taps + tap];
+      } else {
+        v = w[((long)c * Cin + n) * taps + (taps - 1 - tap)];
+      }
+    }
+    out[idx] = f2bf(v);
+  }
+}
+
+}  // namespace
+
+extern "C" int wsr_conv_tile_tpk(int32_t red_channels_padded, int32_t taps) {
+  // K-step shape used by the tile kernel for a reduction over `red_channels_padded` (multiple of 8) channels
+  if (taps == 1) return red_channels_padded % 32 == 0 ? 1 : (red_channels_padded % 16 == 0 ? 2 : 4);
+  return red_channels_padded % 16 == 0 ? 2 : 4;
+}
+
+extern "C" int64_t wsr_frag_filter_elems(int32_t rows, int32_t red, int32_t taps) {
+  const int redp = (red + 7) / 8 * 8;
+  const int tpk = wsr_conv_tile_tpk(redp, taps);
+  const int ck = 32 / tpk;
+  const long nchunks = (redp + ck - 1) / ck, nts = (taps + tpk - 1) / tpk, nt = (rows + 15) / 16;
+  return nchunks * nts * nt * 512;
+}
+
+extern "C" int wsr_pack_filter_frag(const float* w, void* out, int32_t Cout, int32_t Cin, int32_t KX, int32_t KY,
+                                    int32_t KZ, int32_t transpose, void* stream) {
+  if (!w || !out || Cout <= 0 || Cin <= 0 || KX <= 0 || KY <= 0 || KZ <= 0) return WSR_EINVAL;
+  const int taps = KX * KY * KZ;
+  const int rows = transpose ? Cin : Cout, red = transpose ? Cout : Cin;
+  const int redp = (red + 7) / 8 * 8;
+  const int tpk = wsr_conv_tile_tpk(redp, taps);
+  const int ck = 32 / tpk;
+  const int nchunks = (redp + ck - 1) / ck, nts = (taps + tpk - 1) / tpk, nt = (rows + 15) / 16;
+  const long total = (long)nchunks * nts * nt * 512;
+  long grid = (total + 255) / 256;
+  if (grid > 2048) grid = 2048;
+  hipLaunchKernelGGL(pack_frag_kernel, dim3((unsigned)grid), dim3(256), 0, as_stream(stream), w,
+                     (unsigned short*)out, Cout, Cin, KX, KY, KZ, transpose, tpk, nchunks, nts, nt);
+  WSR_LAUNCH_CHECK();
+  return 0;
+}
+
+// Shared by the forward and input-gradient entry points.  `red` = reduction channel count
+// as stored (multiple of 8), gather offset in = out - (px,py,pz) + tap.
+static int run_conv_tile(CtArgs& a, int red, hipStream_t st) {
+  const int taps = a.KX * a.KY * a.KZ;
+  if (red % 8 || a.in_ctot % 8 || a.in_off % 8) return WSR_EUNSUPPORTED;
+  if (a.KX > 8 || a.KY > 8 || a.KZ > 8) return WSR_EUNSUPPORTED;
+  const int tpk = wsr_conv_tile_tpk(red, taps);
+  const int ck = 32 / tpk;
+  a.nchunks = (red + ck - 1) / ck;
+  a.cin_valid = red;
+  a.vec_ok = (!a.out_planar && a.out_ctot % 4 == 0 && a.out_off % 4 == 0 &&
+              (!a.res || (a.res_ctot % 4 == 0 && a.res_off % 4 == 0)))
+                 ? 1
+                 : 0;
+  if (tpk == 1) return dispatch_ct<1>(a, st);
+  if (tpk == 2) return dispatch_ct<2>(a, st);
+  return dispatch_ct<4>(a, st);
+}
+
+extern "C" int wsr_conv3d_fwd_tile(const wsr_conv_t* c, const void* x, const void* wfrag, void* y,
+                                   const wsr_epilogue_t* ep, void* stream) {
+  if (!conv_geom_ok(c) || !x || !wfrag || !y) return WSR_EINVAL;
+  if (c->dtype != WSR_BF16 || (c->sx | c->sy | c->sz) != 1) return WSR_EUNSUPPORTED;
+  CtArgs a{};
+  a.in = (const unsigned short*)x;
+  a.wf = (const unsigned short*)wfrag;
+  a.out = y;
+  a.alpha = 1.f;
+  if (ep) {
+    a.bias = ep->bias;
+    a.chan_scale = ep->chan_scale;
+    a.res = (const unsigned short*)ep->res;
+    a.res_ctot = ep->res_ctot;
+    a.res_off = ep->res_off;
+    a.alpha = ep->alpha;
+    a.beta = ep->beta;
+    a.slope = ep->slope;
+    a.act = ep->act;
+    a.out_planar = ep->out_planar;
+    if (a.res && (a.res_off < 0 || a.res_off + c->Cout > a.res_ctot)) return WSR_EINVAL;
+  }
+  a.B = c->B; a.Xi = c->Xi; a.Yi = c->Yi; a.Zi = c->Zi;
+  a.Xo = c->Xo; a.Yo = c->Yo; a.Zo = c->Zo;
+  a.ups = c->upsample_xy ? 1 : 0;
+  a.in_ctot = c->in_ctot; a.in_off = c->in_off;
+  a.Cout = c->Cout; a.out_ctot = c->out_ctot; a.out_off = c->out_off;
+  a.KX = c->KX; a.KY = c->KY; a.KZ = c->KZ;
+  a.px = c->px; a.py = c->py; a.pz = c->pz;
+  return run_conv_tile(a, c->Cin, as_stream(stream));
+}
+
+extern "C" int wsr_conv3d_dgrad_tile(const wsr_conv_t* c, const void* dy, const void* wfrag_t, void* dx, float alpha,
+                                     int accumulate, int dx_planar, void* stream) {
+  if (!conv_geom_ok(c) || !dy || !wfrag_t || !dx) return WSR_EINVAL;
+  if (c->dtype != WSR_BF16 || (c->sx | c->sy | c->sz) != 1) return WSR_EUNSUPPORTED;
+  const int ux = c->upsample_xy ? 2 : 1;
+  CtArgs a{};
+  a.in = (const unsigned short*)dy;
+  a.wf = (const unsigned short*)wfrag_t;
+  a.out = dx;
+  a.alpha = alpha;
+  a.out_planar = dx_planar ? 1 : 0;
+  if (accumulate) {
+    if (dx_planar) return WSR_EUNSUPPORTED;
+    a.res = (const unsigned short*)dx;
+    a.res_ctot = c->in_ctot;
+    a.res_off = c->in_off;
+    a.beta = 1.f;
+  }
+  a.B = c->B;
+  a.Xi = c->Xo; a.Yi = c->Yo; a.Zi = c->Zo;            // gathered tensor = dy
+  a.Xo = c->Xi * ux; a.Yo = c->Yi * ux; a.Zo = c->Zi;  // produced tensor = dx (fine resolution when up-sampled)
+  a.ups = 0;
+  a.in_ctot = c->out_ctot; a.in_off = c->out_off;
+  a.Cout = c->Cin; a.out_ctot = c->in_ctot; a.out_off = c->in_off;
+  a.KX = c->KX; a.KY = c->KY; a.KZ = c->KZ;
+  a.px = c->KX - 1 - c->px; a.py = c->KY - 1 - c->py; a.pz = c->KZ - 1 - c->pz;
+  return run_conv_tile(a, c->Cout, as_stream(stream));
+}

@@ -66,6 +66,17 @@ class FilterCache:
         self._c[key] = (stamp, out)
         return out
 
+    def get_frag(self, p: Tensor, transpose: bool) -> Tensor:
+        """bf16 MFMA-fragment-order copy for the LDS-tile kernels"""
+        key = (id(p), "frag", transpose)
+        stamp = (p._version, p.data_ptr(), p.device)
+        hit = self._c.get(key)
+        if hit is not None and hit[0] == stamp:
+            return hit[1]
+        out = ops.pack_filter_frag(p.detach().contiguous(), transpose=transpose)
+        self._c[key] = (stamp, out)
+        return out
+
     def clear(self):
         self._c.clear()
 
@@ -136,12 +147,18 @@ class ProgramBase:
         self.grad_done_hook: Optional[Callable[[], None]] = None
         #: optional hook(tag, fn) used by bench.py to time selected launches; fn() issues them
         self.launch_probe: Optional[Callable[[str, Callable[[], None]], None]] = None
+        #: route stride-1 bf16 convs through the LDS halo-tile kernels (False: generic implicit GEMM only)
+        self.use_tile = True
 
     def cp(self, c: int) -> int:
         """channel count padded to whole 16-byte pieces"""
         return (c + self.e - 1) // self.e * self.e
 
     # ---- conv helpers --------------------------------------------------------
+    def tile_ok(self, s: ConvSite) -> bool:
+        """LDS halo-tile kernels: bf16, stride 1 (everything in G; the k3 s1 convs of D)"""
+        return self.use_tile and self.dt == torch.bfloat16 and s.stride == (1, 1, 1)
+
     def _w(self, s: ConvSite) -> Tensor:
         return self.filters.get(s.weight, self.dt, False, self.cp(s.cin), s.cout)
 
@@ -160,11 +177,16 @@ class ProgramBase:
         d = self._desc(s, B, tuple(x.shape[1:4]), x.shape[-1], x_off, s.cout if planar else y.shape[-1],
                        0 if planar else y_off, cin=self.cp(s.cin))
         bias = s.bias.detach() if s.bias is not None else None
-        w = self._w(s)
+
+        def run():
+            if self.tile_ok(s) and ops.conv_fwd_tile(d, x, self.filters.get_frag(s.weight, False), y, bias=bias, **ep):
+                return
+            ops.conv_fwd(d, x, self._w(s), y, bias=bias, **ep)
+
         if self.launch_probe is not None:
-            self.launch_probe("fwd:" + s.name, lambda: ops.conv_fwd(d, x, w, y, bias=bias, **ep))
+            self.launch_probe("fwd:" + s.name, run)
         else:
-            ops.conv_fwd(d, x, w, y, bias=bias, **ep)
+            run()
 
     def dgrad(self, s: ConvSite, g: Tensor, g_off: int, dx: Tensor, dx_off: int, in_xyz, *, alpha: float = 1.0,
               accumulate: bool = False, dx_planar: bool = False) -> None:
@@ -173,12 +195,17 @@ class ProgramBase:
         cin = s.cin if dx_planar else self.cp(s.cin)
         d = self._desc(s, B, tuple(in_xyz), s.cin if dx_planar else dx.shape[-1], 0 if dx_planar else dx_off,
                        g.shape[-1], g_off, cin=cin, cout=self.cp(s.cout))
-        wt = self._wt(s)
+
+        def run():
+            if self.tile_ok(s) and ops.conv_dgrad_tile(d, g, self.filters.get_frag(s.weight, True), dx, alpha=alpha,
+                                                       accumulate=accumulate, dx_planar=dx_planar):
+                return
+            ops.conv_dgrad(d, g, self._wt(s), dx, alpha=alpha, accumulate=accumulate, dx_planar=dx_planar)
+
         if self.launch_probe is not None:
-            self.launch_probe("dgrad:" + s.name, lambda: ops.conv_dgrad(d, g, wt, dx, alpha=alpha,
-                                                                        accumulate=accumulate, dx_planar=dx_planar))
+            self.launch_probe("dgrad:" + s.name, run)
         else:
-            ops.conv_dgrad(d, g, wt, dx, alpha=alpha, accumulate=accumulate, dx_planar=dx_planar)
+            run()
 
     def wgrad(self, s: ConvSite, x: Tensor, x_off: int, g: Tensor, g_off: int, flat: Tensor, space: GradSpace,
               scratch: Tensor, scale: float = 1.0) -> None:

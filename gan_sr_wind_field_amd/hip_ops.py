@@ -107,6 +107,53 @@ def conv_fwd(desc: ConvDesc, x: Tensor, w: Tensor, y: Tensor, *, bias: Optional[
     return y
 
 
+def conv_fwd_tile(desc: ConvDesc, x: Tensor, wfrag: Tensor, y: Tensor, *, bias: Optional[Tensor] = None,
+                  chan_scale: Optional[Tensor] = None, res: Optional[Tensor] = None, res_off: int = 0,
+                  alpha: float = 1.0, beta: float = 0.0, act: bool = False, slope: float = 0.2,
+                  out_planar: bool = False) -> bool:
+    """LDS halo-tile forward conv (bf16, stride 1).  Returns False when the shape is outside
+    the tile kernels (the caller then uses :func:`conv_fwd`)."""
+    _need_cuda(x, wfrag, y, bias, chan_scale, res)
+    ep = Epilogue()
+    ep.bias, ep.chan_scale, ep.res = _p(bias), _p(chan_scale), _p(res)
+    ep.res_ctot = res.shape[-1] if res is not None else 0
+    ep.res_off = res_off
+    ep.alpha, ep.beta = alpha, beta
+    ep.act, ep.slope = int(act), slope
+    ep.out_planar = int(out_planar)
+    rc = _lib.lib().wsr_conv3d_fwd_tile(C.byref(desc), _p(x), _p(wfrag), _p(y), C.byref(ep), _stream())
+    if rc == _lib.WSR_EUNSUPPORTED:
+        return False
+    check(rc, "conv3d_fwd_tile")
+    return True
+
+
+def conv_dgrad_tile(desc: ConvDesc, dy: Tensor, wfrag_t: Tensor, dx: Tensor, *, alpha: float = 1.0,
+                    accumulate: bool = False, dx_planar: bool = False) -> bool:
+    _need_cuda(dy, wfrag_t, dx)
+    rc = _lib.lib().wsr_conv3d_dgrad_tile(C.byref(desc), _p(dy), _p(wfrag_t), _p(dx), alpha, int(accumulate),
+                                          int(dx_planar), _stream())
+    if rc == _lib.WSR_EUNSUPPORTED:
+        return False
+    check(rc, "conv3d_dgrad_tile")
+    return True
+
+
+def pack_filter_frag(w: Tensor, *, transpose: bool = False, out: Optional[Tensor] = None) -> Tensor:
+    """fp32 master ``(Cout, Cin, KX, KY, KZ)`` -> bf16 MFMA-fragment order for the tile kernels."""
+    _need_cuda(w)
+    if not w.is_contiguous() or w.dtype != torch.float32 or w.dim() != 5:
+        raise ValueError("pack_filter_frag wants a contiguous fp32 (Cout, Cin, KX, KY, KZ) tensor")
+    cout, cin, kx, ky, kz = w.shape
+    rows, red = (cin, cout) if transpose else (cout, cin)
+    n = _lib.lib().wsr_frag_filter_elems(rows, red, kx * ky * kz)
+    if out is None:
+        out = torch.empty(n, dtype=torch.bfloat16, device=w.device)
+    check(_lib.lib().wsr_pack_filter_frag(_p(w), _p(out), cout, cin, kx, ky, kz, int(transpose), _stream()),
+          "pack_filter_frag")
+    return out
+
+
 def conv_dgrad(desc: ConvDesc, dy: Tensor, wt: Tensor, dx: Tensor, *, alpha: float = 1.0,
                accumulate: bool = False, dx_planar: bool = False) -> Tensor:
     _need_cuda(dy, wt, dx)

@@ -88,6 +88,22 @@ int wsr_conv3d_fwd(const wsr_conv_t* c, const void* x, const void* w, void* y,
 int wsr_conv3d_dgrad(const wsr_conv_t* c, const void* dy, const void* wt, void* dx, float alpha,
                      int accumulate, int dx_planar, void* stream);
 
+/* ---- LDS halo-tile path (bf16, stride 1) ------------------------------------
+ * Same contracts as wsr_conv3d_fwd / wsr_conv3d_dgrad, but the activation tile
+ * (with halo) is staged in LDS once per channel chunk and re-used by every tap,
+ * and the filter comes in MFMA-fragment order from wsr_pack_filter_frag
+ * (transpose = 0 for the forward pass, 1 for the input gradient; element count
+ * from wsr_frag_filter_elems(rows, reduction channels, taps)).  Return
+ * WSR_EUNSUPPORTED for shapes outside the tile kernels (strided convs, fp32):
+ * the caller then uses the generic entry points above.                          */
+int wsr_conv3d_fwd_tile(const wsr_conv_t* c, const void* x, const void* wfrag, void* y,
+                        const wsr_epilogue_t* ep, void* stream);
+int wsr_conv3d_dgrad_tile(const wsr_conv_t* c, const void* dy, const void* wfrag_t, void* dx, float alpha,
+                          int accumulate, int dx_planar, void* stream);
+int64_t wsr_frag_filter_elems(int32_t rows, int32_t red, int32_t taps);
+int wsr_pack_filter_frag(const float* w, void* out, int32_t Cout, int32_t Cin, int32_t KX, int32_t KY, int32_t KZ,
+                         int32_t transpose, void* stream);
+
 /* aten::convolution_backward, filter gradient: dw[Cout][taps][Cin] fp32 (packed
  * order) is ACCUMULATED into (caller zeroes it when a fresh gradient is wanted;
  * wsr_unpack_wgrad moves it to the master layout).                             */

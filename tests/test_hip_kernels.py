@@ -337,3 +337,91 @@ def test_wgrad_dense_block_fused(hip):
         o.unpack_wgrad(dwp[i * gc:(i + 1) * gc], dw)
         ref = _cpu_wgrad(x[:, :ci], g[:, nf + i * gc:nf + (i + 1) * gc], (3, 3, 3), (1, 1, 1))
         assert rel_l2(dw.cpu(), ref) < 2e-5, i
+
+
+@pytest.mark.parametrize("case", [c for c in CONV_CASES if c[4] == (1, 1, 1)], ids=lambda c: c[0])
+def test_conv_tile_kernels_vs_golden(golden, hip, case):
+    """LDS halo-tile forward / input-gradient kernels (bf16, stride 1) on the reference's conv fixtures."""
+    o = ops()
+    dt = torch.bfloat16
+    name, cin, cout, k, s, p, bias, act, xyz, B = case
+    g = golden("conv_cases.npz")
+    x, w, y_ref, gy, dx_ref = (T(g[f"{name}.{n}"]) for n in ("x", "w", "y", "gy", "dx"))
+    b = T(g[f"{name}.b"]).to(DEV) if bias else None
+    cin_p, cout_p = o.pad_channels(cin, dt), o.pad_channels(cout, dt)
+    in_off, out_off = 8, 16
+    in_ctot, out_ctot = cin_p + 16, cout_p + 24
+    xb = to_ndhwc(x, in_ctot, in_off, dt)
+    wm = packed_master(w)
+    d = o.make_desc(o.ConvGeom(cin_p, cout, k, s, p), dt, B, xyz, in_ctot, in_off, out_ctot, out_off)
+    yb = torch.full((B, d.Xo, d.Yo, d.Zo, out_ctot), 7.0, dtype=dt, device=DEV)
+    assert o.conv_fwd_tile(d, xb, o.pack_filter_frag(wm), yb, bias=b, act=act, slope=0.2)
+    y = from_ndhwc(yb, out_off, cout)
+    assert rel_l2(y, y_ref) < 1e-2
+    assert float((yb[..., :out_off].float() - 7.0).abs().max()) == 0.0
+    assert float((yb[..., out_off + cout:].float() - 7.0).abs().max()) == 0.0
+    y2 = F.conv3d(x.bfloat16().float(), w.bfloat16().float(), b.cpu() if bias else None, s, p)
+    y2 = F.leaky_relu(y2, 0.2) if act else y2
+    assert rel_l2(y, y2) < 4e-3  # same rounded operands, fp32 accumulation, bf16 store
+    # the generic implicit-GEMM kernel computes the same thing
+    yb2 = torch.full_like(yb, 7.0)
+    o.conv_fwd(d, xb, o.pack_filter(wm, dt, kpad=cin_p), yb2, bias=b, act=act, slope=0.2)
+    assert rel_l2(yb.float(), yb2.float()) < 4e-3
+
+    gb = to_ndhwc(gy, out_ctot, out_off, dt)
+    if act:
+        o.lrelu_bwd_(gb, out_off, to_ndhwc(y_ref, out_ctot, out_off, dt), out_off, cout_p, 0.2)
+    wft = o.pack_filter_frag(wm, transpose=True)
+    dd = o.make_desc(o.ConvGeom(cin, cout_p, k, s, p), dt, B, xyz, in_ctot, in_off, out_ctot, out_off)
+    dxb = torch.full((B,) + tuple(xyz) + (in_ctot,), 3.0, dtype=dt, device=DEV)
+    assert o.conv_dgrad_tile(dd, gb, wft, dxb)
+    assert rel_l2(from_ndhwc(dxb, in_off, cin), dx_ref) < 1e-2
+    assert float((dxb[..., :in_off].float() - 3.0).abs().max()) == 0.0
+    assert o.conv_dgrad_tile(dd, gb, wft, dxb, accumulate=True)
+    assert rel_l2(from_ndhwc(dxb, in_off, cin), 2 * dx_ref) < 1e-2
+    dxp = torch.zeros((B, cin) + tuple(xyz), dtype=torch.float32, device=DEV)
+    dd2 = o.make_desc(o.ConvGeom(cin, cout_p, k, s, p), dt, B, xyz, cin, 0, out_ctot, out_off)
+    assert o.conv_dgrad_tile(dd2, gb, wft, dxp, dx_planar=True)
+    assert rel_l2(dxp.cpu(), dx_ref) < 1e-2
+
+
+@pytest.mark.parametrize("name,cin,cout,k,xyz,B,ups", [
+    ("rdb_n32", 160, 32, (3, 3, 3), (9, 10, 19), 1, False),    # <4,1,8,2>: 512-row tiles, ragged in x/y/z
+    ("hr0_n144", 144, 144, (5, 5, 5), (9, 7, 10), 1, False),   # <8,1,4,9>, TPK=2 with an odd tap count (125)
+    ("up_n128", 128, 128, (3, 3, 3), (5, 6, 8), 1, True),      # nearest x(2,2,1) folded into the halo load
+    ("lff_1x1", 256, 128, (1, 1, 1), (7, 9, 11), 2, False),    # TPK=1 (32-channel K-steps)
+    ("dg_n224", 32, 224, (3, 3, 3), (6, 9, 17), 1, False),     # <4,2,4,7>: two n-tile wave columns
+    ("n64_c24", 24, 64, (3, 3, 3), (8, 5, 6), 2, False),       # TPK=4 (24 channels), N=64
+    ("n3_k5", 144, 3, (5, 5, 5), (8, 8, 10), 1, False),        # N=3 (one 16-tile), planar-style narrow output
+])
+def test_conv_tile_shapes_vs_cpu(hip, name, cin, cout, k, xyz, B, ups):
+    """Every tile-kernel configuration against an fp32 CPU conv of the same bf16-rounded operands,
+    forward and input gradient (with residual epilogue on the forward pass)."""
+    o = ops()
+    dt = torch.bfloat16
+    gen = torch.Generator().manual_seed(cin * 7 + cout)
+    x = torch.randn((B, cin) + tuple(xyz), generator=gen).bfloat16().float()
+    w = (torch.randn((cout, cin) + tuple(k), generator=gen) / math.sqrt(cin * k[0] * k[1] * k[2])).bfloat16().float()
+    p = tuple(kk // 2 for kk in k)
+    geom = o.ConvGeom(cin, cout, k, (1, 1, 1), p, upsample=ups)
+    cout_p = o.pad_channels(cout, dt)
+    xb = to_ndhwc(x, cin + 8, 8, dt)
+    d = o.make_desc(geom, dt, B, xyz, cin + 8, 8, cout_p + 8, 0)
+    oxyz = (d.Xo, d.Yo, d.Zo)
+    res = torch.randn((B, cout) + oxyz, generator=gen).bfloat16().float()
+    rb = to_ndhwc(res, cout_p, 0, dt)
+    yb = torch.zeros((B,) + oxyz + (cout_p + 8,), dtype=dt, device=DEV)
+    wm = packed_master(w)
+    assert o.conv_fwd_tile(d, xb, o.pack_filter_frag(wm), yb, res=rb, res_off=0, alpha=0.2, beta=1.0)
+    xr = x.repeat_interleave(2, dim=2).repeat_interleave(2, dim=3) if ups else x
+    ref = 0.2 * F.conv3d(xr, w, None, 1, p) + res
+    assert rel_l2(from_ndhwc(yb, 0, cout), ref) < 4e-3, name
+    # input gradient (at the fine resolution when up-sampled; the 2x2 fold is a separate kernel)
+    gy = torch.randn((B, cout) + oxyz, generator=gen).bfloat16().float()
+    gb = to_ndhwc(gy, cout_p + 8, 0, dt)
+    dd = o.make_desc(o.ConvGeom(cin, cout_p, k, (1, 1, 1), p, upsample=ups), dt, B, xyz, cin + 8, 8, cout_p + 8, 0)
+    dxb = torch.zeros((B,) + tuple(xr.shape[2:]) + (cin + 8,), dtype=dt, device=DEV)
+    assert o.conv_dgrad_tile(dd, gb, o.pack_filter_frag(wm, transpose=True), dxb)
+    xg = xr.clone().requires_grad_(True)
+    F.conv3d(xg, w, None, 1, p).backward(gy)
+    assert rel_l2(from_ndhwc(dxb, 8, cin), xg.grad) < 4e-3, name
