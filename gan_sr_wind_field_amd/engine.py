@@ -29,6 +29,9 @@ from .hip_ops import ConvGeom
 
 Tensor = torch.Tensor
 
+#: debugging aid (tests set it): allocate work buffers filled with NaN instead of uninitialised
+POISON_BUFFERS = bool(int(__import__("os").environ.get("WSR_POISON_BUFFERS", "0")))
+
 
 def compute_dtype_of(flag) -> torch.dtype:
     """Map the reference's ``use_mixed_precision`` ctor flag / a dtype / a string."""
@@ -255,8 +258,11 @@ class ProgramBase:
         return max(s.cout * s.taps * ((s.cin + e - 1) // e * e) for s in sites)
 
     def _empty(self, shape, like: Tensor, zero: bool = False) -> Tensor:
-        f = torch.zeros if zero else torch.empty
-        return f(shape, dtype=self.dt, device=like.device)
+        if zero:
+            return torch.zeros(shape, dtype=self.dt, device=like.device)
+        if POISON_BUFFERS:  # tests: every element must be written by a kernel before it is read
+            return torch.full(shape, float("nan"), dtype=self.dt, device=like.device)
+        return torch.empty(shape, dtype=self.dt, device=like.device)
 
 
 # =============================================================================
