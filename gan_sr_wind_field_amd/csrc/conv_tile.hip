@@ -32,6 +32,7 @@ struct CtArgs {
   const unsigned short* in;
   const unsigned short* wf;  // fragment-packed filter: [chunk][kstep][ntile][64 lanes][8]
   void* out;
+  const void* zero16;        // 16 zero bytes in global memory (source of out-of-range DMA lanes)
   const float* bias;
   const float* chan_scale;
   const unsigned short* res;
@@ -52,9 +53,25 @@ struct CtArgs {
   int P;            // activation plane stride (bytes)
   int off_mtab, off_htab, off_vtab, off_ttab, off_xs, off_ws;
   int vec_ok;
+  int xbufs;        // activation buffers in LDS: 2 = next chunk prefetched during the MFMAs
 };
 
-template <int WM, int WN, int TM, int TN, int TPK>
+// LDS-DMA of 16 B per lane: LDS[lds_addr + 16*lane] <- *gsrc.  Issued as inline asm so that hipcc does
+// not serialise it against the LDS fragment reads of the phase in flight (with the builtin it puts
+// s_waitcnt vmcnt(0) in front of every ds_read that follows); completion is waited for explicitly
+// (dma_wait) before the barrier that publishes the buffer.  M0 carries the wave-uniform LDS base
+// and is restored, as the compiler reserves it.
+__device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_addr) {
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(gsrc), "s"(lds_addr)
+      : "memory");
+}
+__device__ __forceinline__ void dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+template <int WM, int WN, int TM, int TN, int TPK, bool PIPE>
 __global__ __launch_bounds__(WM * WN * 64) void conv_tile_kernel(const CtArgs a) {
   constexpr int WAVES = WM * WN, NT = WAVES * 64;
   constexpr int PL = 4 / TPK;      // octet planes per chunk
@@ -114,11 +131,17 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_tile_kernel(const CtArgs a)
 
   // ---- per-lane fragment geometry --------------------------------------------------------
   const int fr = lane & 15, fg = lane >> 4;
-  const int lane_plane = (fg % PL) * a.P;  // byte offset of this lane's octet plane
+  // Activation image in LDS.  TPK = 2: voxel-major 32-byte rows [voxel][2 octets] - one DMA instruction
+  // then fetches 32 B per voxel with adjacent lanes (half the L2 requests of an octet-plane gather) and
+  // ds_read_b128 stays conflict-free (even/odd 16-byte slots of the two octets never meet inside a
+  // 16-lane read group).  Otherwise: octet-major planes [octet][voxel][16 B].
+  constexpr bool VM = TPK == 2;
+  constexpr int RB = VM ? 32 : 16;  // bytes per voxel row
+  const int lane_plane = VM ? (fg & 1) * 16 : (fg % PL) * a.P;
   const int lane_tsub = fg / PL;           // which of the K-step's TPK taps this lane's octet belongs to
   int hb[TM];                              // byte offset of row `fr` of m-tile i in a plane
 #pragma unroll
-  for (int i = 0; i < TM; ++i) hb[i] = (int)htab[(wm * TM + i) * 16 + fr] * 16 + lane_plane;
+  for (int i = 0; i < TM; ++i) hb[i] = (int)htab[(wm * TM + i) * 16 + fr] * RB + lane_plane;
 
   f32x4_t acc[TM][TN];
 #pragma unroll
@@ -128,91 +151,139 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_tile_kernel(const CtArgs a)
 
   const int U = a.ups ? 1 : 0;
   const int nstages = (a.nts + a.TS - 1) / a.TS;
-  const int stage_units = a.TS * NTW;  // 1 KB fragments per stage
-  constexpr int WREG = 3;              // staged fragments per wave per stage (register ring)
+  const int stage_units = a.TS * NTW;  // 1 KB fragments per weight stage
+  const int UPP = VM ? (L + 31) >> 5 : (L + 63) >> 6;  // 1 KB DMA units per activation plane (VM: per chunk)
+  const int HU = VM ? UPP : UPP * PL;                   // ... per chunk
+  const int xs_bytes = VM ? a.P : PL * a.P;
   const unsigned short* wbase = a.wf + (size_t)nt0 * 512;
+  typedef __attribute__((address_space(3))) char* lptr_t;
+  const unsigned xs_lds = (unsigned)(unsigned long)(lptr_t)Xs;  // LDS byte addresses
+  const unsigned ws_lds = (unsigned)(unsigned long)(lptr_t)Ws;
 
-  // issue the global loads of weight stage (chunk, st) into registers
-  auto w_load = [&](int chunk, int st, uint4 (&wr)[WREG]) {
-#pragma unroll
-    for (int k = 0; k < WREG; ++k) {
-      const int u = wave + WAVES * k;
-      uint4 v = make_uint4(0, 0, 0, 0);
-      if (u < stage_units) {
-        const int tsi = u / NTW, nl = u - tsi * NTW;
-        const int ts = st * a.TS + tsi;
-        if (ts < a.nts && nt0 + nl < a.NT_total)
-          v = *reinterpret_cast<const uint4*>(wbase + ((size_t)(chunk * a.nts + ts) * a.NT_total + nl) * 512 + lane * 8);
+  // LDS-DMA (global_load_lds): each wave moves whole 1 KB units, lane l -> unit base + 16*l.
+  // weights of stage (chunk, st) -> Ws[buf]
+  auto w_issue = [&](int chunk, int st, int buf) {
+    const unsigned dst = ws_lds + buf * stage_units * 1024;
+    for (int u = wave; u < stage_units; u += WAVES) {
+      const int tsi = u / NTW, nl = u - tsi * NTW;
+      const int ts = st * a.TS + tsi;
+      if (ts < a.nts && nt0 + nl < a.NT_total) {
+        const unsigned short* src = wbase + ((size_t)(chunk * a.nts + ts) * a.NT_total + nl) * 512 + lane * 8;
+        glds16(src, __builtin_amdgcn_readfirstlane(dst + u * 1024));
       }
-      wr[k] = v;
     }
   };
-  auto w_store = [&](int buf, const uint4 (&wr)[WREG]) {
-    char* dst = Ws + buf * stage_units * 1024;
+  // The halo geometry is the same for every chunk, so each wave resolves the source of "its" DMA units
+  // (u = wave + WAVES*k) once: element offset of the lane's voxel (or OOB), octet plane, LDS offset.
+  constexpr int XK = 10;  // max units per wave per chunk (checked on the host)
+  unsigned xoff[XK];
+  int xo8[XK], xdst[XK];
 #pragma unroll
-    for (int k = 0; k < WREG; ++k) {
+  for (int k = 0; k < XK; ++k) {
+    const int u = wave + WAVES * k;
+    unsigned off = 0xFFFFFFFFu;
+    int pl = 0, dsto = 0;
+    if (u < HU) {
+      int v;
+      if constexpr (VM) {
+        pl = lane & 1;
+        v = u * 32 + (lane >> 1);
+        dsto = u * 1024;
+      } else {
+        pl = u / UPP;
+        v = (u - pl * UPP) * 64 + lane;
+        dsto = pl * a.P + (u - pl * UPP) * 1024;
+      }
+      if (v < L) {
+        const unsigned hv = vtab[v];
+        const int gx = x0 - a.px + (int)(hv & 255), gy = y0 - a.py + (int)((hv >> 8) & 255),
+                  gz = z0 - a.pz + (int)(hv >> 16);
+        if ((unsigned)gx < (unsigned)(a.Xi << U) && (unsigned)gy < (unsigned)(a.Yi << U) &&
+            (unsigned)gz < (unsigned)a.Zi) {
+          const long vox = (((long)b * a.Xi + (gx >> U)) * a.Yi + (gy >> U)) * a.Zi + gz;
+          off = (unsigned)(vox * a.in_ctot + a.in_off + 8 * pl);
+        }
+      }
+    }
+    xoff[k] = off;
+    xo8[k] = 8 * pl;
+    xdst[k] = __builtin_amdgcn_readfirstlane(dsto);
+  }
+  // units [u0, u1) of the activation chunk (with halo) -> Xs[buf]; out-of-range voxels read the zero page
+  auto x_issue = [&](int chunk, int buf, int u0, int u1) {
+    const unsigned dst = xs_lds + buf * xs_bytes;
+#pragma unroll
+    for (int k = 0; k < XK; ++k) {
       const int u = wave + WAVES * k;
-      if (u < stage_units) *reinterpret_cast<uint4*>(dst + u * 1024 + lane * 16) = wr[k];
+      if (u >= u0 && u < u1) {
+        const bool ok = xoff[k] != 0xFFFFFFFFu && chunk * CK + xo8[k] < a.cin_valid;
+        const unsigned short* src = ok ? a.in + (size_t)xoff[k] + chunk * CK
+                                       : reinterpret_cast<const unsigned short*>(a.zero16);
+        glds16(src, dst + xdst[k]);
+      }
     }
   };
 
-  uint4 wr[WREG];
-  for (int chunk = 0; chunk < a.nchunks; ++chunk) {
-    w_load(chunk, 0, wr);
-    __syncthreads();  // previous chunk's fragment reads are done
-    // ---- stage the activation chunk with its halo ------------------------------------------
-    for (int i0 = t; i0 < L * PL; i0 += NT * 4) {
-      uint4 vals[4];
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const int i = i0 + k * NT;
-        uint4 val = make_uint4(0, 0, 0, 0);
-        if (i < L * PL) {
-          const int v = i / PL, pl = i - v * PL;
-          const unsigned hv = vtab[v];
-          const int gx = x0 - a.px + (int)(hv & 255), gy = y0 - a.py + (int)((hv >> 8) & 255),
-                    gz = z0 - a.pz + (int)(hv >> 16);
-          const int c = chunk * CK + 8 * pl;
-          if ((unsigned)gx < (unsigned)(a.Xi << U) && (unsigned)gy < (unsigned)(a.Yi << U) &&
-              (unsigned)gz < (unsigned)a.Zi && c < a.cin_valid) {
-            const long vox = (((long)b * a.Xi + (gx >> U)) * a.Yi + (gy >> U)) * a.Zi + gz;
-            val = *reinterpret_cast<const uint4*>(a.in + vox * a.in_ctot + a.in_off + c);
-          }
-        }
-        vals[k] = val;
-      }
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const int i = i0 + k * NT;
-        if (i < L * PL) {
-          const int v = i / PL, pl = i - v * PL;
-          *reinterpret_cast<uint4*>(Xs + pl * a.P + v * 16) = vals[k];
-        }
-      }
-    }
-    w_store(0, wr);
-    __syncthreads();
+  x_issue(0, 0, 0, HU);
+  w_issue(0, 0, 0);
+  dma_wait();
+  __syncthreads();
 
-    for (int st = 0; st < nstages; ++st) {
-      const bool more = st + 1 < nstages;
-      if (more) w_load(chunk, st + 1, wr);  // in flight during this stage's MFMAs
-      const char* wcur = Ws + (st & 1) * stage_units * 1024 + (wn * TN) * 1024 + lane * 16;
-      const int ts_end = min(a.TS, a.nts - st * a.TS);
-      for (int tsi = 0; tsi < ts_end; ++tsi) {
-        const int toff = ttab[(st * a.TS + tsi) * TPK + lane_tsub] * 16;
-        uint4 wfr[TN];
-#pragma unroll
-        for (int j = 0; j < TN; ++j) wfr[j] = *reinterpret_cast<const uint4*>(wcur + (tsi * NTW + j) * 1024);
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-          const uint4 xf = *reinterpret_cast<const uint4*>(Xs + hb[i] + toff);
-#pragma unroll
-          for (int j = 0; j < TN; ++j) mma_chunk<BF16>(acc[i][j], wfr[j], xf);
-        }
-      }
-      if (more) w_store((st + 1) & 1, wr);
+  const int total_phases = a.nchunks * nstages;
+  int chunk = 0, st = 0;
+  for (int ph = 0; ph < total_phases; ++ph) {
+    // ---- prefetch: next weight stage, and a slice of the next chunk's activations -------
+    if (ph + 1 < total_phases) {
+      const bool wrap = st + 1 == nstages;
+      w_issue(wrap ? chunk + 1 : chunk, wrap ? 0 : st + 1, (ph + 1) & 1);
+    }
+    if (a.xbufs == 2) {
+      if (chunk + 1 < a.nchunks) x_issue(chunk + 1, (chunk + 1) & 1, (HU * st) / nstages, (HU * (st + 1)) / nstages);
+    } else if (st == 0 && chunk > 0) {  // single activation buffer: reload it between chunks
+      x_issue(chunk, 0, 0, HU);
+      dma_wait();
       __syncthreads();
     }
+
+    const char* wcur = Ws + (ph & 1) * stage_units * 1024 + (wn * TN) * 1024 + lane * 16;
+    const char* xcur = Xs + (a.xbufs == 2 ? (chunk & 1) * xs_bytes : 0);
+    const int ts_end = min(a.TS, a.nts - st * a.TS);
+    const int* tt = ttab + st * a.TS * TPK + lane_tsub;
+    auto load_frags = [&](int tsi, uint4 (&wf)[TN], uint4 (&xf)[TM]) {
+      const int toff = tt[tsi * TPK] * RB;
+#pragma unroll
+      for (int j = 0; j < TN; ++j) wf[j] = *reinterpret_cast<const uint4*>(wcur + (tsi * NTW + j) * 1024);
+#pragma unroll
+      for (int i = 0; i < TM; ++i) xf[i] = *reinterpret_cast<const uint4*>(xcur + hb[i] + toff);
+    };
+    auto mma_frags = [&](const uint4 (&wf)[TN], const uint4 (&xf)[TM]) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) mma_chunk<BF16>(acc[i][j], wf[j], xf[i]);
+    };
+    if constexpr (PIPE) {
+      // register double-buffering: the fragments of K-step t+1 are in flight during the MFMAs of K-step t
+      uint4 wA[TN], xA[TM], wB[TN], xB[TM];
+      load_frags(0, wA, xA);
+      int tsi = 0;
+      for (; tsi + 2 <= ts_end; tsi += 2) {
+        load_frags(tsi + 1, wB, xB);
+        mma_frags(wA, xA);
+        if (tsi + 2 < ts_end) load_frags(tsi + 2, wA, xA);
+        mma_frags(wB, xB);
+      }
+      if (tsi < ts_end) mma_frags(wA, xA);
+    } else {
+      for (int tsi = 0; tsi < ts_end; ++tsi) {
+        uint4 wf[TN], xf[TM];
+        load_frags(tsi, wf, xf);
+        mma_frags(wf, xf);
+      }
+    }
+    dma_wait();  // this wave's prefetches have landed ...
+    __syncthreads();  // ... and so have everybody else's; the buffers just read are free again
+    if (++st == nstages) { st = 0; ++chunk; }
   }
 
   // ---- epilogue: acc[i][j][r] -> channel (nt0 + wn*TN + j)*16 + 4*fg + r, voxel row fr of m-tile i
@@ -285,26 +356,40 @@ int launch_ct(CtArgs& a, hipStream_t st) {
   a.nts = (taps + TPK - 1) / TPK;
   a.NT_total = (a.Cout + 15) / 16;
   a.ngroups = (a.NT_total + NTW - 1) / NTW;
-  int TS = (WAVES * 3) / NTW;  // the register ring holds 3 fragments per wave per stage
-  if (TS < 1) return WSR_EUNSUPPORTED;
-  if (TS > a.nts) TS = a.nts;
-  if (TS > 8) TS = 8;
-  a.TS = TS;
   constexpr int PL = 4 / TPK;
-  a.P = round_up(L * 16, 256);
+  constexpr bool VM = TPK == 2;
+  a.P = VM ? round_up(L * 32, 1024) : round_up(L * 16, 1024);  // whole 1 KB DMA units; == 0 (mod 256)
   a.off_mtab = 0;
   a.off_htab = M * 4;
   a.off_vtab = round_up(a.off_htab + M * 2, 16);
   a.off_ttab = a.off_vtab + L * 4;
-  a.off_xs = round_up(a.off_ttab + a.nts * TPK * 4, 256);
-  a.off_ws = a.off_xs + PL * a.P;
-  const size_t lds = (size_t)a.off_ws + (size_t)2 * TS * NTW * 1024;
+  a.off_xs = round_up(a.off_ttab + a.nts * TPK * 4, 1024);
+  // two activation buffers when that still leaves room for weight stages of >= 2 K-steps
+  int ts_max = 0;
+  for (a.xbufs = 2; a.xbufs >= 1; --a.xbufs) {
+    a.off_ws = a.off_xs + a.xbufs * (VM ? 1 : PL) * a.P;
+    const int avail = 160 * 1024 - a.off_ws;
+    ts_max = avail / (2 * NTW * 1024);
+    const int cap = 32 / NTW > 0 ? 32 / NTW : 1;  // <= 32 KB per weight stage
+    if (ts_max > cap) ts_max = cap;
+    if (ts_max >= 2 || (ts_max >= 1 && a.nts == 1)) break;
+  }
+  if (a.xbufs < 1) {
+    a.xbufs = 1;
+    if (ts_max < 1) return WSR_EUNSUPPORTED;
+  }
+  if ((VM ? (L + 31) / 32 : ((L + 63) / 64) * PL) > 10 * WAVES) return WSR_EUNSUPPORTED;  // XK units per wave
+  if ((long)a.B * a.Xi * a.Yi * a.Zi * a.in_ctot >= 0xFFFFFFFFL) return WSR_EUNSUPPORTED;  // 32-bit element offsets
+  const int nph = (a.nts + ts_max - 1) / ts_max;
+  a.TS = (a.nts + nph - 1) / nph;  // balanced stages
+  const size_t lds = (size_t)a.off_ws + (size_t)2 * a.TS * NTW * 1024;
   if (lds > 160 * 1024) return WSR_EUNSUPPORTED;
   a.tiles_x = (a.Xo + a.TX - 1) / a.TX;
   a.tiles_y = (a.Yo + a.TY - 1) / a.TY;
   a.tiles_z = (a.Zo + a.TZ - 1) / a.TZ;
   a.ntiles = a.B * a.tiles_x * a.tiles_y * a.tiles_z;
-  auto kern = conv_tile_kernel<WM, WN, TM, TN, TPK>;
+  constexpr bool PIPE = TN <= 7;  // register budget: (TM+TN)*8 fragment + TM*TN*4 accumulator VGPRs
+  auto kern = conv_tile_kernel<WM, WN, TM, TN, TPK, PIPE>;
   static bool attr_done = false;
   if (!attr_done) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -341,7 +426,7 @@ template <int TPK>
 int dispatch_ct(CtArgs& a, hipStream_t st) {
   const int N = a.Cout;
   if (N <= 16) { pick_tile(a, 512); return launch_ct<8, 1, 4, 1, TPK>(a, st); }
-  if (N <= 32) { pick_tile(a, 512); return launch_ct<4, 1, 8, 2, TPK>(a, st); }
+  if (N <= 32) { pick_tile(a, 512); return launch_ct<8, 1, 4, 2, TPK>(a, st); }
   if (N <= 64) { pick_tile(a, 256); return launch_ct<4, 1, 4, 4, TPK>(a, st); }
   if (N <= 128) { pick_tile(a, 256); return launch_ct<4, 2, 4, 4, TPK>(a, st); }
   if (N == 144) { pick_tile(a, 512); return launch_ct<8, 1, 4, 9, TPK>(a, st); }
@@ -356,6 +441,8 @@ int dispatch_ct(CtArgs& a, hipStream_t st) {
 // out[chunk][kstep][ntile][lane][e]: lane (i = lane&15, g = lane>>4), octet g -> tap kstep*TPK + g/PL,
 // channel chunk*CK + (g%PL)*8 + e.  transpose = 0: rows n = Cout, reduction c = Cin (forward);
 // transpose = 1: rows n = Cin, reduction c = Cout, taps flipped (input gradient).
+__device__ uint4 g_zero16 = {0u, 0u, 0u, 0u};
+
 __global__ void pack_frag_kernel(const float* __restrict__ w, unsigned short* __restrict__ out, int Cout, int Cin,
                                  int KX, int KY, int KZ, int transpose, int TPK, int nchunks, int nts, int NT_total) {
   const int PL = 4 / TPK, CK = 8 * PL;
@@ -429,6 +516,14 @@ static int run_conv_tile(CtArgs& a, int red, hipStream_t st) {
   const int ck = 32 / tpk;
   a.nchunks = (red + ck - 1) / ck;
   a.cin_valid = red;
+  {
+    static void* zp = nullptr;
+    if (!zp) {
+      hipError_t e = hipGetSymbolAddress(&zp, HIP_SYMBOL(g_zero16));
+      if (e != hipSuccess) return (int)e;
+    }
+    a.zero16 = zp;
+  }
   a.vec_ok = (!a.out_planar && a.out_ctot % 4 == 0 && a.out_off % 4 == 0 &&
               (!a.res || (a.res_ctot % 4 == 0 && a.res_off % 4 == 0)))
                  ? 1

@@ -1,0 +1,86 @@
+#!/usr/bin/env python
+"""Micro-benchmark of single conv launches through the C-ABI (device time via HIP events).
+
+    python tools/bench_conv.py [case ...]      cases: rdb hr0 hr0w rdbw up lff dg224 hr1 all
+"""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+
+from gan_sr_wind_field_amd import hip_ops as o  # noqa: E402
+
+DEV = "cuda:0"
+DT = torch.bfloat16
+
+
+def timeit(fn, iters=20, warm=3):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters  # ms
+
+
+def conv_case(name, cin, cout, k, xyz, in_ctot=None, out_ctot=None, out_off=0, ups=False, what="fwd"):
+    B = 1
+    in_ctot = in_ctot or cin
+    geom = o.ConvGeom(cin, cout, k, (1, 1, 1), tuple(kk // 2 for kk in k), upsample=ups)
+    g = torch.Generator(device=DEV).manual_seed(1)
+    x = torch.randn((B,) + xyz + (in_ctot,), device=DEV, generator=g).to(DT)
+    w = torch.randn((cout, cin) + k, device=DEV, generator=g) * 0.05
+    d = o.make_desc(geom, DT, B, xyz, in_ctot, 0, out_ctot or cout, out_off)
+    oxyz = (d.Xo, d.Yo, d.Zo)
+    y = torch.zeros((B,) + oxyz + (out_ctot or cout,), dtype=DT, device=DEV)
+    vox = oxyz[0] * oxyz[1] * oxyz[2]
+    flops = 2.0 * vox * cin * cout * k[0] * k[1] * k[2]
+    if what == "fwd":
+        wf = o.pack_filter_frag(w)
+        ms = timeit(lambda: o.conv_fwd_tile(d, x, wf, y, act=True))
+    elif what == "fwd_generic":
+        wp = o.pack_filter(w, DT)
+        ms = timeit(lambda: o.conv_fwd(d, x, wp, y, act=True))
+    elif what == "dgrad":
+        wft = o.pack_filter_frag(w, transpose=True)
+        gy = torch.randn_like(y)
+        dx = torch.zeros((B,) + tuple(oxyz) + (in_ctot,), dtype=DT, device=DEV)
+        ms = timeit(lambda: o.conv_dgrad_tile(d, gy, wft, dx))
+    elif what == "wgrad":
+        gy = torch.randn_like(y)
+        dw = torch.zeros((cout, geom.taps, cin), dtype=torch.float32, device=DEV)
+        ms = timeit(lambda: o.conv_wgrad(d, x, gy, dw))
+    print(f"{name:28s} {what:12s} {ms * 1e3:9.1f} us  {flops / ms / 1e9:8.1f} TF/s")
+
+
+LR = (32, 32, 128)
+HR = (128, 128, 128)
+CASES = {
+    "rdb": lambda: [conv_case(f"rdb conv{i} {128 + 32 * i}->32", 128 + 32 * i, 32, (3, 3, 3), LR, 256, 256, 128 + 32 * i)
+                    for i in range(4)],
+    "rdbg": lambda: conv_case("rdb conv3 224->32", 224, 32, (3, 3, 3), LR, 256, 256, 224, what="fwd_generic"),
+    "hr0": lambda: [conv_case("hr0 144->144 k5", 144, 144, (5, 5, 5), HR, what=w) for w in ("fwd", "dgrad")],
+    "hr0w": lambda: conv_case("hr0 144->144 k5", 144, 144, (5, 5, 5), HR, what="wgrad"),
+    "up": lambda: [conv_case("up1 128->128 (64^2)", 128, 128, (3, 3, 3), (32, 32, 128), ups=True),
+                   conv_case("up2 128->128 (128^2)", 128, 128, (3, 3, 3), (64, 64, 128), ups=True),
+                   conv_case("up2 dgrad", 128, 128, (3, 3, 3), (128, 128, 128), what="dgrad"),
+                   conv_case("up2 wgrad", 128, 128, (3, 3, 3), (64, 64, 128), ups=True, what="wgrad")],
+    "lff": lambda: [conv_case("lff 256->128 k1", 256, 128, (1, 1, 1), LR),
+                    conv_case("lff dgrad", 256, 128, (1, 1, 1), LR, what="dgrad")],
+    "dg": lambda: [conv_case(f"rdb dgrad 32->{128 + 32 * i}", 128 + 32 * i, 32, (3, 3, 3), LR, 256, 256, 0, what="dgrad")
+                   for i in range(4)],
+    "hr1": lambda: [conv_case("hr1 144->3 k5", 144, 3, (5, 5, 5), HR, 144, 8, what=w) for w in ("fwd", "dgrad", "wgrad")],
+    "lr": lambda: [conv_case("lr_conv 128->128", 128, 128, (3, 3, 3), LR, what=w) for w in ("fwd", "dgrad", "wgrad")],
+}
+
+if __name__ == "__main__":
+    names = sys.argv[1:] or ["all"]
+    if names == ["all"]:
+        names = list(CASES)
+    for n in names:
+        CASES[n]()
