@@ -136,14 +136,28 @@ class DataParallel:
         """Wire a ``wind_field_GAN_3D`` for data-parallel training."""
         gan.dp = self
         self.broadcast_module(gan.G)
-        progG = gan.G.program() if hasattr(gan.G, "program") else None
+
+        def hip_backed(module) -> bool:
+            # the fused HIP programs produce gradients in flat buckets; anything else (the classifier
+            # head, or CPU stand-in networks in the gloo tests) goes through per-parameter hooks
+            return hasattr(module, "program") and next(module.parameters()).is_cuda
+
+        def hook_params(module):
+            for p in module.parameters():
+                p.register_post_accumulate_grad_hook(lambda p_: self._avg_async(p_.grad))
+
+        progG = gan.G.program() if hip_backed(gan.G) else None
+        if progG is None:
+            hook_params(gan.G)
         if progG is not None:
             progG.grad_ready_hook = lambda flat, lo, hi: self.grad_ready("G", flat, lo, hi)
             progG.grad_done_hook = lambda: self.grad_done("G")
         if getattr(gan, "D", None) is not None:
             self.broadcast_module(gan.D)
             feats = gan.D.features
-            progD = feats.program() if hasattr(feats, "program") else None
+            progD = feats.program() if hip_backed(feats) else None
+            if progD is None:
+                hook_params(feats)
             if progD is not None:
                 progD.grad_ready_hook = lambda flat, lo, hi: self.grad_ready("D", flat, lo, hi)
                 progD.grad_done_hook = lambda: self.grad_done("D")

@@ -1,0 +1,120 @@
+"""Data-parallel path on the CPU: world_size = 2 over gloo (``dist.py``).
+
+The collectives that make an N-rank step equal the single-process step on the
+concatenated batch - RaGAN batch means (with their backward), the max-reduced
+physics-loss normalisers, bucketed gradient averaging - are exercised with the
+product ``wind_field_GAN_3D`` whose networks are answered by the CPU oracle
+(``tests/oracle_nets.py``); the HIP programs plug into the same hooks on the GPU.
+"""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+from conftest import REPO
+
+LOCAL_INI = os.path.join(REPO, "gan_sr_wind_field_amd", "config", "wind_field_GAN_3D_config_local.ini")
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _build_gan():
+    import oracle_nets
+    from gan_sr_wind_field_amd.config.config import Config
+    from gan_sr_wind_field_amd.GAN_models import wind_field_GAN_3D as mod
+    from oracle import nets as onets
+
+    mod.Generator_3D = oracle_nets.OracleGenerator
+    mod.Discriminator_3D = oracle_nets.OracleDiscriminator
+    cfg = Config(LOCAL_INI)
+    cfg.is_train, cfg.is_test, cfg.is_use = True, False, False
+    cfg.gpu_id, cfg.device = None, torch.device("cpu")
+    cfg.generator.num_features, cfg.generator.num_RRDB, cfg.generator.RDB_growth_chan = 16, 1, 8
+    cfg.generator.terrain_number_of_features = 4
+    cfg.generator.dropout_probability = cfg.discriminator.dropout_probability = 0.0
+    cfg.discriminator.num_features = 4
+    cfg.gan_config.number_of_z_layers = 4
+    cfg.training.use_instance_noise = False
+    cfg.training.use_noisy_labels = False
+    cfg.training.niter = 150000
+    torch.manual_seed(2001)
+    gan = mod.wind_field_GAN_3D(cfg)
+    gs = onets.GSpec(in_channels=4, nf=16, n_rrdb=1, gc=8, tf=4, hr_kern=5, upscale=4)
+    ds = onets.DSpec(bf=4, nz=4, enable_slicing=True)
+    gan.G.load_state_dict(onets.deterministic_state(onets.g_param_shapes(gs), seed=41, scale=0.5))
+    gan.D.load_state_dict(onets.deterministic_state(onets.d_param_shapes(ds), seed=43, scale=1.0))
+    return gan, cfg
+
+
+def _g_iteration(gan, cfg, LR, HR, Z, x, y):
+    gan.feed_xy_niter(x, y, torch.tensor(cfg.training.niter), 1, 1)
+    gan.optimize_parameters(LR, HR, Z, 0)  # it = 0 -> G-iteration (D in eval mode: no batch statistics)
+    sd = gan.G.state_dict()
+    keys = ("model.0.0.weight", "hr_convs.2.weight", "hr_convs.0.0.weight", "model.1.module.0.RDBs.1.LFF.bias")
+    losses = {k: float(v) for k, v in gan.get_G_train_loss_dict_ref().items()}
+    return {k: sd[k].clone() for k in keys}, losses
+
+
+def _worker(rank, world, port, out_dir):
+    import sys
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    torch.set_num_threads(2)
+    import torch.distributed as dist
+    from gan_sr_wind_field_amd import dist as wdist
+    from oracle.gan import synthetic_batch
+
+    assert wdist.init_from_env("gloo")
+    gan, cfg = _build_gan()
+    dp = wdist.attach(gan, bucket_mb=0.05, sync_bn=True)
+    LR, HR, Z, x, y = synthetic_batch(world, 16, 4, 4, seed=2001)
+    sl = slice(rank, rank + 1)  # one sample per rank
+    w, losses = _g_iteration(gan, cfg, LR[sl], HR[sl], Z[sl], x, y)
+    # primitives
+    t = torch.tensor([1.0 + rank, 3.0 * (rank + 1)], requires_grad=True)
+    m = dp.batch_mean(t)
+    (m * m).backward()
+    mx = dp.global_max(torch.tensor([float(rank), -float(rank)]))
+    torch.save({"w": w, "losses": losses, "mean": float(m), "mean_grad": t.grad.clone(), "max": mx,
+                "n_coll": dp.n_collectives}, os.path.join(out_dir, f"rank{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_g_iteration_equals_full_batch(tmp_path):
+    import sys
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    from oracle.gan import synthetic_batch
+
+    world, port = 2, _free_port()
+    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    r0 = torch.load(tmp_path / "rank0.pt")
+    r1 = torch.load(tmp_path / "rank1.pt")
+
+    gan, cfg = _build_gan()
+    LR, HR, Z, x, y = synthetic_batch(world, 16, 4, 4, seed=2001)
+    w_ref, losses_ref = _g_iteration(gan, cfg, LR, HR, Z, x, y)
+    for k, v in w_ref.items():
+        # both ranks end with the same weights, equal to the single-process step on the full batch
+        assert torch.equal(r0["w"][k], r1["w"][k]), k
+        np.testing.assert_allclose(r0["w"][k].numpy(), v.numpy(), rtol=2e-5, atol=1e-7, err_msg=k)
+    # batch-mean losses: the average over ranks of the per-rank means is the full-batch mean for the
+    # terms that are plain means over samples (pix); adversarial uses the global logit means
+    np.testing.assert_allclose(0.5 * (r0["losses"]["pix"] + r1["losses"]["pix"]), losses_ref["pix"], rtol=1e-5)
+    np.testing.assert_allclose(0.5 * (r0["losses"]["adversarial"] + r1["losses"]["adversarial"]),
+                               losses_ref["adversarial"], rtol=1e-4)
+    # primitives: mean over the 4 values {1, 3, 2, 6} = 3; d(m^2)/dt_i = 2 m / 4 per rank, summed over ranks' losses
+    assert abs(r0["mean"] - 3.0) < 1e-6 and abs(r1["mean"] - 3.0) < 1e-6
+    np.testing.assert_allclose(r0["mean_grad"].numpy(), np.full(2, 2 * 2 * 3.0 / 4), rtol=1e-6)
+    assert r0["max"].tolist() == [1.0, 0.0]
+    assert r0["n_coll"] >= 2  # more than one gradient bucket was all-reduced
