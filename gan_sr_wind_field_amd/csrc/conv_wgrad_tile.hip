@@ -2,22 +2,28 @@
 //
 //   dw[n, tap, c] += sum_v dy[v, n] * x[v + tap - pad, c]
 //
-// A workgroup owns one (n-chunk of 16*TN output channels, c-chunk of 16*CT input
-// channels) pair and walks a strided list of spatial tiles.  Per tile it stages
+// A workgroup (8 waves) owns one (n-chunk of 16*TN output channels, c-chunk of
+// 16*CT input channels) pair and walks a strided list of spatial tiles.  Per tile
 //   Xs : the input tile WITH its halo, (TX+KX-1)(TY+KY-1)(TZ+KZ-1) voxels x 16*CT ch
 //   Ys : the output-gradient tile, TX*TY*TZ voxels x 16*TN ch
-// once, and then contracts over the tile's voxels for ALL taps: the x operand of
-// tap (kx,ky,kz) is the same LDS image read at a shifted voxel index, so x and dy
-// are fetched from HBM/L2 once per tile instead of once per tap.  Accumulators for
-// every (tap, 16-channel c-tile) "slot" stay in registers across the whole tile
-// list (slots are dealt round-robin to the waves: wavefront-level partial sums),
-// and are added to the fp32 gradient once, at the very end.
+// are brought into LDS once by LDS-DMA (global_load_lds), the NEXT tile's DMA in
+// flight while the current one is contracted, and the contraction over the tile's
+// voxels runs for ALL taps: the x operand of tap (kx,ky,kz) is the same LDS image
+// read at a shifted voxel index, so x and dy leave L2/HBM once per tile, not once
+// per tap.  Accumulators of every (tap, 16-channel c-tile) "slot" stay in
+// registers across the whole tile list (slots are dealt round-robin to the waves:
+// wavefront-level partial sums) and are added to the fp32 gradient once, at the end.
 //
-// LDS images are octet-major planes [8-channel octet][voxel][16 B]; the reduction
-// index (voxel) is the slow dimension of both MFMA operands, so fragments are
-// fetched with the transposing read ds_read_b64_tr_b16.  The plane stride is
-// == 64 (mod 256) bytes, which makes the four 64-byte runs a half-wave touches
-// (2 voxel quads x 2 octets) land on disjoint banks.
+// LDS images are voxel-major rows so that the lanes of one DMA instruction fetch
+// whole 32..128-byte runs of a voxel:  Xs = CT planes of 32-byte rows [c-tile][halo
+// voxel][16 ch], Ys = 128-byte rows [voxel][8 octets] (the last 8-2*TN octets are
+// padding).  The reduction index (voxel) is the slow dimension of both MFMA
+// operands, so fragments come from the transposing read ds_read_b64_tr_b16.  The
+// MFMA k index is mapped to voxels so that a half-wave reads 8 CONSECUTIVE voxels
+// (k = 8G+j <-> voxel 4G + (j&3) + 16*(j>>2) of the 32-voxel step): for x that is
+// 256 contiguous bytes at any tap shift - conflict free, and the shifted address is
+// just base + tap offset; for dy the 32-byte blocks of a row are XOR-swizzled by
+// (voxel>>1)&3 (on the DMA source side: the LDS destination of a DMA is linear).
 //
 // `tri_step` > 0 describes the block-triangular structure of a residual dense
 // block: output channel n belongs to conv i = n / tri_step whose input is only
@@ -34,16 +40,18 @@ struct WgtArgs {
   const unsigned short* x;
   const unsigned short* dy;
   float* dw;
+  const void* zero16;
   int B, Xi, Yi, Zi, Xo, Yo, Zo;
   int Cin, in_ctot, in_off;    // Cin = padded channel count of the x window (dw row length)
   int Cout, out_ctot, out_off; // Cout = channels of dy that are real (dw rows)
   int KX, KY, KZ, px, py, pz, ups;
   int TX, TY, TZ;              // output tile
-  int CT;                      // 16-channel c-tiles per c-chunk
   int n_chunks, c_chunks, S;   // grid = n_chunks * c_chunks * S
   int tiles_x, tiles_y, tiles_z, ntiles;
-  int PX, PY;                  // plane strides (bytes)
-  int off_mtab, off_htab, off_vtab, off_xs, off_ys;  // LDS carve (bytes)
+  int nbuf;                    // LDS tile buffers (2: next tile's DMA overlaps the MFMAs)
+  int xp_bytes;                // one c-tile plane of the x image
+  int xs_bytes, buf_bytes;     // Xs image size (CT planes), Xs + Ys size (per buffer)
+  int off_buf;                 // LDS carve (bytes); htab sits at 0
   int tri_base, tri_step;
 };
 
@@ -54,9 +62,26 @@ __device__ __forceinline__ uint4 tr_frag(const char* lo, const char* hi) {
   return make_uint4(l2.x, l2.y, h2.x, h2.y);
 }
 
-template <int WAVES, int TN, int SPW>
-__global__ __launch_bounds__(WAVES * 64) void wgrad_tile_kernel(const WgtArgs a) {
-  constexpr int NT = WAVES * 64;
+// LDS-DMA of 16 B per lane: LDS[lds_addr + 16*lane] <- *gsrc (see conv_tile.hip: inline asm keeps hipcc
+// from draining it in front of every LDS read; waited for explicitly with dma_wait()).
+__device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_addr) {
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(gsrc), "s"(lds_addr)
+      : "memory");
+}
+__device__ __forceinline__ void dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+// 32-byte block swizzle of the dy image (128-byte rows): 8 consecutive voxels x one n-tile -> 8 distinct slots
+__device__ __forceinline__ int ysw(int v) { return (v >> 1) & 3; }
+
+template <int TN, int SPW, int CT>
+__global__ __launch_bounds__(512) void wgrad_tile_kernel(const WgtArgs a) {
+  constexpr int WAVES = 8, NT = 512;
+  constexpr int XRPU = 32;            // x rows (32 B) per 1 KB DMA unit
+  constexpr int XK = 6, YK = 5;       // DMA units per wave per tile (checked on the host)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int t = threadIdx.x, lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -65,12 +90,10 @@ __global__ __launch_bounds__(WAVES * 64) void wgrad_tile_kernel(const WgtArgs a)
   const int L = Lx * Ly * Lz;
   const int M = a.TX * a.TY * a.TZ;
   const int taps = a.KX * a.KY * a.KZ;
-
-  unsigned* mtab = reinterpret_cast<unsigned*>(smem + a.off_mtab);          // [M]  ox | oy<<8 | oz<<16
-  unsigned short* htab = reinterpret_cast<unsigned short*>(smem + a.off_htab);  // [M] halo index of voxel m
-  unsigned* vtab = reinterpret_cast<unsigned*>(smem + a.off_vtab);          // [L]  hx | hy<<8 | hz<<16
-  char* Xs = smem + a.off_xs;
-  char* Ys = smem + a.off_ys;
+  unsigned short* htab = reinterpret_cast<unsigned short*>(smem);  // [M] halo index of voxel m
+  char* buf0 = smem + a.off_buf;
+  typedef __attribute__((address_space(3))) char* lptr_t;
+  const unsigned buf_lds = (unsigned)(unsigned long)(lptr_t)buf0;
 
   // ---- which chunk pair / spatial slice ------------------------------------------
   int bid = xcd_remap(blockIdx.x, gridDim.x);
@@ -78,7 +101,7 @@ __global__ __launch_bounds__(WAVES * 64) void wgrad_tile_kernel(const WgtArgs a)
   bid /= a.c_chunks;
   const int nc = bid % a.n_chunks;
   const int s0 = bid / a.n_chunks;
-  const int c0 = cc * 16 * a.CT, n0 = nc * 16 * TN;
+  const int c0 = cc * 16 * CT, n0 = nc * 16 * TN;
 
   // block-triangular structure: n-tile i is needed iff c0 < tri_base + tri_step*conv(n)
   bool act[TN];
@@ -96,33 +119,111 @@ __global__ __launch_bounds__(WAVES * 64) void wgrad_tile_kernel(const WgtArgs a)
   }
   if (!any) return;  // uniform over the workgroup
 
-  // ---- per-kernel tables ------------------------------------------------------------
   for (int m = t; m < M; m += NT) {
     const int oz = m % a.TZ, r = m / a.TZ;
     const int oy = r % a.TY, ox = r / a.TY;
-    mtab[m] = ox | (oy << 8) | (oz << 16);
     htab[m] = (unsigned short)((ox * Ly + oy) * Lz + oz);
   }
-  for (int v = t; v < L; v += NT) {
-    const int hz = v % Lz, r = v / Lz;
-    const int hy = r % Ly, hx = r / Ly;
-    vtab[v] = hx | (hy << 8) | (hz << 16);
+
+  // ---- DMA geometry of this lane, resolved once (tiles differ only in their origin) ------------
+  // geo = x | y<<8 | z<<16 | valid<<24 | (channel offset / 8)<<25 of what this lane fetches in unit k
+  const int XUP = (L + XRPU - 1) / XRPU;  // 1 KB units per c-tile plane of the x image
+  const int XU = XUP * CT;
+  const int YU = (M + 7) >> 3;           // ... of the dy image (8 rows of 128 B)
+  unsigned xgeo[XK], ygeo[YK];
+#pragma unroll
+  for (int k = 0; k < XK; ++k) {
+    const int u = wave + WAVES * k;
+    unsigned geo = 0;
+    if (u < XU) {
+      const int ct = u / XUP;
+      const int h = (u - ct * XUP) * XRPU + (lane >> 1);  // halo voxel = LDS row of plane ct
+      const int ch8 = 2 * ct + (lane & 1);
+      if (h < L) {
+        const int hz = h % Lz, q = h / Lz;
+        const int hy = q % Ly, hx = q / Ly;
+        geo = hx | (hy << 8) | (hz << 16) | (1u << 24) | ((unsigned)ch8 << 25);
+      }
+    }
+    xgeo[k] = geo;
+  }
+#pragma unroll
+  for (int k = 0; k < YK; ++k) {
+    const int u = wave + WAVES * k;
+    unsigned geo = 0;
+    if (u < YU) {
+      const int v = u * 8 + (lane >> 3), s = lane & 7;
+      const int b32 = (s >> 1) ^ ysw(v);
+      if (v < M && b32 < TN) {
+        const int oz = v % a.TZ, q = v / a.TZ;
+        const int oy = q % a.TY, ox = q / a.TY;
+        geo = ox | (oy << 8) | (oz << 16) | (1u << 24) | ((unsigned)(2 * b32 + (s & 1)) << 25);
+      }
+    }
+    ygeo[k] = geo;
   }
 
+  const int U = a.ups ? 1 : 0;
+  const unsigned short* zsrc = reinterpret_cast<const unsigned short*>(a.zero16);
+  auto issue_tile = [&](int tile, int buf) {
+    int r = tile;
+    const int tz = r % a.tiles_z; r /= a.tiles_z;
+    const int ty = r % a.tiles_y; r /= a.tiles_y;
+    const int tx = r % a.tiles_x;
+    const int b = r / a.tiles_x;
+    const int x0 = tx * a.TX, y0 = ty * a.TY, z0 = tz * a.TZ;
+    const unsigned dstx = buf_lds + buf * a.buf_bytes;
+    const unsigned dsty = dstx + a.xs_bytes;
+#pragma unroll
+    for (int k = 0; k < XK; ++k) {
+      const int u = wave + WAVES * k;
+      if (u < XU) {
+        const unsigned geo = xgeo[k];
+        const int gx = x0 - a.px + (int)(geo & 255), gy = y0 - a.py + (int)((geo >> 8) & 255),
+                  gz = z0 - a.pz + (int)((geo >> 16) & 255);
+        const unsigned short* src = zsrc;
+        const int c = c0 + 8 * (int)(geo >> 25);
+        if (((geo >> 24) & 1) && (unsigned)gx < (unsigned)(a.Xi << U) && (unsigned)gy < (unsigned)(a.Yi << U) &&
+            (unsigned)gz < (unsigned)a.Zi && c < a.Cin) {
+          const long vox = (((long)b * a.Xi + (gx >> U)) * a.Yi + (gy >> U)) * a.Zi + gz;
+          src = a.x + vox * a.in_ctot + a.in_off + c;
+        }
+        glds16(src, __builtin_amdgcn_readfirstlane(dstx + u * 1024));
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < YK; ++k) {
+      const int u = wave + WAVES * k;
+      if (u < YU) {
+        const unsigned geo = ygeo[k];
+        const int gx = x0 + (int)(geo & 255), gy = y0 + (int)((geo >> 8) & 255), gz = z0 + (int)((geo >> 16) & 255);
+        const unsigned short* src = zsrc;
+        const int n = n0 + 8 * (int)(geo >> 25);
+        // channel windows are whole octets here (the host routes anything else to the per-tap kernel)
+        if (((geo >> 24) & 1) && gx < a.Xo && gy < a.Yo && gz < a.Zo && n < a.Cout) {
+          const long vox = (((long)b * a.Xo + gx) * a.Yo + gy) * a.Zo + gz;
+          src = a.dy + vox * a.out_ctot + a.out_off + n;
+        }
+        glds16(src, __builtin_amdgcn_readfirstlane(dsty + u * 1024));
+      }
+    }
+  };
+
   // ---- this wave's slots: (tap, c-tile) pairs ------------------------------------------
-  const int nslots = taps * a.CT;
-  int soff[SPW];  // byte offset of the slot's x image relative to the un-shifted one
+  const int nslots = taps * CT;
+  int soff[SPW];  // byte offset of the slot's x rows relative to the un-shifted tap of c-tile 0
 #pragma unroll
   for (int j = 0; j < SPW; ++j) {
     const int sj = wave + WAVES * j;
-    int off = 0;
+    int off = 0, ct = 0;
     if (sj < nslots) {
-      const int tap = sj / a.CT, ct = sj % a.CT;
+      const int tap = sj / CT;
+      ct = sj % CT;
       const int kz = tap % a.KZ, r = tap / a.KZ;
       const int ky = r % a.KY, kx = r / a.KY;
-      off = 2 * ct * a.PX + ((kx * Ly + ky) * Lz + kz) * 16;
+      off = (kx * Ly + ky) * Lz + kz;
     }
-    soff[j] = __builtin_amdgcn_readfirstlane(off);
+    soff[j] = __builtin_amdgcn_readfirstlane(off * 32 + ct * a.xp_bytes);
   }
 
   f32x4_t acc[SPW][TN];
@@ -131,85 +232,45 @@ __global__ __launch_bounds__(WAVES * 64) void wgrad_tile_kernel(const WgtArgs a)
 #pragma unroll
     for (int i = 0; i < TN; ++i) acc[j][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
-  // tr-read lane roles: 16-lane group G supplies rows (voxels) 8G+q, columns 4p..4p+3
+  // tr-read lane roles: 16-lane group G supplies rows (voxels) 4G+q (+16), columns 4p..4p+3 of a 16-wide tile
   const int G = lane >> 4, q = (lane & 15) >> 2, p = lane & 3;
-  const int lane_x = (p >> 1) * a.PX + (p & 1) * 8;
-  const int lane_y = (p >> 1) * a.PY + (p & 1) * 8;
-  const int XP = 2 * a.CT, YP = 2 * TN;
-  const int U = a.ups ? 1 : 0;
   const int ksteps = M >> 5;
 
-  for (int tile = s0; tile < a.ntiles; tile += a.S) {
-    int r = tile;
-    const int tz = r % a.tiles_z; r /= a.tiles_z;
-    const int ty = r % a.tiles_y; r /= a.tiles_y;
-    const int tx = r % a.tiles_x;
-    const int b = r / a.tiles_x;
-    const int x0 = tx * a.TX, y0 = ty * a.TY, z0 = tz * a.TZ;
-
-    __syncthreads();  // tables ready / previous tile's fragment reads done
-    // ---- stage x (with halo) ------------------------------------------------------
-    for (int i = t; i < L * XP; i += NT) {
-      const int v = i / XP, pl = i - v * XP;
-      const unsigned hv = vtab[v];
-      const int gx = x0 - a.px + (int)(hv & 255), gy = y0 - a.py + (int)((hv >> 8) & 255),
-                gz = z0 - a.pz + (int)(hv >> 16);
-      uint4 val = make_uint4(0, 0, 0, 0);
-      const int c = c0 + 8 * pl;
-      if ((unsigned)gx < (unsigned)(a.Xi << U) && (unsigned)gy < (unsigned)(a.Yi << U) &&
-          (unsigned)gz < (unsigned)a.Zi && c < a.Cin) {
-        const long vox = (((long)b * a.Xi + (gx >> U)) * a.Yi + (gy >> U)) * a.Zi + gz;
-        val = *reinterpret_cast<const uint4*>(a.x + vox * a.in_ctot + a.in_off + c);
-      }
-      *reinterpret_cast<uint4*>(Xs + pl * a.PX + v * 16) = val;
-    }
-    // ---- stage dy -------------------------------------------------------------------
-    for (int i = t; i < M * YP; i += NT) {
-      const int m = i / YP, pl = i - m * YP;
-      const unsigned mv = mtab[m];
-      const int gx = x0 + (int)(mv & 255), gy = y0 + (int)((mv >> 8) & 255), gz = z0 + (int)(mv >> 16);
-      uint4 val = make_uint4(0, 0, 0, 0);
-      const int n = n0 + 8 * pl;
-      if (gx < a.Xo && gy < a.Yo && gz < a.Zo && n < a.Cout) {
-        const long vox = (((long)b * a.Xo + gx) * a.Yo + gy) * a.Zo + gz;
-        const unsigned short* src = a.dy + vox * a.out_ctot + a.out_off + n;
-        if (n + 8 <= a.Cout) {
-          val = *reinterpret_cast<const uint4*>(src);
-        } else {  // ragged tail of the channel window (e.g. the 3-channel SR output)
-          unsigned short tmp[8];
+  // Software pipeline over the tile list: iteration `it` prefetches tile s0 + it*S into buffer it&1 while
+  // tile s0 + (it-1)*S is contracted out of the other buffer (one DMA call site, one MFMA call site).
+  for (int it = 0;; ++it) {
+    const int pre = s0 + it * a.S;
+    if (pre < a.ntiles) issue_tile(pre, it & 1);
+    if (it > 0) {
+      const char* Xs = buf0 + ((it - 1) & 1) * a.buf_bytes;
+      const char* Ys = Xs + a.xs_bytes;
+      for (int ks = 0; ks < ksteps; ++ks) {
+        const int m_lo = ks * 32 + 4 * G + q, m_hi = m_lo + 16;
+        const char* xlo = Xs + (int)htab[m_lo] * 32 + p * 8;
+        const char* xhi = Xs + (int)htab[m_hi] * 32 + p * 8;
+        uint4 af[TN];
+        {
+          const char* rlo = Ys + m_lo * 128 + p * 8;
+          const char* rhi = Ys + m_hi * 128 + p * 8;
+          const int slo = ysw(m_lo), shi = ysw(m_hi);
 #pragma unroll
-          for (int e = 0; e < 8; ++e) tmp[e] = (n + e < a.Cout) ? src[e] : (unsigned short)0;
-          val = *reinterpret_cast<uint4*>(tmp);
+          for (int i = 0; i < TN; ++i) af[i] = tr_frag(rlo + ((i ^ slo) << 5), rhi + ((i ^ shi) << 5));
         }
-      }
-      *reinterpret_cast<uint4*>(Ys + pl * a.PY + m * 16) = val;
-    }
-    __syncthreads();
-
-    // ---- contract over the tile's voxels, 32 per step --------------------------------------
-    for (int ks = 0; ks < ksteps; ++ks) {
-      const int m_lo = ks * 32 + 8 * G + q;
-      const int h_lo = htab[m_lo], h_hi = htab[m_lo + 4];
-      uint4 af[TN];
+        // branch-free over slots and n-tiles: a slot past the end re-reads tap 0 into accumulators that are
+        // never flushed, an n-tile the triangular structure does not need is computed and dropped at the flush
 #pragma unroll
-      for (int i = 0; i < TN; ++i) {
-        const char* base = Ys + 2 * i * a.PY + lane_y;
-        af[i] = tr_frag(base + m_lo * 16, base + (m_lo + 4) * 16);
-      }
-      const char* xlo = Xs + lane_x + h_lo * 16;
-      const char* xhi = Xs + lane_x + h_hi * 16;
-#pragma unroll
-      for (int j = 0; j < SPW; ++j) {
-        if (wave + WAVES * j < nslots) {
+        for (int j = 0; j < SPW; ++j) {
           const uint4 bf = tr_frag(xlo + soff[j], xhi + soff[j]);
 #pragma unroll
           for (int i = 0; i < TN; ++i)
-            if (act[i])
-              acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, af[i]),
-                                                                  __builtin_bit_cast(bf16x8_t, bf), acc[j][i], 0, 0, 0);
+            acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, af[i]),
+                                                                __builtin_bit_cast(bf16x8_t, bf), acc[j][i], 0, 0, 0);
         }
       }
     }
+    dma_wait();
+    __syncthreads();  // the prefetched tile has landed for everybody; the buffer just read is free again
+    if (pre >= a.ntiles) break;
   }
 
   // ---- add this workgroup's partial sums: acc[j][i][r] -> n = n0+16i+4G+r, c = c0+16ct+(lane&15)
@@ -217,7 +278,7 @@ __global__ __launch_bounds__(WAVES * 64) void wgrad_tile_kernel(const WgtArgs a)
   for (int j = 0; j < SPW; ++j) {
     const int sj = wave + WAVES * j;
     if (sj >= nslots) continue;
-    const int tap = sj / a.CT, ct = sj % a.CT;
+    const int tap = sj / CT, ct = sj % CT;
     const int c = c0 + 16 * ct + (lane & 15);
     if (c >= a.Cin) continue;
 #pragma unroll
@@ -234,33 +295,62 @@ __global__ __launch_bounds__(WAVES * 64) void wgrad_tile_kernel(const WgtArgs a)
 
 static inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 
-template <int WAVES, int TN, int SPW>
-int launch_tile(WgtArgs& a, int wg_target, hipStream_t st) {
+__device__ uint4 g_wg_zero16 = {0u, 0u, 0u, 0u};
+
+template <int TN, int SPW, int CT>
+int launch_tile(WgtArgs& a, hipStream_t st) {
+  constexpr int WAVES = 8;
   const int taps = a.KX * a.KY * a.KZ;
+  if (taps * CT > WAVES * SPW) return WSR_EUNSUPPORTED;
+  {
+    static void* zp = nullptr;
+    if (!zp) {
+      hipError_t e = hipGetSymbolAddress(&zp, HIP_SYMBOL(g_wg_zero16));
+      if (e != hipSuccess) return (int)e;
+    }
+    a.zero16 = zp;
+  }
+  // tile: z whole when short, else 16 (the two z-octets of a half-wave read stay in one row run); x, y as
+  // large as two LDS buffers and the per-wave DMA unit registers allow
+  const int tz = a.Zo <= 16 ? a.Zo : ((a.Zo % 16 == 0 || a.Zo > 64) ? 16 : 8);
+  static const int cand[][2] = {{8, 8}, {4, 8}, {4, 4}, {2, 4}, {2, 2}, {1, 2}, {1, 1}};
+  int best = -1, best_nbuf = 0;
+  for (int nbuf = 2; nbuf >= 2 && best < 0; --nbuf) {  // the kernel is written for two buffers
+    for (int ci = 0; ci < 7; ++ci) {
+      const int tx = cand[ci][0], ty = cand[ci][1];
+      const int M = tx * ty * tz;
+      if (M & 31) continue;
+      const int L = (tx + a.KX - 1) * (ty + a.KY - 1) * (tz + a.KZ - 1);
+      const int xs = CT * round_up(L * 32, 1024), ys = round_up(M * 128, 1024);
+      if (xs / 1024 > 6 * WAVES || ys / 1024 > 5 * WAVES || L > 65535) continue;
+      if (round_up(M * 2, 1024) + nbuf * (xs + ys) > 160 * 1024) continue;
+      best = ci;
+      best_nbuf = nbuf;
+      break;
+    }
+  }
+  if (best < 0) return WSR_EUNSUPPORTED;
+  a.TX = cand[best][0]; a.TY = cand[best][1]; a.TZ = tz;
+  a.nbuf = best_nbuf;
   const int M = a.TX * a.TY * a.TZ;
   const int L = (a.TX + a.KX - 1) * (a.TY + a.KY - 1) * (a.TZ + a.KZ - 1);
-  if (taps * a.CT > WAVES * SPW || (M & 31) || L > 65535) return WSR_EUNSUPPORTED;
-  a.PX = round_up(L * 16, 256) + 64;
-  a.PY = round_up(M * 16, 256) + 64;
-  a.off_mtab = 0;
-  a.off_htab = a.off_mtab + M * 4;
-  a.off_vtab = round_up(a.off_htab + M * 2, 16);
-  a.off_xs = round_up(a.off_vtab + L * 4, 256);
-  a.off_ys = a.off_xs + 2 * a.CT * a.PX;
-  const size_t lds = (size_t)a.off_ys + (size_t)2 * TN * a.PY;
-  if (lds > 160 * 1024) return WSR_EUNSUPPORTED;
+  a.xp_bytes = round_up(L * 32, 1024);
+  a.xs_bytes = CT * a.xp_bytes;
+  a.buf_bytes = a.xs_bytes + round_up(M * 128, 1024);
+  a.off_buf = round_up(M * 2, 1024);
+  const size_t lds = (size_t)a.off_buf + (size_t)a.nbuf * a.buf_bytes;
   a.n_chunks = (a.Cout + 16 * TN - 1) / (16 * TN);
-  a.c_chunks = (a.Cin + 16 * a.CT - 1) / (16 * a.CT);
+  a.c_chunks = (a.Cin + 16 * CT - 1) / (16 * CT);
   a.tiles_x = (a.Xo + a.TX - 1) / a.TX;
   a.tiles_y = (a.Yo + a.TY - 1) / a.TY;
   a.tiles_z = (a.Zo + a.TZ - 1) / a.TZ;
   a.ntiles = a.B * a.tiles_x * a.tiles_y * a.tiles_z;
   const int combos = a.n_chunks * a.c_chunks;
-  int S = (wg_target + combos - 1) / combos;
+  int S = (256 * 3 + combos - 1) / combos;  // ~3 workgroups per CU over the launch, one resident at a time
   if (S > a.ntiles) S = a.ntiles;
   if (S < 1) S = 1;
   a.S = S;
-  auto kern = wgrad_tile_kernel<WAVES, TN, SPW>;
+  auto kern = wgrad_tile_kernel<TN, SPW, CT>;
   static bool attr_done = false;  // raise the dynamic-LDS cap once per instantiation
   if (!attr_done) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -281,9 +371,11 @@ int wsr_wgrad_tile_bf16(const wsr_conv_t* c, const void* x, const void* dy, floa
                         void* stream) {
   if (c->dtype != WSR_BF16 || (c->sx | c->sy | c->sz) != 1) return WSR_EUNSUPPORTED;
   const int taps = c->KX * c->KY * c->KZ;
-  if (taps < 2) return WSR_EUNSUPPORTED;
+  if (taps < 2 || taps > 128) return WSR_EUNSUPPORTED;
   if (c->Cin % 8 || c->in_ctot % 8 || c->in_off % 8 || c->out_ctot % 8 || c->out_off % 8) return WSR_EUNSUPPORTED;
-  const int ux = c->upsample_xy ? 2 : 1;
+  // the dy DMA moves whole octets of the channel window: it must own them (true for padded NDHWC buffers)
+  if (c->out_off + (c->Cout + 7) / 8 * 8 > c->out_ctot) return WSR_EUNSUPPORTED;
+  if (c->KX > 8 || c->KY > 8 || c->KZ > 8) return WSR_EUNSUPPORTED;
   WgtArgs a{};
   a.x = (const unsigned short*)x;
   a.dy = (const unsigned short*)dy;
@@ -294,23 +386,16 @@ int wsr_wgrad_tile_bf16(const wsr_conv_t* c, const void* x, const void* dy, floa
   a.Cout = c->Cout; a.out_ctot = c->out_ctot; a.out_off = c->out_off;
   a.KX = c->KX; a.KY = c->KY; a.KZ = c->KZ;
   a.px = c->px; a.py = c->py; a.pz = c->pz;
-  a.ups = ux == 2;
+  a.ups = c->upsample_xy ? 1 : 0;
   a.tri_base = tri_base; a.tri_step = tri_step;
-  if (c->KX > 8 || c->KY > 8 || c->KZ > 8) return WSR_EUNSUPPORTED;
-  a.TZ = c->Zo <= 12 ? c->Zo : 8;
-  a.CT = 1;
   hipStream_t st = as_stream(stream);
-  if (taps > 28) {  // 5x5x5: eight waves, 16 slots each, one workgroup per CU
-    if (taps > 128) return WSR_EUNSUPPORTED;
-    a.TX = 8; a.TY = 8;
-    if (a.TZ > 10) a.TZ = 8;
-    if (c->Cout <= 16) return launch_tile<8, 1, 16>(a, 256 * 3, st);
-    if (c->Cout % 48 == 0) return launch_tile<8, 3, 16>(a, 256 * 3, st);
-    return launch_tile<8, 2, 16>(a, 256 * 3, st);
+  if (taps > 28) {  // 5x5x5: 16 slots per wave, 16 input channels per chunk
+    if (c->Cout <= 16) return launch_tile<1, 16, 1>(a, st);
+    if (c->Cout % 48 == 0) return launch_tile<3, 16, 1>(a, st);
+    return launch_tile<2, 16, 1>(a, st);
   }
-  // <= 28 taps (3x3x3): four waves, 7 slots each, several workgroups per CU overlap load and MFMA
-  a.TX = 4; a.TY = 8;
-  if (c->Cout <= 16) return launch_tile<4, 1, 7>(a, 256 * 8, st);
-  if (c->Cout <= 32) return launch_tile<4, 2, 7>(a, 256 * 8, st);
-  return launch_tile<4, 4, 7>(a, 256 * 8, st);
+  // <= 28 taps (3x3x3): 7 slots per wave = 28 taps x 2 c-tiles (32 input channels per chunk)
+  if (c->Cout <= 16) return launch_tile<1, 7, 2>(a, st);
+  if (c->Cout <= 32) return launch_tile<2, 7, 2>(a, st);
+  return launch_tile<4, 7, 2>(a, st);
 }

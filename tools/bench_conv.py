@@ -58,6 +58,19 @@ def conv_case(name, cin, cout, k, xyz, in_ctot=None, out_ctot=None, out_off=0, u
     print(f"{name:28s} {what:12s} {ms * 1e3:9.1f} us  {flops / ms / 1e9:8.1f} TF/s")
 
 
+def tri_case():
+    B, xyz, nf, gc, nconv = 1, (32, 32, 128), 128, 32, 4
+    g = torch.Generator(device=DEV).manual_seed(1)
+    x = torch.randn((B,) + xyz + (256,), device=DEV, generator=g).to(DT)
+    gd = torch.randn((B,) + xyz + (256,), device=DEV, generator=g).to(DT)
+    cin_w, cout = nf + (nconv - 1) * gc, nconv * gc
+    d = o.make_desc(o.ConvGeom(cin_w, cout, (3, 3, 3)), DT, B, xyz, 256, 0, 256, nf)
+    dw = torch.zeros((cout, 27, cin_w), dtype=torch.float32, device=DEV)
+    ms = timeit(lambda: o.conv_wgrad_tri(d, x, gd, dw, nf, gc))
+    flops = 2.0 * xyz[0] * xyz[1] * xyz[2] * 27 * gc * sum(nf + i * gc for i in range(nconv))
+    print(f"{'rdb stacked wgrad (4 convs)':28s} {'wgrad_tri':12s} {ms * 1e3:9.1f} us  {flops / ms / 1e9:8.1f} TF/s")
+
+
 LR = (32, 32, 128)
 HR = (128, 128, 128)
 CASES = {
@@ -65,6 +78,7 @@ CASES = {
                     for i in range(4)],
     "rdbg": lambda: conv_case("rdb conv3 224->32", 224, 32, (3, 3, 3), LR, 256, 256, 224, what="fwd_generic"),
     "hr0": lambda: [conv_case("hr0 144->144 k5", 144, 144, (5, 5, 5), HR, what=w) for w in ("fwd", "dgrad")],
+    "rdbw": tri_case,
     "hr0w": lambda: conv_case("hr0 144->144 k5", 144, 144, (5, 5, 5), HR, what="wgrad"),
     "up": lambda: [conv_case("up1 128->128 (64^2)", 128, 128, (3, 3, 3), (32, 32, 128), ups=True),
                    conv_case("up2 128->128 (128^2)", 128, 128, (3, 3, 3), (64, 64, 128), ups=True),
