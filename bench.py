@@ -193,9 +193,11 @@ def main():
                                f"batch {B}/GPU, G 16 RRDB nf128 (34.77M), D 128^3 bf32",
                    "global_batch": B * world, "parallelism": f"dp{world}",
                    "step_tflop": round(pair_flops / 1e12, 2),
-                   "achieved_tflops_per_gpu": round(pair_flops / 1e12 / (elapsed / args.steps), 1)},
-        "roofline": {"bound": "mfma", "kernel": "igemm_kernel<%s,4,1,2,9> (hr_convs.0 5x5x5 144->144 fwd+dgrad)"
-                     % ("BF16" if args.dtype == "bf16" else "F32"),
+                   "achieved_tflops_per_gpu": round(pair_flops / 1e12 / (elapsed / args.steps), 1),
+                   "peak_hbm_gb": round(torch.cuda.max_memory_allocated(dev) / 2**30, 2)},
+        "roofline": {"bound": "mfma",
+                     "kernel": ("conv_tile_kernel<8,1,4,9,2> (LDS halo-tile conv)" if args.dtype == "bf16"
+                                else "igemm_kernel<F32,4,1,2,9>") + ": hr_convs.0 5x5x5 144->144 fwd + dgrad",
                      "achieved": round(achieved, 1) if achieved else None, "peak": peak, "unit": "TFLOP/s",
                      "frac": round(achieved / peak, 4) if achieved else None, "traffic": None,
                      "launches_timed": len(k_ms), "avg_launch_ms": round(sum(k_ms) / len(k_ms), 3) if k_ms else None},
