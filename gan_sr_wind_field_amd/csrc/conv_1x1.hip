@@ -1,0 +1,145 @@
+// 1x1x1 convolution (the local-feature-fusion conv of a residual dense block, reference
+// torch_blocks.py:278-290, and its input gradient) as a streaming GEMM, bf16:
+//
+//   y[v, n] = alpha * (sum_c x[v, c] * w[n, c] + bias[n]) + beta * res[v, n]
+//
+// At 256 -> 128 channels the arithmetic intensity is ~64 flop/byte: the launch is bound by streaming
+// the activations once from HBM, not by the MFMAs.  So the structure is the opposite of the halo-tile
+// kernel: the whole filter (<= 64 KB in MFMA-fragment order) is staged in LDS ONCE per workgroup and
+// re-used for every voxel the workgroup visits, while the activation fragments - each is needed by
+// exactly one wave - go from global memory straight to registers (16 voxels x 64 contiguous bytes per
+// wave-instruction), all K-steps of a 32-voxel strip in flight at once.  MFMA is issued as
+// D = W * X^T, so a lane holds 4 consecutive output channels of one voxel (8-byte stores).
+#include "common.h"
+
+namespace {
+
+struct C1Args {
+  const unsigned short* in;
+  const unsigned short* wf;  // fragment order [K/32][n-tile][64 lanes][8] (wsr_pack_filter_frag, TPK = 1)
+  unsigned short* out;
+  const float* bias;
+  const unsigned short* res;
+  int res_ctot, res_off;
+  float alpha, beta, slope;
+  int act;
+  long nvox;
+  int in_ctot, in_off, out_ctot, out_off, Cout;
+  int nstrips;  // ceil(nvox / (16*TM))
+};
+
+template <int TN, int TM, int KS>
+__global__ __launch_bounds__(256) void conv1x1_kernel(const C1Args a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // KS * TN fragments of 1 KB
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int fr = lane & 15, fg = lane >> 4;
+  {  // stage the filter: linear copy of KS*TN KB
+    const uint4* src = reinterpret_cast<const uint4*>(a.wf);
+    uint4* dst = reinterpret_cast<uint4*>(smem);
+    for (int i = t; i < KS * TN * 64; i += 256) dst[i] = src[i];
+  }
+  __syncthreads();
+  const char* wl = smem + lane * 16;
+
+  for (int strip = blockIdx.x * 4 + wave; strip < a.nstrips; strip += gridDim.x * 4) {
+    const long v0 = (long)strip * (16 * TM);
+    // ---- all activation fragments of the strip: voxel row fr of m-tile i, K-octet fg of K-step ks
+    uint4 xf[KS][TM];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const long v = v0 + 16 * i + fr;
+      const unsigned short* p = a.in + (v < a.nvox ? v : 0) * a.in_ctot + a.in_off + fg * 8;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) xf[ks][i] = *reinterpret_cast<const uint4*>(p + ks * 32);
+    }
+    f32x4_t acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const uint4 w = *reinterpret_cast<const uint4*>(wl + (ks * TN + j) * 1024);
+#pragma unroll
+        for (int i = 0; i < TM; ++i) mma_chunk<BF16>(acc[i][j], w, xf[ks][i]);
+      }
+    }
+    // ---- epilogue: acc[i][j][r] -> channel 16j + 4fg + r of voxel v0 + 16i + fr
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const long v = v0 + 16 * i + fr;
+      if (v >= a.nvox) continue;
+      unsigned short* o = a.out + v * a.out_ctot + a.out_off + 4 * fg;
+      const unsigned short* rp = a.res ? a.res + v * a.res_ctot + a.res_off + 4 * fg : nullptr;
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int co0 = 16 * j + 4 * fg;
+        if (co0 >= a.Cout) continue;  // Cout is a multiple of 4 here (checked on the host)
+        float4 o4 = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+        if (a.bias) {
+          const float4 b4 = *reinterpret_cast<const float4*>(a.bias + co0);
+          o4.x += b4.x; o4.y += b4.y; o4.z += b4.z; o4.w += b4.w;
+        }
+        if (a.act) {
+          o4.x = o4.x > 0.f ? o4.x : o4.x * a.slope;
+          o4.y = o4.y > 0.f ? o4.y : o4.y * a.slope;
+          o4.z = o4.z > 0.f ? o4.z : o4.z * a.slope;
+          o4.w = o4.w > 0.f ? o4.w : o4.w * a.slope;
+        }
+        o4.x *= a.alpha; o4.y *= a.alpha; o4.z *= a.alpha; o4.w *= a.alpha;
+        if (rp) {
+          const float4 r4 = ld4<BF16>(rp + 16 * j);
+          o4.x += a.beta * r4.x; o4.y += a.beta * r4.y; o4.z += a.beta * r4.z; o4.w += a.beta * r4.w;
+        }
+        st4<BF16>(o + 16 * j, o4);
+      }
+    }
+  }
+}
+
+template <int TN, int TM, int KS>
+int launch_c1(const C1Args& a0, hipStream_t st) {
+  C1Args a = a0;
+  a.nstrips = (int)((a.nvox + 16 * TM - 1) / (16 * TM));
+  const size_t lds = (size_t)KS * TN * 1024;
+  auto kern = conv1x1_kernel<TN, TM, KS>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       160 * 1024);
+    if (e != hipSuccess) return (int)e;
+    attr_done = true;
+  }
+  int grid = (a.nstrips + 3) / 4;
+  if (grid > 512) grid = 512;  // two workgroups per CU; the filter is staged once per workgroup
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds, st, a);
+  WSR_LAUNCH_CHECK();
+  return 0;
+}
+
+}  // namespace
+
+// Called by the tile entry points for 1x1x1 convs; WSR_EUNSUPPORTED -> the halo-tile kernel takes over.
+// `red` = reduction channels (multiple of 32), `n_out` = produced channels.
+int wsr_conv1x1_bf16(const unsigned short* in, int in_ctot, int in_off, int red, const unsigned short* wfrag,
+                     unsigned short* out, int out_ctot, int out_off, int n_out, long nvox, const float* bias,
+                     const unsigned short* res, int res_ctot, int res_off, float alpha, float beta, int act,
+                     float slope, hipStream_t st) {
+  if (red % 32 || red > 256 || n_out % 4 || n_out > 256) return WSR_EUNSUPPORTED;
+  if (in_ctot % 8 || in_off % 8 || out_ctot % 4 || out_off % 4 || (res && (res_ctot % 4 || res_off % 4)))
+    return WSR_EUNSUPPORTED;
+  C1Args a{};
+  a.in = in; a.wf = wfrag; a.out = out; a.bias = bias; a.res = res;
+  a.res_ctot = res_ctot; a.res_off = res_off;
+  a.alpha = alpha; a.beta = beta; a.slope = slope; a.act = act;
+  a.nvox = nvox;
+  a.in_ctot = in_ctot; a.in_off = in_off; a.out_ctot = out_ctot; a.out_off = out_off; a.Cout = n_out;
+  if (n_out % 16) return WSR_EUNSUPPORTED;  // the fragment-order filter must have exactly TN n-tiles
+  const int nt = n_out / 16, ks = red / 32;
+  if (nt == 8 && ks == 8) return launch_c1<8, 2, 8>(a, st);    // 256 -> 128 (LFF forward)
+  if (nt == 16 && ks == 4) return launch_c1<16, 1, 4>(a, st);  // 128 -> 256 (LFF input gradient)
+  if (nt == 8 && ks == 4) return launch_c1<8, 2, 4>(a, st);    // 128 -> 128
+  return WSR_EUNSUPPORTED;
+}

@@ -472,7 +472,44 @@ __global__ void pack_frag_kernel(const float* __restrict__ w, unsigned short* __
   }
 }
 
+// one block row (blockIdx.y) per job
+__global__ void pack_frag_multi_kernel(const wsr_pack_job_t* __restrict__ jobs) {
+  const wsr_pack_job_t j = jobs[blockIdx.y];
+  const int taps = j.KX * j.KY * j.KZ;
+  const int rows = j.transpose ? j.Cin : j.Cout, red = j.transpose ? j.Cout : j.Cin;
+  const int redp = (red + 7) / 8 * 8;
+  const int TPK = taps == 1 ? (redp % 32 == 0 ? 1 : (redp % 16 == 0 ? 2 : 4)) : (redp % 16 == 0 ? 2 : 4);
+  const int PL = 4 / TPK, CK = 8 * PL;
+  const int nchunks = (redp + CK - 1) / CK, nts = (taps + TPK - 1) / TPK, NT_total = (rows + 15) / 16;
+  const long total = (long)nchunks * nts * NT_total * 512;
+  const float* __restrict__ w = j.w;
+  unsigned short* __restrict__ out = reinterpret_cast<unsigned short*>(j.out);
+  for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const int e = (int)(idx & 7);
+    const int lane = (int)((idx >> 3) & 63);
+    long q = idx >> 9;
+    const int nt = (int)(q % NT_total); q /= NT_total;
+    const int ts = (int)(q % nts);
+    const int chunk = (int)(q / nts);
+    const int i = lane & 15, g = lane >> 4;
+    const int tap = ts * TPK + g / PL;
+    const int c = chunk * CK + (g % PL) * 8 + e;
+    const int n = nt * 16 + i;
+    float v = 0.f;
+    if (tap < taps && c < red && n < rows)
+      v = j.transpose ? w[((long)c * j.Cin + n) * taps + (taps - 1 - tap)] : w[((long)n * j.Cin + c) * taps + tap];
+    out[idx] = f2bf(v);
+  }
+}
+
 }  // namespace
+
+extern "C" int wsr_pack_filter_frag_multi(const wsr_pack_job_t* jobs_dev, int32_t n_jobs, void* stream) {
+  if (!jobs_dev || n_jobs <= 0 || n_jobs > 65535) return WSR_EINVAL;
+  hipLaunchKernelGGL(pack_frag_multi_kernel, dim3(64, (unsigned)n_jobs), dim3(256), 0, as_stream(stream), jobs_dev);
+  WSR_LAUNCH_CHECK();
+  return 0;
+}
 
 extern "C" int wsr_conv_tile_tpk(int32_t red_channels_padded, int32_t taps) {
   // K-step shape used by the tile kernel for a reduction over `red_channels_padded` (multiple of 8) channels
@@ -533,6 +570,11 @@ static int run_conv_tile(CtArgs& a, int red, hipStream_t st) {
   return dispatch_ct<4>(a, st);
 }
 
+int wsr_conv1x1_bf16(const unsigned short* in, int in_ctot, int in_off, int red, const unsigned short* wfrag,
+                     unsigned short* out, int out_ctot, int out_off, int n_out, long nvox, const float* bias,
+                     const unsigned short* res, int res_ctot, int res_off, float alpha, float beta, int act,
+                     float slope, hipStream_t st);  // conv_1x1.hip
+
 extern "C" int wsr_conv3d_fwd_tile(const wsr_conv_t* c, const void* x, const void* wfrag, void* y,
                                    const wsr_epilogue_t* ep, void* stream) {
   if (!conv_geom_ok(c) || !x || !wfrag || !y) return WSR_EINVAL;
@@ -562,6 +604,12 @@ extern "C" int wsr_conv3d_fwd_tile(const wsr_conv_t* c, const void* x, const voi
   a.Cout = c->Cout; a.out_ctot = c->out_ctot; a.out_off = c->out_off;
   a.KX = c->KX; a.KY = c->KY; a.KZ = c->KZ;
   a.px = c->px; a.py = c->py; a.pz = c->pz;
+  if (c->KX * c->KY * c->KZ == 1 && !a.ups && !a.out_planar && !a.chan_scale && (c->px | c->py | c->pz) == 0) {
+    const int rc = wsr_conv1x1_bf16(a.in, a.in_ctot, a.in_off, c->Cin, a.wf, (unsigned short*)a.out, a.out_ctot,
+                                    a.out_off, a.Cout, (long)c->B * c->Xo * c->Yo * c->Zo, a.bias, a.res, a.res_ctot,
+                                    a.res_off, a.alpha, a.beta, a.act, a.slope, as_stream(stream));
+    if (rc != WSR_EUNSUPPORTED) return rc;
+  }
   return run_conv_tile(a, c->Cin, as_stream(stream));
 }
 
@@ -591,5 +639,11 @@ extern "C" int wsr_conv3d_dgrad_tile(const wsr_conv_t* c, const void* dy, const 
   a.Cout = c->Cin; a.out_ctot = c->in_ctot; a.out_off = c->in_off;
   a.KX = c->KX; a.KY = c->KY; a.KZ = c->KZ;
   a.px = c->KX - 1 - c->px; a.py = c->KY - 1 - c->py; a.pz = c->KZ - 1 - c->pz;
+  if (c->KX * c->KY * c->KZ == 1 && ux == 1 && !a.out_planar && (c->px | c->py | c->pz) == 0) {
+    const int rc = wsr_conv1x1_bf16(a.in, a.in_ctot, a.in_off, c->Cout, a.wf, (unsigned short*)a.out, a.out_ctot,
+                                    a.out_off, a.Cout, (long)c->B * c->Xo * c->Yo * c->Zo, nullptr, a.res, a.res_ctot,
+                                    a.res_off, a.alpha, a.beta, 0, 0.f, as_stream(stream));
+    if (rc != WSR_EUNSUPPORTED) return rc;
+  }
   return run_conv_tile(a, c->Cout, as_stream(stream));
 }

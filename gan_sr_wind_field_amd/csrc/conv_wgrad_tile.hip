@@ -74,14 +74,18 @@ __device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_addr) {
 }
 __device__ __forceinline__ void dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
-// 32-byte block swizzle of the dy image (128-byte rows): 8 consecutive voxels x one n-tile -> 8 distinct slots
-__device__ __forceinline__ int ysw(int v) { return (v >> 1) & 3; }
+// 32-byte block swizzle of the dy image: 8 consecutive voxels x one n-tile -> 8 distinct 32-byte bank slots
+// (128-byte rows, TN <= 4: two voxels per 256-byte bank row; 256-byte rows, TN = 8: one)
+template <int TN> __device__ __forceinline__ int ysw(int v) { return TN <= 4 ? (v >> 1) & 3 : v & 7; }
 
 template <int TN, int SPW, int CT>
 __global__ __launch_bounds__(512) void wgrad_tile_kernel(const WgtArgs a) {
   constexpr int WAVES = 8, NT = 512;
   constexpr int XRPU = 32;            // x rows (32 B) per 1 KB DMA unit
   constexpr int XK = 6, YK = 5;       // DMA units per wave per tile (checked on the host)
+  constexpr int RBY = TN <= 4 ? 128 : 256;  // bytes per dy row
+  constexpr int YRPU = 1024 / RBY;          // dy rows per 1 KB DMA unit
+  static_assert(TN <= 8, "dy rows hold at most 128 channels");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int t = threadIdx.x, lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -129,7 +133,7 @@ __global__ __launch_bounds__(512) void wgrad_tile_kernel(const WgtArgs a) {
   // geo = x | y<<8 | z<<16 | valid<<24 | (channel offset / 8)<<25 of what this lane fetches in unit k
   const int XUP = (L + XRPU - 1) / XRPU;  // 1 KB units per c-tile plane of the x image
   const int XU = XUP * CT;
-  const int YU = (M + 7) >> 3;           // ... of the dy image (8 rows of 128 B)
+  const int YU = (M + YRPU - 1) / YRPU;   // ... of the dy image
   unsigned xgeo[XK], ygeo[YK];
 #pragma unroll
   for (int k = 0; k < XK; ++k) {
@@ -152,8 +156,8 @@ __global__ __launch_bounds__(512) void wgrad_tile_kernel(const WgtArgs a) {
     const int u = wave + WAVES * k;
     unsigned geo = 0;
     if (u < YU) {
-      const int v = u * 8 + (lane >> 3), s = lane & 7;
-      const int b32 = (s >> 1) ^ ysw(v);
+      const int v = u * YRPU + lane / (RBY / 16), s = lane % (RBY / 16);
+      const int b32 = (s >> 1) ^ ysw<TN>(v);
       if (v < M && b32 < TN) {
         const int oz = v % a.TZ, q = v / a.TZ;
         const int oy = q % a.TY, ox = q / a.TY;
@@ -250,9 +254,9 @@ __global__ __launch_bounds__(512) void wgrad_tile_kernel(const WgtArgs a) {
         const char* xhi = Xs + (int)htab[m_hi] * 32 + p * 8;
         uint4 af[TN];
         {
-          const char* rlo = Ys + m_lo * 128 + p * 8;
-          const char* rhi = Ys + m_hi * 128 + p * 8;
-          const int slo = ysw(m_lo), shi = ysw(m_hi);
+          const char* rlo = Ys + m_lo * RBY + p * 8;
+          const char* rhi = Ys + m_hi * RBY + p * 8;
+          const int slo = ysw<TN>(m_lo), shi = ysw<TN>(m_hi);
 #pragma unroll
           for (int i = 0; i < TN; ++i) af[i] = tr_frag(rlo + ((i ^ slo) << 5), rhi + ((i ^ shi) << 5));
         }
@@ -321,7 +325,7 @@ int launch_tile(WgtArgs& a, hipStream_t st) {
       const int M = tx * ty * tz;
       if (M & 31) continue;
       const int L = (tx + a.KX - 1) * (ty + a.KY - 1) * (tz + a.KZ - 1);
-      const int xs = CT * round_up(L * 32, 1024), ys = round_up(M * 128, 1024);
+      const int xs = CT * round_up(L * 32, 1024), ys = round_up(M * (TN <= 4 ? 128 : 256), 1024);
       if (xs / 1024 > 6 * WAVES || ys / 1024 > 5 * WAVES || L > 65535) continue;
       if (round_up(M * 2, 1024) + nbuf * (xs + ys) > 160 * 1024) continue;
       best = ci;
@@ -336,7 +340,7 @@ int launch_tile(WgtArgs& a, hipStream_t st) {
   const int L = (a.TX + a.KX - 1) * (a.TY + a.KY - 1) * (a.TZ + a.KZ - 1);
   a.xp_bytes = round_up(L * 32, 1024);
   a.xs_bytes = CT * a.xp_bytes;
-  a.buf_bytes = a.xs_bytes + round_up(M * 128, 1024);
+  a.buf_bytes = a.xs_bytes + round_up(M * (TN <= 4 ? 128 : 256), 1024);
   a.off_buf = round_up(M * 2, 1024);
   const size_t lds = (size_t)a.off_buf + (size_t)a.nbuf * a.buf_bytes;
   a.n_chunks = (a.Cout + 16 * TN - 1) / (16 * TN);
@@ -371,7 +375,7 @@ int wsr_wgrad_tile_bf16(const wsr_conv_t* c, const void* x, const void* dy, floa
                         void* stream) {
   if (c->dtype != WSR_BF16 || (c->sx | c->sy | c->sz) != 1) return WSR_EUNSUPPORTED;
   const int taps = c->KX * c->KY * c->KZ;
-  if (taps < 2 || taps > 128) return WSR_EUNSUPPORTED;
+  if (taps > 128) return WSR_EUNSUPPORTED;
   if (c->Cin % 8 || c->in_ctot % 8 || c->in_off % 8 || c->out_ctot % 8 || c->out_off % 8) return WSR_EUNSUPPORTED;
   // the dy DMA moves whole octets of the channel window: it must own them (true for padded NDHWC buffers)
   if (c->out_off + (c->Cout + 7) / 8 * 8 > c->out_ctot) return WSR_EUNSUPPORTED;
@@ -389,6 +393,10 @@ int wsr_wgrad_tile_bf16(const wsr_conv_t* c, const void* x, const void* dy, floa
   a.ups = c->upsample_xy ? 1 : 0;
   a.tri_base = tri_base; a.tri_step = tri_step;
   hipStream_t st = as_stream(stream);
+  if (taps == 1) {  // 1x1x1 (LFF): a plain GEMM over the voxels; 8 slots = 8 c-tiles (128 input channels per chunk)
+    if (c->Cout < 64 || c->Cin < 64) return WSR_EUNSUPPORTED;  // tiny GEMMs stay on the per-tap kernel
+    return launch_tile<8, 1, 8>(a, st);
+  }
   if (taps > 28) {  // 5x5x5: 16 slots per wave, 16 input channels per chunk
     if (c->Cout <= 16) return launch_tile<1, 16, 1>(a, st);
     if (c->Cout % 48 == 0) return launch_tile<3, 16, 1>(a, st);

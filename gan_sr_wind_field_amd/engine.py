@@ -80,6 +80,29 @@ class FilterCache:
         self._c[key] = (stamp, out)
         return out
 
+    def refresh_frags(self, wanted) -> None:
+        """Re-pack, in ONE launch, every stale fragment-order copy among ``wanted`` = [(param, transpose)]
+        (after an optimizer step that is all of them: ~600 filters for the generator)."""
+        jobs, stamps = [], []
+        for p, tr in wanted:
+            key = (id(p), "frag", tr)
+            stamp = (p._version, p.data_ptr(), p.device)
+            hit = self._c.get(key)
+            if hit is not None and hit[0] == stamp:
+                continue
+            w = p.detach()
+            if not w.is_contiguous():
+                w = w.contiguous()
+            n = ops.frag_filter_elems(w, tr)
+            out = hit[1] if hit is not None and hit[1].numel() == n and hit[1].device == w.device else \
+                torch.empty(n, dtype=torch.bfloat16, device=w.device)
+            jobs.append((w, out, tr))
+            stamps.append((key, stamp, out))
+        if jobs:
+            ops.pack_filter_frag_multi(jobs)
+            for key, stamp, out in stamps:
+                self._c[key] = (stamp, out)
+
     def clear(self):
         self._c.clear()
 
@@ -158,6 +181,19 @@ class ProgramBase:
         return (c + self.e - 1) // self.e * self.e
 
     # ---- conv helpers --------------------------------------------------------
+    def refresh_filters(self, backward: bool) -> None:
+        """bring the fragment-order filter copies of all tile-kernel convs up to date in one launch"""
+        if not (self.use_tile and self.dt == torch.bfloat16):
+            return
+        sites = [s for s in self.conv_sites() if self.tile_ok(s)]
+        wanted = [(s.weight, False) for s in sites]
+        if backward:
+            wanted += [(s.weight, True) for s in sites]
+        self.filters.refresh_frags(wanted)
+
+    def conv_sites(self) -> Sequence[ConvSite]:
+        return getattr(self, "all_sites", [])
+
     def tile_ok(self, s: ConvSite) -> bool:
         """LDS halo-tile kernels: bf16, stride 1 (everything in G; the k3 s1 convs of D)"""
         return self.use_tile and self.dt == torch.bfloat16 and s.stride == (1, 1, 1)
@@ -326,6 +362,7 @@ class GeneratorProgram(ProgramBase):
         """x (B, Cin, X, Y, nz), Z (B, 1, sX, sY, nz) planar fp32 -> (B, 3, sX, sY, nz) fp32 (+ saved state)"""
         B, _, X, Y, nz = x.shape
         nf, gc, tf, sl = self.nf, self.gc, self.tf, self.slope
+        self.refresh_filters(backward=save)
         x = x.contiguous().float()
         Z = Z.contiguous().float()
         cin_p = self.cp(self.feature.cin)
@@ -559,6 +596,7 @@ class DiscriminatorProgram(ProgramBase):
         self.space = GradSpace(order)
         self.param_list = order
         self._scratch_elems = self.wgrad_scratch_elems([l.conv for l in self.layers], self.e)
+        self.all_sites = [l.conv for l in self.layers]
         for l in self.layers:
             if l.bn is not None and (l.conv.cout > 256 or 256 % l.conv.cout or l.conv.cout % self.e):
                 raise ValueError(f"BatchNorm3d kernels need a channel count dividing 256 and a multiple of {self.e} "
@@ -568,6 +606,7 @@ class DiscriminatorProgram(ProgramBase):
         """x (B, C, X, Y, Z) planar fp32 -> NDHWC feature tensor (+ saved state)"""
         sl = self.slope
         B = x.shape[0]
+        self.refresh_filters(backward=save)
         x = x.contiguous().float()
         c0 = self.cp(self.layers[0].conv.cin)
         h = self._empty((B,) + tuple(x.shape[2:]) + (c0,), x)

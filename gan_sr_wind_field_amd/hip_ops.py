@@ -154,6 +154,30 @@ def pack_filter_frag(w: Tensor, *, transpose: bool = False, out: Optional[Tensor
     return out
 
 
+def frag_filter_elems(w: Tensor, transpose: bool) -> int:
+    cout, cin, kx, ky, kz = w.shape
+    rows, red = (cin, cout) if transpose else (cout, cin)
+    return int(_lib.lib().wsr_frag_filter_elems(rows, red, kx * ky * kz))
+
+
+def pack_filter_frag_multi(jobs) -> None:
+    """``jobs``: list of (master fp32 weight, out bf16 tensor, transpose).  One launch for all of them."""
+    import numpy as np
+
+    if not jobs:
+        return
+    rec = np.zeros((len(jobs), 5), dtype=np.int64)  # wsr_pack_job_t = 2 pointers + 6 int32
+    for r, (w, out, tr) in zip(rec, jobs):
+        cout, cin, kx, ky, kz = w.shape
+        r[0], r[1] = w.data_ptr(), out.data_ptr()
+        r[2] = cout | (cin << 32)
+        r[3] = kx | (ky << 32)
+        r[4] = kz | (int(tr) << 32)
+    dev = jobs[0][0].device
+    table = torch.from_numpy(rec).to(dev, non_blocking=False)
+    check(_lib.lib().wsr_pack_filter_frag_multi(_p(table), len(jobs), _stream()), "pack_filter_frag_multi")
+
+
 def conv_dgrad(desc: ConvDesc, dy: Tensor, wt: Tensor, dx: Tensor, *, alpha: float = 1.0,
                accumulate: bool = False, dx_planar: bool = False) -> Tensor:
     _need_cuda(dy, wt, dx)

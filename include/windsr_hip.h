@@ -103,6 +103,14 @@ int wsr_conv3d_dgrad_tile(const wsr_conv_t* c, const void* dy, const void* wfrag
 int64_t wsr_frag_filter_elems(int32_t rows, int32_t red, int32_t taps);
 int wsr_pack_filter_frag(const float* w, void* out, int32_t Cout, int32_t Cin, int32_t KX, int32_t KY, int32_t KZ,
                          int32_t transpose, void* stream);
+/* The same for many filters in ONE launch (every filter changes at each optimizer step, and a
+ * generator has ~300 of them): `jobs_dev` is a DEVICE array of n_jobs records.                    */
+typedef struct wsr_pack_job {
+  const float* w;  /* master (Cout, Cin, KX, KY, KZ) fp32 */
+  void* out;       /* wsr_frag_filter_elems(...) bf16 elements */
+  int32_t Cout, Cin, KX, KY, KZ, transpose;
+} wsr_pack_job_t;
+int wsr_pack_filter_frag_multi(const wsr_pack_job_t* jobs_dev, int32_t n_jobs, void* stream);
 
 /* aten::convolution_backward, filter gradient: dw[Cout][taps][Cin] fp32 (packed
  * order) is ACCUMULATED into (caller zeroes it when a fresh gradient is wanted;

@@ -287,6 +287,7 @@ def _cpu_wgrad(x, gy, k, p):
     ("k3_128", 40, 128, (3, 3, 3), (6, 9, 13), 1, False),      # TN=4 config, two n-chunks, ragged c-chunk
     ("k3_gc", 64, 32, (3, 3, 3), (5, 8, 9), 2, False),         # TN=2 config
     ("k3_up", 16, 64, (3, 3, 3), (4, 5, 6), 1, True),          # nearest x(2,2,1) folded into the x tile load
+    ("lff_1x1", 256, 128, (1, 1, 1), (5, 6, 19), 1, False),    # 1x1x1: <8,1,8>, two c-chunks of 128 channels
 ])
 def test_wgrad_tile_kernel_bf16(hip, name, cin, cout, k, xyz, B, ups):
     """LDS-tile filter-gradient kernel (bf16) vs an fp32 CPU wgrad of the same rounded operands."""

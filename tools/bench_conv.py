@@ -85,7 +85,8 @@ CASES = {
                    conv_case("up2 dgrad", 128, 128, (3, 3, 3), (128, 128, 128), what="dgrad"),
                    conv_case("up2 wgrad", 128, 128, (3, 3, 3), (64, 64, 128), ups=True, what="wgrad")],
     "lff": lambda: [conv_case("lff 256->128 k1", 256, 128, (1, 1, 1), LR),
-                    conv_case("lff dgrad", 256, 128, (1, 1, 1), LR, what="dgrad")],
+                    conv_case("lff dgrad", 256, 128, (1, 1, 1), LR, what="dgrad"),
+                    conv_case("lff wgrad", 256, 128, (1, 1, 1), LR, what="wgrad")],
     "dg": lambda: [conv_case(f"rdb dgrad 32->{128 + 32 * i}", 128 + 32 * i, 32, (3, 3, 3), LR, 256, 256, 0, what="dgrad")
                    for i in range(4)],
     "hr1": lambda: [conv_case("hr1 144->3 k5", 144, 3, (5, 5, 5), HR, 144, 8, what=w) for w in ("fwd", "dgrad", "wgrad")],
