@@ -1,0 +1,106 @@
+"""Data-parallel train step through the HIP programs: two ranks (both on cuda:0, gloo transport so
+that one card is enough) against the single-process step on the concatenated batch.
+
+Covers what the CPU gloo test cannot: gradient buckets filled by the programs' hand-written backward,
+SyncBN statistics (forward and backward sums) inside the discriminator program, and the D-iteration.
+On a multi-GPU node the same hooks run over backend "nccl" (RCCL)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+from conftest import REPO
+
+pytestmark = pytest.mark.gpu
+LOCAL_INI = os.path.join(REPO, "gan_sr_wind_field_amd", "config", "wind_field_GAN_3D_config_local.ini")
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _build_gan(dtype):
+    from gan_sr_wind_field_amd.config.config import Config
+    from gan_sr_wind_field_amd.GAN_models.wind_field_GAN_3D import wind_field_GAN_3D
+    from oracle import nets as onets
+
+    dev = torch.device("cuda:0")
+    cfg = Config(LOCAL_INI)
+    cfg.is_train, cfg.is_test, cfg.is_use = True, False, False
+    cfg.gpu_id, cfg.device = 0, dev
+    cfg.compute_dtype = dtype
+    cfg.generator.num_features, cfg.generator.num_RRDB, cfg.generator.RDB_growth_chan = 16, 1, 8
+    cfg.generator.terrain_number_of_features = 8
+    cfg.generator.dropout_probability = cfg.discriminator.dropout_probability = 0.0
+    cfg.discriminator.num_features = 8
+    cfg.gan_config.number_of_z_layers = 4
+    cfg.training.use_instance_noise = False
+    cfg.training.use_noisy_labels = False
+    cfg.training.niter = 150000
+    torch.manual_seed(2001)
+    gan = wind_field_GAN_3D(cfg)
+    gs = onets.GSpec(in_channels=4, nf=16, n_rrdb=1, gc=8, tf=8, hr_kern=5, upscale=4)
+    ds = onets.DSpec(bf=8, nz=4, enable_slicing=True)
+    gan.G.load_state_dict(onets.deterministic_state(onets.g_param_shapes(gs), seed=41, scale=0.5))
+    gan.D.load_state_dict(onets.deterministic_state(onets.d_param_shapes(ds), seed=43, scale=1.0))
+    return gan, cfg
+
+
+def _two_iterations(gan, cfg, LR, HR, Z, x, y):
+    dev = cfg.device
+    gan.feed_xy_niter(x.to(dev), y.to(dev), torch.tensor(cfg.training.niter, device=dev), 1, 1)
+    gan.optimize_parameters(LR.to(dev), HR.to(dev), Z.to(dev), 0)  # G-iteration
+    gan.optimize_parameters(LR.to(dev), HR.to(dev), Z.to(dev), 1)  # D-iteration (train-mode BatchNorm)
+    sdG, sdD = gan.G.state_dict(), gan.D.state_dict()
+    keys_g = ("model.0.0.weight", "hr_convs.2.weight", "hr_convs.0.0.weight", "model.1.module.0.RDBs.1.LFF.bias")
+    keys_d = ("features.0.0.0.weight", "features.1.1.1.weight", "features.3.1.0.weight", "classifier.2.weight",
+              "features.2.0.1.running_var")
+    out = {"G." + k: sdG[k].detach().float().cpu() for k in keys_g}
+    out.update({"D." + k: sdD[k].detach().float().cpu() for k in keys_d})
+    return out
+
+
+def _worker(rank, world, port, out_dir, dtype):
+    import sys
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK="0")
+    import torch.distributed as dist
+    from gan_sr_wind_field_amd import dist as wdist
+    from oracle.gan import synthetic_batch
+
+    assert wdist.init_from_env("gloo")
+    gan, cfg = _build_gan(dtype)
+    dp = wdist.attach(gan, bucket_mb=0.02, sync_bn=True)
+    LR, HR, Z, x, y = synthetic_batch(2 * world, 16, 4, 4, seed=2001)
+    sl = slice(2 * rank, 2 * rank + 2)  # two samples per rank
+    res = _two_iterations(gan, cfg, LR[sl], HR[sl], Z[sl], x, y)
+    res["n_coll"] = dp.n_collectives
+    torch.save(res, os.path.join(out_dir, f"rank{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_step_equals_full_batch_hip(hip, tmp_path):
+    import sys
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    from oracle.gan import synthetic_batch
+
+    world, port = 2, _free_port()
+    mp.spawn(_worker, args=(world, port, str(tmp_path), "fp32"), nprocs=world, join=True)
+    r0 = torch.load(tmp_path / "rank0.pt")
+    r1 = torch.load(tmp_path / "rank1.pt")
+    gan, cfg = _build_gan("fp32")
+    LR, HR, Z, x, y = synthetic_batch(2 * world, 16, 4, 4, seed=2001)
+    ref = _two_iterations(gan, cfg, LR, HR, Z, x, y)
+    for k, v in ref.items():
+        assert torch.equal(r0[k], r1[k]), k  # replicas stay identical
+        np.testing.assert_allclose(r0[k].numpy(), v.numpy(), rtol=5e-4, atol=2e-6, err_msg=k)
+    assert r0["n_coll"] > 4  # several gradient buckets + the classifier head
