@@ -29,6 +29,8 @@
 // block: output channel n belongs to conv i = n / tri_step whose input is only
 // channels [0, tri_base + i*tri_step) of the shared dense buffer, so the four
 // growth convs of an RDB (reference torch_blocks.py:256-267) are ONE launch.
+#include <cstdlib>
+
 #include "common.h"
 
 namespace {
@@ -350,10 +352,18 @@ int launch_tile(WgtArgs& a, hipStream_t st) {
   a.tiles_z = (a.Zo + a.TZ - 1) / a.TZ;
   a.ntiles = a.B * a.tiles_x * a.tiles_y * a.tiles_z;
   const int combos = a.n_chunks * a.c_chunks;
-  int S = (256 * 3 + combos - 1) / combos;  // ~3 workgroups per CU over the launch, one resident at a time
-  if (S > a.ntiles) S = a.ntiles;
+  // Spatial split S: ONE round of workgroups (one is resident per CU: 148 KB of LDS).  Measured on the
+  // dense-block and the 5x5x5 wgrad: launches of <= 256 workgroups are fastest, a launch just over a
+  // multiple of 256 is up to 1.6x slower (a nearly empty extra round), and more, smaller workgroups
+  // only add accumulator flushes (each flush is worth ~6 tiles of MFMA work at the atomic rate).
+  int S = 256 / combos;
   if (S < 1) S = 1;
+  if (S > a.ntiles) S = a.ntiles;
   a.S = S;
+  if (const char* ov = getenv("WSR_WGRAD_S")) {  // tuning aid
+    const int v = atoi(ov);
+    if (v >= 1 && v <= a.ntiles) a.S = v;
+  }
   auto kern = wgrad_tile_kernel<TN, SPW, CT>;
   static bool attr_done = false;  // raise the dynamic-LDS cap once per instantiation
   if (!attr_done) {
@@ -362,7 +372,7 @@ int launch_tile(WgtArgs& a, hipStream_t st) {
     if (e != hipSuccess) return (int)e;
     attr_done = true;
   }
-  hipLaunchKernelGGL(kern, dim3((unsigned)(combos * S)), dim3(WAVES * 64), lds, st, a);
+  hipLaunchKernelGGL(kern, dim3((unsigned)(combos * a.S)), dim3(WAVES * 64), lds, st, a);
   WSR_LAUNCH_CHECK();
   return 0;
 }
