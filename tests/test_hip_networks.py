@@ -131,8 +131,9 @@ def test_discriminator_fp32_vs_reference(golden, hip, slicing, xy, nz):
     # The z21 case is bimodal on the GPU: measured 1.1e-6 (most runs) or 2.4e-3 against an fp64
     # evaluation, depending on the order of the float atomics in the BatchNorm sums - one
     # near-zero pre-activation changes its LeakyReLU branch (the reference's own fp32 result is
-    # 5.4e-4 away from fp64 for the same reason).  `flip` is the allowance for that event.
-    flip = 4e-3 if nz == 21 else 0.0
+    # 5.4e-4 away from fp64 for the same reason).  `flip` is the allowance for that event (worst
+    # observed: 6.5e-3 on a 4-element BatchNorm weight gradient).
+    flip = 1e-2 if nz == 21 else 0.0
     assert rel_l2(x.grad[:, :, ::4, ::4, :], T(g["dx_sub"])) < max(1e-3, flip)
     assert abs(float(x.grad.double().abs().sum()) / float(g["dx_abs_sum"]) - 1) < max(1e-3, flip)
     # The recorded fp32 reference gradients are themselves up to 5.3e-4 away from an fp64
