@@ -24,6 +24,8 @@
 // channels of one voxel (8-byte vector stores into the NDHWC channel window).
 // The input-gradient pass is the same kernel over dy with the transposed,
 // tap-flipped filter and pad' = K-1-pad.
+#include <cstdlib>
+
 #include "common.h"
 
 namespace {
@@ -370,7 +372,8 @@ int launch_ct(CtArgs& a, hipStream_t st) {
     a.off_ws = a.off_xs + a.xbufs * (VM ? 1 : PL) * a.P;
     const int avail = 160 * 1024 - a.off_ws;
     ts_max = avail / (2 * NTW * 1024);
-    const int cap = 32 / NTW > 0 ? 32 / NTW : 1;  // <= 32 KB per weight stage
+    const int cap_kb = getenv("WSR_WSTAGE_KB") ? atoi(getenv("WSR_WSTAGE_KB")) : 48;  // tuning aid
+    const int cap = cap_kb / NTW > 0 ? cap_kb / NTW : 1;  // <= 48 KB per weight stage (measured: up-convs +7 %, others flat)
     if (ts_max > cap) ts_max = cap;
     if (ts_max >= 2 || (ts_max >= 1 && a.nts == 1)) break;
   }

@@ -49,6 +49,22 @@ __global__ void unpack_wgrad_kernel(const float* __restrict__ src, float* __rest
   }
 }
 
+// many filter gradients in one launch: one block row (blockIdx.y) per job
+__global__ void unpack_wgrad_multi_kernel(const wsr_unpack_job_t* __restrict__ jobs) {
+  const wsr_unpack_job_t j = jobs[blockIdx.y];
+  const long total = (long)j.Cout * j.Cin * j.taps;
+  const float* __restrict__ src = j.src;
+  float* __restrict__ dst = j.dst;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int tap = (int)(i % j.taps);
+    const long nc = i / j.taps;
+    const int c = (int)(nc % j.Cin);
+    const int n = (int)(nc / j.Cin);
+    const float v = j.scale * src[((long)n * j.taps + tap) * j.kpad + c];
+    dst[i] = j.accumulate ? dst[i] + v : v;
+  }
+}
+
 // ---- channel-window elementwise ---------------------------------------------------
 template <class T>
 __global__ void lrelu_bwd_kernel(typename T::elem* g, int g_ctot, int g_off, const typename T::elem* y, int y_ctot,
@@ -299,6 +315,13 @@ extern "C" int wsr_unpack_wgrad(const float* src, float* dst, int32_t Cout, int3
   if (!src || !dst || Cout <= 0 || taps <= 0 || Cin <= 0 || kpad < Cin) return WSR_EINVAL;
   hipLaunchKernelGGL(unpack_wgrad_kernel, dim3(ew_grid((long)Cout * Cin * taps)), dim3(EW_BLOCK), 0,
                      as_stream(stream), src, dst, Cout, taps, Cin, kpad, scale, accumulate);
+  WSR_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int wsr_unpack_wgrad_multi(const wsr_unpack_job_t* jobs_dev, int32_t n_jobs, void* stream) {
+  if (!jobs_dev || n_jobs <= 0 || n_jobs > 65535) return WSR_EINVAL;
+  hipLaunchKernelGGL(unpack_wgrad_multi_kernel, dim3(32, (unsigned)n_jobs), dim3(256), 0, as_stream(stream), jobs_dev);
   WSR_LAUNCH_CHECK();
   return 0;
 }

@@ -175,6 +175,10 @@ class ProgramBase:
         self.launch_probe: Optional[Callable[[str, Callable[[], None]], None]] = None
         #: route stride-1 bf16 convs through the LDS halo-tile kernels (False: generic implicit GEMM only)
         self.use_tile = True
+        self._arena: Optional[Tensor] = None
+        self._arena_off = 0
+        self._pending_unpack: list = []
+        self._scratch_elems_total = 0
 
     def cp(self, c: int) -> int:
         """channel count padded to whole 16-byte pieces"""
@@ -252,14 +256,12 @@ class ProgramBase:
         B = x.shape[0]
         cin_p = self.cp(s.cin)
         d = self._desc(s, B, tuple(x.shape[1:4]), x.shape[-1], x_off, g.shape[-1], g_off, cin=cin_p)
-        n = s.cout * s.taps * cin_p
-        dwp = scratch[:n]
-        dwp.zero_()
+        dwp = self._arena_take(s.cout * s.taps * cin_p, x.device)
         if self.launch_probe is not None:
             self.launch_probe("wgrad:" + s.name, lambda: ops.conv_wgrad(d, x, g, dwp))
         else:
             ops.conv_wgrad(d, x, g, dwp)
-        ops.unpack_wgrad(dwp.view(s.cout, s.taps, cin_p), space.view(flat, s.weight), scale=scale, accumulate=False)
+        self._pending_unpack.append((dwp.view(s.cout, s.taps, cin_p), space.view(flat, s.weight), scale))
 
     def wgrad_dense(self, convs: Sequence[ConvSite], buf: Tensor, gd: Tensor, flat: Tensor, space: GradSpace,
                     scratch: Tensor) -> None:
@@ -279,15 +281,39 @@ class ProgramBase:
         g = ConvGeom(cin_w, cout, convs[0].kernel, (1, 1, 1), convs[0].pad)
         d = ops.make_desc(g, self.dt, B, tuple(buf.shape[1:4]), buf.shape[-1], 0, gd.shape[-1], nf)
         taps = convs[0].taps
-        dwp = scratch[:cout * taps * cin_w]
-        dwp.zero_()
-        dw3 = dwp.view(cout, taps, cin_w)
+        dw3 = self._arena_take(cout * taps * cin_w, buf.device).view(cout, taps, cin_w)
         if self.launch_probe is not None:
             self.launch_probe("wgrad_tri:" + convs[0].name, lambda: ops.conv_wgrad_tri(d, buf, gd, dw3, nf, gc))
         else:
             ops.conv_wgrad_tri(d, buf, gd, dw3, nf, gc)
         for i, c in enumerate(convs):
-            ops.unpack_wgrad(dw3[i * gc:(i + 1) * gc], space.view(flat, c.weight), accumulate=False)
+            self._pending_unpack.append((dw3[i * gc:(i + 1) * gc], space.view(flat, c.weight), 1.0))
+
+    # ---- packed filter-gradient arena -------------------------------------------------------------
+    # The wgrad kernels accumulate (float atomics) into packed [Cout][taps][Cin_p] buffers.  One arena per
+    # backward pass is zeroed with a single fill, every conv takes a slice, and the slices are moved to
+    # the master layout in batches (one launch per `flush_unpack`) instead of a fill + an unpack per conv.
+    def begin_backward(self, dev) -> None:
+        n = int(self._scratch_elems_total * 1.3) + 4096
+        self._arena = torch.zeros(n, dtype=torch.float32, device=dev)
+        self._arena_off = 0
+        self._pending_unpack = []
+
+    def _arena_take(self, n: int, dev) -> Tensor:
+        off = self._arena_off
+        if self._arena is None or off + n > self._arena.numel():
+            return torch.zeros(n, dtype=torch.float32, device=dev)
+        self._arena_off = off + (n + 63) // 64 * 64
+        return self._arena[off:off + n]
+
+    def flush_unpack(self) -> None:
+        if self._pending_unpack:
+            ops.unpack_wgrad_multi(self._pending_unpack)
+            self._pending_unpack = []
+
+    def end_backward(self) -> None:
+        self.flush_unpack()
+        self._arena = None
 
     @staticmethod
     def wgrad_scratch_elems(sites: Sequence[ConvSite], e: int) -> int:
@@ -356,6 +382,7 @@ class GeneratorProgram(ProgramBase):
         if self.rrdbs and self.rrdbs[0][0][0]:
             c = self.rrdbs[0][0][0]
             self._scratch_elems = max(self._scratch_elems, len(c) * c[0].cout * c[0].taps * self.cp(c[-1].cin))
+        self._scratch_elems_total = sum(s.cout * s.taps * self.cp(s.cin) for s in self.all_sites)
 
     # ---- forward -------------------------------------------------------------------
     def forward(self, x: Tensor, Z: Tensor, training: bool, save: bool, drop_scale: Optional[Tensor]):
@@ -431,7 +458,8 @@ class GeneratorProgram(ProgramBase):
         X, Y, nz = saved["lr_xyz"]
         sX, sY, _ = saved["hr_xyz"]
         flat = self.space.new(dev)
-        scratch = torch.empty(self._scratch_elems, dtype=torch.float32, device=dev)
+        scratch = None  # (packed gradients live in the per-backward arena)
+        self.begin_backward(dev)
         sp = self.space
         done = 0
 
@@ -439,6 +467,7 @@ class GeneratorProgram(ProgramBase):
             nonlocal done
             if self.grad_ready_hook is None:
                 return
+            self.flush_unpack()  # the gradients of `params` must be in the flat buffer before it is reduced
             hi = max(sp.offsets[id(p)][0] + (sp.offsets[id(p)][1] + 63) // 64 * 64 for p in params)
             if hi > done:
                 self.grad_ready_hook(flat, done, hi)
@@ -526,6 +555,7 @@ class GeneratorProgram(ProgramBase):
         ops.chan_axpby(g, 0, gs, 0, nf, alpha=1.0, beta=1.0)
         self.wgrad(self.feature, saved["x_nd"], 0, g, 0, flat, sp, scratch)
         ready(self.feature.weight)
+        self.end_backward()
         if self.grad_done_hook is not None:
             self.grad_done_hook()
         return flat
@@ -597,6 +627,7 @@ class DiscriminatorProgram(ProgramBase):
         self.param_list = order
         self._scratch_elems = self.wgrad_scratch_elems([l.conv for l in self.layers], self.e)
         self.all_sites = [l.conv for l in self.layers]
+        self._scratch_elems_total = sum(s.cout * s.taps * self.cp(s.cin) for s in self.all_sites)
         for l in self.layers:
             if l.bn is not None and (l.conv.cout > 256 or 256 % l.conv.cout or l.conv.cout % self.e):
                 raise ValueError(f"BatchNorm3d kernels need a channel count dividing 256 and a multiple of {self.e} "
@@ -665,7 +696,9 @@ class DiscriminatorProgram(ProgramBase):
         sl = self.slope
         dev = g_feat.device
         flat = self.space.new(dev) if need_dw else None
-        scratch = torch.empty(self._scratch_elems, dtype=torch.float32, device=dev) if need_dw else None
+        scratch = None
+        if need_dw:
+            self.begin_backward(dev)
         sp = self.space
         done = 0
         g = g_feat.contiguous()
@@ -706,6 +739,7 @@ class DiscriminatorProgram(ProgramBase):
             if need_dw:
                 self.wgrad(s, inp, 0, gy, 0, flat, sp, scratch)
                 if self.grad_ready_hook is not None:
+                    self.flush_unpack()
                     hi = sp.offsets[id(s.weight)][0] + (s.weight.numel() + 63) // 64 * 64
                     self.grad_ready_hook(flat, done, hi)
                     done = hi
@@ -716,6 +750,8 @@ class DiscriminatorProgram(ProgramBase):
             elif need_dx:
                 dx = torch.empty(saved["in_shape"], dtype=torch.float32, device=dev)
                 self.dgrad(s, gy, 0, dx, 0, tuple(inp.shape[1:4]), dx_planar=True)
+        if need_dw:
+            self.end_backward()
         if need_dw and self.grad_done_hook is not None:
             self.grad_done_hook()
         return dx, flat

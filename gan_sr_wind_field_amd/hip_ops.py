@@ -232,6 +232,23 @@ def unpack_wgrad(src: Tensor, dst: Tensor, scale: float = 1.0, accumulate: bool 
                                       _stream()), "unpack_wgrad")
 
 
+def unpack_wgrad_multi(jobs) -> None:
+    """``jobs``: list of (packed src [Cout][taps][kpad] fp32, master-layout dst fp32, scale).  One launch."""
+    import numpy as np
+
+    if not jobs:
+        return
+    rec = np.zeros((len(jobs), 5), dtype=np.int64)  # wsr_unpack_job_t: 2 pointers + 4 int32 + float + int32
+    for r, (src, dst, scale) in zip(rec, jobs):
+        cout, taps, kpad = src.shape
+        r[0], r[1] = src.data_ptr(), dst.data_ptr()
+        r[2] = cout | (taps << 32)
+        r[3] = dst.shape[1] | (kpad << 32)
+        r[4] = int(np.float32(scale).view(np.int32)) & 0xFFFFFFFF  # accumulate = 0
+    table = torch.from_numpy(rec).to(jobs[0][0].device)
+    check(_lib.lib().wsr_unpack_wgrad_multi(_p(table), len(jobs), _stream()), "unpack_wgrad_multi")
+
+
 def lrelu_bwd_(g: Tensor, g_off: int, y: Tensor, y_off: int, C_: int, slope: float,
                chan_scale: Optional[Tensor] = None) -> None:
     nvox = g.numel() // g.shape[-1]

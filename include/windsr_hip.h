@@ -140,6 +140,16 @@ int wsr_pack_filter(const float* w, void* out, int32_t dtype, int32_t Cout, int3
 int wsr_unpack_wgrad(const float* src, float* dst, int32_t Cout, int32_t taps, int32_t Cin,
                      int32_t kpad, float scale, int32_t accumulate, void* stream);
 
+/* The same for many filter gradients in ONE launch; `jobs_dev` is a DEVICE array of n_jobs records. */
+typedef struct wsr_unpack_job {
+  const float* src; /* packed [Cout][taps][kpad] */
+  float* dst;       /* master (Cout, Cin, taps)   */
+  int32_t Cout, taps, Cin, kpad;
+  float scale;
+  int32_t accumulate;
+} wsr_unpack_job_t;
+int wsr_unpack_wgrad_multi(const wsr_unpack_job_t* jobs_dev, int32_t n_jobs, void* stream);
+
 /* ---- elementwise / normalisation ---------------------------------------------
  * leaky_relu_backward from the saved OUTPUT sign, in place on a channel window
  * (torch_blocks.py:35 autograd):  g *= (y > 0 ? 1 : slope), optionally also
