@@ -43,6 +43,8 @@ struct IgemmArgs {
   int ppt;         // pieces per tap = Cin*sizeof(T)/16
   int total_pieces;
   int vec_ok;      // 4-channel vector epilogue allowed
+  int pcls;        // strided dgrad: rows grouped by parity class (x%sx, y%sy, z%sz) so that a block's taps
+  int tpc;         //   that divide are the same for all its rows and the others are skipped; tiles per class
 };
 
 template <class T, int WM, int WN, int TM, int TN, bool GENERAL>
@@ -56,8 +58,11 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a) {
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
   int4* rowc = reinterpret_cast<int4*>(smem);                      // [BM]
-  int* taptab = reinterpret_cast<int*>(smem + BM * 16);            // [MAXTAPS]
-  char* Xt = smem + BM * 16 + MAXTAPS * 4;                         // [BM][RS]
+  int* taptab = reinterpret_cast<int*>(smem + BM * 16);            // [MAXTAPS] packed offsets of the taps walked
+  int* tapid = taptab + MAXTAPS;                                   // [MAXTAPS] their index in the filter
+  int* rowm = tapid + MAXTAPS;                                     // [BM] output voxel of a row (-1: none)
+  int* ntap_s = rowm + BM;                                         // [4]
+  char* Xt = smem + BM * 16 + MAXTAPS * 8 + BM * 4 + 16;           // [BM][RS]
   char* Wt = Xt + BM * RS;                                         // [BN][RS]
 
   const int t = threadIdx.x;
@@ -68,24 +73,46 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a) {
   const int nwg = gridDim.x;
   const int bid = xcd_remap(blockIdx.x, nwg);
   const int mt = bid / ntiles, nt = bid % ntiles;
-  const int m0 = mt * BM, n0 = nt * BN;
+  const int n0 = nt * BN;
   const int taps = a.KX * a.KY * a.KZ;
+
+  // parity class of this block (strided dgrad) and its voxel sub-grid
+  int cx = 0, cy = 0, cz = 0, Xc = a.Xo, Yc = a.Yo, Zc = a.Zo, m0 = mt * BM;
+  const bool pc = GENERAL && a.pcls;
+  if (pc) {
+    const int cls = mt / a.tpc;
+    m0 = (mt - cls * a.tpc) * BM;
+    cz = cls % a.dz_;
+    cy = (cls / a.dz_) % a.dy_;
+    cx = cls / (a.dz_ * a.dy_);
+    Xc = (a.Xo - cx + a.dx_ - 1) / a.dx_;
+    Yc = (a.Yo - cy + a.dy_ - 1) / a.dy_;
+    Zc = (a.Zo - cz + a.dz_ - 1) / a.dz_;
+  }
+  const int Mc = a.B * Xc * Yc * Zc;
 
   // ---- per-block tables ------------------------------------------------------
   for (int r = t; r < BM; r += 256) {
     int m = m0 + r;
     int4 rc;
-    if (m < a.M) {
-      int zo = m % a.Zo;
-      int q = m / a.Zo;
-      int yo = q % a.Yo;
-      q /= a.Yo;
-      int xo = q % a.Xo;
-      int b = q / a.Xo;
+    int mo = -1;
+    if (m < Mc) {
+      int zo = m % Zc;
+      int q = m / Zc;
+      int yo = q % Yc;
+      q /= Yc;
+      int xo = q % Xc;
+      int b = q / Xc;
+      if (pc) {
+        xo = xo * a.dx_ + cx;
+        yo = yo * a.dy_ + cy;
+        zo = zo * a.dz_ + cz;
+      }
       rc.x = b * a.Xi * a.Yi * a.Zi;
       rc.y = xo * a.mx + a.ox;
       rc.z = yo * a.my + a.oy;
       rc.w = zo * a.mz + a.oz;
+      mo = ((b * a.Xo + xo) * a.Yo + yo) * a.Zo + zo;
     } else {
       rc.x = 0;
       rc.y = -(1 << 28);  // fails every bounds test
@@ -93,15 +120,39 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a) {
       rc.w = 0;
     }
     rowc[r] = rc;
+    rowm[r] = mo;
   }
-  for (int k = t; k < taps; k += 256) {
-    int kz = k % a.KZ;
-    int q = k / a.KZ;
-    int ky = q % a.KY;
-    int kx = q / a.KY;
-    taptab[k] = ((a.tap_sign * kx) & 0x3ff) | (((a.tap_sign * ky) & 0x3ff) << 10) | (((a.tap_sign * kz) & 0x3ff) << 20);
+  if (!pc) {
+    for (int k = t; k < taps; k += 256) {
+      int kz = k % a.KZ;
+      int q = k / a.KZ;
+      int ky = q % a.KY;
+      int kx = q / a.KY;
+      taptab[k] = ((a.tap_sign * kx) & 0x3ff) | (((a.tap_sign * ky) & 0x3ff) << 10) | (((a.tap_sign * kz) & 0x3ff) << 20);
+      tapid[k] = k;
+    }
+    if (t == 0) ntap_s[0] = taps;
+  } else if (t == 0) {  // only the taps whose gather coordinate divides by the stride for this class
+    int n = 0;
+    for (int k = 0; k < taps; ++k) {
+      int kz = k % a.KZ;
+      int q = k / a.KZ;
+      int ky = q % a.KY;
+      int kx = q / a.KY;
+      // x = xo + ox + tap_sign*kx with xo == cx (mod sx)
+      int rx = (cx + a.ox + a.tap_sign * kx) % a.dx_, ry = (cy + a.oy + a.tap_sign * ky) % a.dy_,
+          rz = (cz + a.oz + a.tap_sign * kz) % a.dz_;
+      if (rx == 0 && ry == 0 && rz == 0) {
+        taptab[n] = ((a.tap_sign * kx) & 0x3ff) | (((a.tap_sign * ky) & 0x3ff) << 10) | (((a.tap_sign * kz) & 0x3ff) << 20);
+        tapid[n] = k;
+        ++n;
+      }
+    }
+    ntap_s[0] = n;
   }
   __syncthreads();
+  const int ntap = ntap_s[0];
+  const int npieces = a.ppt * ntap;  // pieces of the K walk of this block
 
   // ---- staging state -----------------------------------------------------------
   const int q = t & (PPS - 1);  // piece slot inside the K-step
@@ -111,13 +162,13 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a) {
     c8 -= a.ppt;
     ++tap;
   }
-  int P = q;  // flat piece index
-  const int nsteps = (a.total_pieces + PPS - 1) / PPS;
+  int P = q;  // flat piece index of the walk
+  const int nsteps = (npieces + PPS - 1) / PPS;
 
   uint4 xr[XI], wr[WI];
 
   auto load_step = [&]() {
-    const bool pv = P < a.total_pieces;
+    const bool pv = P < npieces;
     int dx = 0, dy = 0, dz = 0;
     if (pv) {
       int tt = taptab[tap];
@@ -154,7 +205,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a) {
       int r = rg + 32 * i;
       uint4 v = make_uint4(0, 0, 0, 0);
       if (r < BN && pv && (n0 + r) < a.Cout) {
-        const char* p = a.w + ((long)(n0 + r) * a.total_pieces + P) * 16;
+        const char* p = a.w + ((long)(n0 + r) * a.total_pieces + (long)tapid[tap] * a.ppt + c8) * 16;
         v = *reinterpret_cast<const uint4*>(p);
       }
       wr[i] = v;
@@ -208,8 +259,8 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a) {
   const long vox_per_b = (long)a.Xo * a.Yo * a.Zo;
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
-    const int m = m0 + (wm * TM + i) * 16 + fr;
-    if (m >= a.M) continue;
+    const int m = rowm[(wm * TM + i) * 16 + fr];
+    if (m < 0) continue;
     const int b = (int)(m / vox_per_b);
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
@@ -263,13 +314,21 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a) {
 template <class T, int WM, int WN, int TM, int TN>
 int launch_cfg(const IgemmArgs& a, bool general, hipStream_t st) {
   constexpr int BM = WM * TM * 16, BN = WN * TN * 16;
-  const int mtiles = (a.M + BM - 1) / BM, ntiles = (a.Cout + BN - 1) / BN;
-  const size_t lds = BM * 16 + MAXTAPS * 4 + (size_t)(BM + BN) * RS;
+  int mtiles = (a.M + BM - 1) / BM;
+  const int ntiles = (a.Cout + BN - 1) / BN;
+  IgemmArgs b = a;
+  if (general && a.pcls) {  // one set of row tiles per parity class
+    const long mc = (long)a.B * ((a.Xo + a.dx_ - 1) / a.dx_) * ((a.Yo + a.dy_ - 1) / a.dy_) *
+                    ((a.Zo + a.dz_ - 1) / a.dz_);
+    b.tpc = (int)((mc + BM - 1) / BM);
+    mtiles = b.tpc * a.dx_ * a.dy_ * a.dz_;
+  }
+  const size_t lds = BM * 16 + MAXTAPS * 8 + BM * 4 + 16 + (size_t)(BM + BN) * RS;
   dim3 grid(mtiles * ntiles), block(256);
   if (general)
-    hipLaunchKernelGGL((igemm_kernel<T, WM, WN, TM, TN, true>), grid, block, lds, st, a);
+    hipLaunchKernelGGL((igemm_kernel<T, WM, WN, TM, TN, true>), grid, block, lds, st, b);
   else
-    hipLaunchKernelGGL((igemm_kernel<T, WM, WN, TM, TN, false>), grid, block, lds, st, a);
+    hipLaunchKernelGGL((igemm_kernel<T, WM, WN, TM, TN, false>), grid, block, lds, st, b);
   WSR_LAUNCH_CHECK();
   return 0;
 }
@@ -368,5 +427,6 @@ extern "C" int wsr_conv3d_dgrad(const wsr_conv_t* c, const void* dy, const void*
   a.ups = 0;
   a.M = c->B * a.Xo * a.Yo * a.Zo;
   const bool general = (c->sx | c->sy | c->sz) != 1;
+  a.pcls = general ? 1 : 0;
   return run_igemm(a, c->dtype, general, as_stream(stream));
 }

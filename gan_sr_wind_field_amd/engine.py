@@ -48,6 +48,7 @@ class FilterCache:
 
     def __init__(self):
         self._c: Dict[tuple, tuple] = {}
+        self._tables: Dict[str, tuple] = {}
 
     def get(self, p: Tensor, dt: torch.dtype, transpose: bool, kpad: int, rows_pad: int) -> Tensor:
         key = (id(p), dt, transpose, kpad, rows_pad)
@@ -81,30 +82,40 @@ class FilterCache:
         return out
 
     def refresh_frags(self, wanted) -> None:
-        """Re-pack, in ONE launch, every stale fragment-order copy among ``wanted`` = [(param, transpose)]
-        (after an optimizer step that is all of them: ~600 filters for the generator)."""
-        jobs, stamps = [], []
+        """Re-pack, in ONE launch, the fragment-order copies among ``wanted`` = [(param, transpose)] when any
+        of them is stale (after an optimizer step that is all ~600 filters of the generator).  The device job
+        table is cached: it only holds pointers, which stay put while parameters and copies keep their storage."""
+        stale = False
+        ptrs = []
         for p, tr in wanted:
-            key = (id(p), "frag", tr)
-            stamp = (p._version, p.data_ptr(), p.device)
-            hit = self._c.get(key)
-            if hit is not None and hit[0] == stamp:
-                continue
-            w = p.detach()
-            if not w.is_contiguous():
-                w = w.contiguous()
-            n = ops.frag_filter_elems(w, tr)
-            out = hit[1] if hit is not None and hit[1].numel() == n and hit[1].device == w.device else \
-                torch.empty(n, dtype=torch.bfloat16, device=w.device)
-            jobs.append((w, out, tr))
-            stamps.append((key, stamp, out))
-        if jobs:
-            ops.pack_filter_frag_multi(jobs)
-            for key, stamp, out in stamps:
-                self._c[key] = (stamp, out)
+            hit = self._c.get((id(p), "frag", tr))
+            ptrs.append(p.data_ptr())
+            if hit is None or hit[0] != (p._version, p.data_ptr(), p.device):
+                stale = True
+        if not stale:
+            return
+        key = tuple(ptrs) + tuple(tr for _, tr in wanted)
+        cached = self._tables.get("pack")
+        if cached is None or cached[0] != key:
+            jobs = []
+            for p, tr in wanted:
+                w = p.detach()
+                if not w.is_contiguous():
+                    raise ValueError("conv filters must be contiguous")
+                hit = self._c.get((id(p), "frag", tr))
+                n = ops.frag_filter_elems(w, tr)
+                out = hit[1] if hit is not None and hit[1].numel() == n and hit[1].device == w.device else \
+                    torch.empty(n, dtype=torch.bfloat16, device=w.device)
+                jobs.append((w, out, tr))
+            cached = (key, ops.pack_job_table(jobs), [j[1] for j in jobs])
+            self._tables["pack"] = cached
+        ops.pack_filter_frag_multi(cached[1])
+        for (p, tr), out in zip(wanted, cached[2]):
+            self._c[(id(p), "frag", tr)] = ((p._version, p.data_ptr(), p.device), out)
 
     def clear(self):
         self._c.clear()
+        self._tables.clear()
 
 
 @dataclass
@@ -178,6 +189,7 @@ class ProgramBase:
         self._arena: Optional[Tensor] = None
         self._arena_off = 0
         self._pending_unpack: list = []
+        self._unpack_tables: Dict[tuple, Tensor] = {}
         self._scratch_elems_total = 0
 
     def cp(self, c: int) -> int:
@@ -307,9 +319,20 @@ class ProgramBase:
         return self._arena[off:off + n]
 
     def flush_unpack(self) -> None:
-        if self._pending_unpack:
-            ops.unpack_wgrad_multi(self._pending_unpack)
-            self._pending_unpack = []
+        if not self._pending_unpack:
+            return
+        jobs = self._pending_unpack
+        self._pending_unpack = []
+        # the arena and the flat gradient buffer usually come back at the same addresses every step
+        # (caching allocator), so the device job table is re-used when all pointers match
+        key = tuple(j[0].data_ptr() for j in jobs) + tuple(j[1].data_ptr() for j in jobs) + tuple(j[2] for j in jobs)
+        table = self._unpack_tables.get(key)
+        if table is None:
+            if len(self._unpack_tables) > 64:
+                self._unpack_tables.clear()
+            table = ops.unpack_job_table(jobs)
+            self._unpack_tables[key] = table
+        ops.unpack_wgrad_multi(table)
 
     def end_backward(self) -> None:
         self.flush_unpack()

@@ -160,22 +160,24 @@ def frag_filter_elems(w: Tensor, transpose: bool) -> int:
     return int(_lib.lib().wsr_frag_filter_elems(rows, red, kx * ky * kz))
 
 
-def pack_filter_frag_multi(jobs) -> None:
-    """``jobs``: list of (master fp32 weight, out bf16 tensor, transpose).  One launch for all of them."""
+def pack_job_table(jobs) -> Tensor:
+    """Device table of ``wsr_pack_job_t`` records for ``jobs`` = [(master fp32 weight, out bf16 tensor, transpose)].
+    The table only holds pointers and shapes, so it stays valid while those tensors keep their storage."""
     import numpy as np
 
-    if not jobs:
-        return
-    rec = np.zeros((len(jobs), 5), dtype=np.int64)  # wsr_pack_job_t = 2 pointers + 6 int32
+    rec = np.zeros((len(jobs), 5), dtype=np.int64)  # 2 pointers + 6 int32
     for r, (w, out, tr) in zip(rec, jobs):
         cout, cin, kx, ky, kz = w.shape
         r[0], r[1] = w.data_ptr(), out.data_ptr()
         r[2] = cout | (cin << 32)
         r[3] = kx | (ky << 32)
         r[4] = kz | (int(tr) << 32)
-    dev = jobs[0][0].device
-    table = torch.from_numpy(rec).to(dev, non_blocking=False)
-    check(_lib.lib().wsr_pack_filter_frag_multi(_p(table), len(jobs), _stream()), "pack_filter_frag_multi")
+    return torch.from_numpy(rec).to(jobs[0][0].device)
+
+
+def pack_filter_frag_multi(table: Tensor) -> None:
+    """One launch for all filters of a job table (see :func:`pack_job_table`)."""
+    check(_lib.lib().wsr_pack_filter_frag_multi(_p(table), table.shape[0], _stream()), "pack_filter_frag_multi")
 
 
 def conv_dgrad(desc: ConvDesc, dy: Tensor, wt: Tensor, dx: Tensor, *, alpha: float = 1.0,
@@ -232,21 +234,23 @@ def unpack_wgrad(src: Tensor, dst: Tensor, scale: float = 1.0, accumulate: bool 
                                       _stream()), "unpack_wgrad")
 
 
-def unpack_wgrad_multi(jobs) -> None:
-    """``jobs``: list of (packed src [Cout][taps][kpad] fp32, master-layout dst fp32, scale).  One launch."""
+def unpack_job_table(jobs) -> Tensor:
+    """Device table of ``wsr_unpack_job_t`` records for ``jobs`` = [(packed src [Cout][taps][kpad] fp32,
+    master-layout dst fp32, scale)]."""
     import numpy as np
 
-    if not jobs:
-        return
-    rec = np.zeros((len(jobs), 5), dtype=np.int64)  # wsr_unpack_job_t: 2 pointers + 4 int32 + float + int32
+    rec = np.zeros((len(jobs), 5), dtype=np.int64)  # 2 pointers + 4 int32 + float + int32
     for r, (src, dst, scale) in zip(rec, jobs):
         cout, taps, kpad = src.shape
         r[0], r[1] = src.data_ptr(), dst.data_ptr()
         r[2] = cout | (taps << 32)
         r[3] = dst.shape[1] | (kpad << 32)
         r[4] = int(np.float32(scale).view(np.int32)) & 0xFFFFFFFF  # accumulate = 0
-    table = torch.from_numpy(rec).to(jobs[0][0].device)
-    check(_lib.lib().wsr_unpack_wgrad_multi(_p(table), len(jobs), _stream()), "unpack_wgrad_multi")
+    return torch.from_numpy(rec).to(jobs[0][0].device)
+
+
+def unpack_wgrad_multi(table: Tensor) -> None:
+    check(_lib.lib().wsr_unpack_wgrad_multi(_p(table), table.shape[0], _stream()), "unpack_wgrad_multi")
 
 
 def lrelu_bwd_(g: Tensor, g_off: int, y: Tensor, y_off: int, C_: int, slope: float,
