@@ -193,6 +193,35 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const typename T::elem* _
   }
 }
 
+// mean[c] = sums[c] / count
+__global__ void bn_mean_kernel(const float* __restrict__ sums, const float* count_dev, float count_host,
+                               float* __restrict__ mean, int C) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const float cnt = count_dev ? *count_dev : count_host;
+  mean[c] = sums[c] / cnt;
+}
+
+// from the shifted sums {sum d, sum d^2}, d = x - mean: biased variance, invstd, running-stat update
+// (nn.BatchNorm3d: momentum update with the unbiased variance)
+__global__ void bn_finalize_kernel(const float* __restrict__ sums2, const float* count_dev, float count_host,
+                                   const float* __restrict__ mean, float eps, float momentum, float* invstd,
+                                   float* var_out, float* running_mean, float* running_var, int C) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const float cnt = count_dev ? *count_dev : count_host;
+  const float dm = sums2[c] / cnt;
+  float var = sums2[C + c] / cnt - dm * dm;
+  var = var > 0.f ? var : 0.f;
+  invstd[c] = rsqrtf(var + eps);
+  if (var_out) var_out[c] = var;
+  if (running_mean) {
+    const float unb = var * (cnt / fmaxf(cnt - 1.f, 1.f));
+    running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean[c];
+    running_var[c] = (1.f - momentum) * running_var[c] + momentum * unb;
+  }
+}
+
 template <class T>
 __global__ void bn_apply_kernel(const typename T::elem* __restrict__ x, typename T::elem* __restrict__ y,
                                 const float* mean, const float* invstd, const float* gamma, const float* beta, int C,
@@ -419,6 +448,26 @@ extern "C" int wsr_bn_stats(const void* x, int32_t C, int64_t nvox, const float*
                                 (const unsigned short*)x, C, (long)nvox, shift, sums),
              hipLaunchKernelGGL(bn_stats_kernel<F32>, dim3(grid), dim3(256), 0, as_stream(stream), (const float*)x, C,
                                 (long)nvox, shift, sums));
+  WSR_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int wsr_bn_mean(const float* sums, const float* count_dev, float count_host, float* mean, int32_t C,
+                           void* stream) {
+  if (!sums || !mean || C <= 0 || (!count_dev && !(count_host > 0.f))) return WSR_EINVAL;
+  hipLaunchKernelGGL(bn_mean_kernel, dim3((C + 255) / 256), dim3(256), 0, as_stream(stream), sums, count_dev,
+                     count_host, mean, C);
+  WSR_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int wsr_bn_finalize(const float* sums2, const float* count_dev, float count_host, const float* mean,
+                               float eps, float momentum, float* invstd, float* var_out, float* running_mean,
+                               float* running_var, int32_t C, void* stream) {
+  if (!sums2 || !mean || !invstd || C <= 0 || (!count_dev && !(count_host > 0.f))) return WSR_EINVAL;
+  if ((running_mean == nullptr) != (running_var == nullptr)) return WSR_EINVAL;
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, as_stream(stream), sums2, count_dev,
+                     count_host, mean, eps, momentum, invstd, var_out, running_mean, running_var, C);
   WSR_LAUNCH_CHECK();
   return 0;
 }

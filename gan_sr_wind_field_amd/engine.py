@@ -85,17 +85,15 @@ class FilterCache:
         """Re-pack, in ONE launch, the fragment-order copies among ``wanted`` = [(param, transpose)] when any
         of them is stale (after an optimizer step that is all ~600 filters of the generator).  The device job
         table is cached: it only holds pointers, which stay put while parameters and copies keep their storage."""
-        stale = False
-        ptrs = []
-        for p, tr in wanted:
-            hit = self._c.get((id(p), "frag", tr))
-            ptrs.append(p.data_ptr())
-            if hit is None or hit[0] != (p._version, p.data_ptr(), p.device):
-                stale = True
-        if not stale:
+        # cheap staleness probe first: one pass over the versions (an optimizer step bumps all of them)
+        kind = ("pack", len(wanted), sum(1 for _, tr in wanted if tr))
+        probe = (sum(p._version for p, _ in wanted), wanted[0][0].data_ptr(), wanted[-1][0].data_ptr())
+        if self._tables.get(("probe",) + kind) == probe:
             return
+        self._tables[("probe",) + kind] = probe
+        ptrs = [p.data_ptr() for p, _ in wanted]
         key = tuple(ptrs) + tuple(tr for _, tr in wanted)
-        cached = self._tables.get("pack")
+        cached = self._tables.get(kind)
         if cached is None or cached[0] != key:
             jobs = []
             for p, tr in wanted:
@@ -108,7 +106,7 @@ class FilterCache:
                     torch.empty(n, dtype=torch.bfloat16, device=w.device)
                 jobs.append((w, out, tr))
             cached = (key, ops.pack_job_table(jobs), [j[1] for j in jobs])
-            self._tables["pack"] = cached
+            self._tables[kind] = cached
         ops.pack_filter_frag_multi(cached[1])
         for (p, tr), out in zip(wanted, cached[2]):
             self._c[(id(p), "frag", tr)] = ((p._version, p.data_ptr(), p.device), out)
@@ -682,27 +680,34 @@ class DiscriminatorProgram(ProgramBase):
             C_ = s.cout
             n = y.numel() // y.shape[-1]
             if training:
-                # pass 1: sum x -> mean ; pass 2: sum (x - mean)^2 -> variance without cancellation
-                s1 = torch.zeros(2 * C_ + 1, dtype=torch.float32, device=x.device)
+                # pass 1: sum x -> mean ; pass 2: sum (x - mean)^2 -> variance without cancellation.
+                # The per-channel steps in between are two tiny fused kernels (was ~14 torch ops per layer).
+                st = torch.zeros(4 * C_ + 1, dtype=torch.float32, device=x.device)
+                s1, s2 = st[:2 * C_], st[2 * C_:4 * C_]
+                work = torch.empty(2 * C_, dtype=torch.float32, device=x.device)
+                mean, invstd = work[:C_], work[C_:]
                 ops.bn_stats(y, s1)
-                s1[-1] = float(n)
-                if self.stat_allreduce is not None:
-                    self.stat_allreduce(s1)
-                count = float(s1[-1]) if self.stat_allreduce is not None else float(n)
-                mean = s1[:C_] / count
-                s2 = torch.zeros(2 * C_, dtype=torch.float32, device=x.device)
+                cdev = None
+                count = float(n)
+                if self.stat_allreduce is not None:  # SyncBN: sums and the voxel count over all ranks
+                    st[-1] = float(n)
+                    packed = torch.cat([s1, st[-1:]])
+                    self.stat_allreduce(packed)
+                    s1.copy_(packed[:-1])
+                    cdev = packed[-1:]
+                    count = float(cdev)  # (host value for the backward pass; a small sync per layer under DP)
+                ops.bn_mean(s1, mean, count, cdev)
                 ops.bn_stats(y, s2, shift=mean)
                 if self.stat_allreduce is not None:
                     self.stat_allreduce(s2)
-                dm = s2[:C_] / count
-                var = (s2[C_:] / count - dm * dm).clamp_min_(0.0)
-                invstd = torch.rsqrt(var + bn.eps)
-                with torch.no_grad():  # nn.BatchNorm3d bookkeeping (momentum, unbiased running var)
-                    if bn.track_running_stats:
+                track = bn.track_running_stats
+                mom = 0.0
+                if track:
+                    with torch.no_grad():
                         bn.num_batches_tracked += 1
-                        mom = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked)
-                        bn.running_mean.mul_(1 - mom).add_(mean, alpha=mom)
-                        bn.running_var.mul_(1 - mom).add_(var * (count / max(count - 1.0, 1.0)), alpha=mom)
+                    mom = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked)
+                ops.bn_finalize(s2, mean, invstd, count, bn.eps, mom, bn.running_mean if track else None,
+                                bn.running_var if track else None, cdev)
             else:
                 mean = bn.running_mean.detach().float()
                 invstd = torch.rsqrt(bn.running_var.detach().float() + bn.eps)

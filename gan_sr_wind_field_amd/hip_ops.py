@@ -303,6 +303,18 @@ def bn_stats(x: Tensor, sums: Tensor, shift: Optional[Tensor] = None) -> None:
           "bn_stats")
 
 
+def bn_mean(sums: Tensor, mean: Tensor, count: float, count_dev: Optional[Tensor] = None) -> None:
+    check(_lib.lib().wsr_bn_mean(_p(sums), _p(count_dev), float(count), _p(mean), mean.numel(), _stream()), "bn_mean")
+
+
+def bn_finalize(sums2: Tensor, mean: Tensor, invstd: Tensor, count: float, eps: float, momentum: float,
+                running_mean: Optional[Tensor], running_var: Optional[Tensor],
+                count_dev: Optional[Tensor] = None) -> None:
+    check(_lib.lib().wsr_bn_finalize(_p(sums2), _p(count_dev), float(count), _p(mean), eps, momentum, _p(invstd),
+                                     C.c_void_p(0), _p(running_mean), _p(running_var), mean.numel(), _stream()),
+          "bn_finalize")
+
+
 def bn_apply_lrelu(x: Tensor, y: Tensor, mean: Tensor, invstd: Tensor, gamma: Tensor, beta: Tensor, act: bool,
                    slope: float) -> None:
     C_ = x.shape[-1]

@@ -177,6 +177,14 @@ int wsr_ndhwc_to_planar(const void* src, float* dst, int32_t B, int32_t C, int64
  * variance.                                                                     */
 int wsr_bn_stats(const void* x, int32_t C, int64_t nvox, const float* shift, float* sums,
                  int32_t dtype, void* stream);
+/* The small per-channel steps between the two statistics passes, fused (they are launch-latency bound):
+ * mean = sums[0:C] / count;  then from the shifted sums: biased variance, invstd = rsqrt(var + eps) and the
+ * nn.BatchNorm3d running-stat update (unbiased variance, `momentum`).  `count_dev` (device scalar, e.g. the
+ * all-reduced voxel count under data parallelism) overrides `count_host` when not NULL.                  */
+int wsr_bn_mean(const float* sums, const float* count_dev, float count_host, float* mean, int32_t C, void* stream);
+int wsr_bn_finalize(const float* sums2, const float* count_dev, float count_host, const float* mean, float eps,
+                    float momentum, float* invstd, float* var_out, float* running_mean, float* running_var,
+                    int32_t C, void* stream);
 /* y = lrelu((x-mean)*invstd*gamma + beta); mean/invstd fp32 [C]                 */
 int wsr_bn_apply_lrelu(const void* x, void* y, const float* mean, const float* invstd,
                        const float* gamma, const float* beta, int32_t C, int64_t nvox, int32_t act,
