@@ -95,12 +95,20 @@ class wind_field_GAN_3D(BaseGAN):
         ).to(self.device, non_blocking=True)
         initialization.init_weights(self.D, scale=cfg_D.weight_init_scale)
 
+        # the reference's optimizers (:151-162), same state layout and checkpoints; on the GPU the fused
+        # multi-tensor implementation of the same update rule is selected (one launch and ~3 ms less host
+        # time per step than the foreach default).  It updates parameters without bumping their version
+        # counters, so the programs' packed-filter caches are invalidated from a post-step hook.
+        fused = {"fused": True} if torch.device(self.device).type == "cuda" else {}
         self.optimizer_G = torch.optim.Adam(self.G.parameters(), lr=cfg_t.learning_rate_g,
                                             weight_decay=cfg_t.adam_weight_decay_g,
-                                            betas=(cfg_t.adam_beta1_g, 0.999))
+                                            betas=(cfg_t.adam_beta1_g, 0.999), **fused)
         self.optimizer_D = torch.optim.Adam(self.D.parameters(), lr=cfg_t.learning_rate_d,
                                             weight_decay=cfg_t.adam_weight_decay_d,
-                                            betas=(cfg_t.adam_beta1_d, 0.999))
+                                            betas=(cfg_t.adam_beta1_d, 0.999), **fused)
+        if fused:
+            self.optimizer_G.register_step_post_hook(lambda *_: self.G.program().filters.invalidate())
+            self.optimizer_D.register_step_post_hook(lambda *_: self.D.features.program().filters.invalidate())
         self.optimizers += [self.optimizer_G, self.optimizer_D]
         if cfg_t.multistep_lr_steps:
             self.scheduler_G = lr_scheduler.MultiStepLR(self.optimizer_G, cfg_t.multistep_lr_steps,

@@ -48,11 +48,12 @@ class FilterCache:
 
     def __init__(self):
         self._c: Dict[tuple, tuple] = {}
-        self._tables: Dict[str, tuple] = {}
+        self._tables: Dict[tuple, tuple] = {}
+        self._gen = 0  # bumped by invalidate(); part of every stamp
 
     def get(self, p: Tensor, dt: torch.dtype, transpose: bool, kpad: int, rows_pad: int) -> Tensor:
         key = (id(p), dt, transpose, kpad, rows_pad)
-        stamp = (p._version, p.data_ptr(), p.device)
+        stamp = (p._version, p.data_ptr(), p.device, self._gen)
         hit = self._c.get(key)
         if hit is not None and hit[0] == stamp:
             return hit[1]
@@ -73,7 +74,7 @@ class FilterCache:
     def get_frag(self, p: Tensor, transpose: bool) -> Tensor:
         """bf16 MFMA-fragment-order copy for the LDS-tile kernels"""
         key = (id(p), "frag", transpose)
-        stamp = (p._version, p.data_ptr(), p.device)
+        stamp = (p._version, p.data_ptr(), p.device, self._gen)
         hit = self._c.get(key)
         if hit is not None and hit[0] == stamp:
             return hit[1]
@@ -109,7 +110,14 @@ class FilterCache:
             self._tables[kind] = cached
         ops.pack_filter_frag_multi(cached[1])
         for (p, tr), out in zip(wanted, cached[2]):
-            self._c[(id(p), "frag", tr)] = ((p._version, p.data_ptr(), p.device), out)
+            self._c[(id(p), "frag", tr)] = ((p._version, p.data_ptr(), p.device, self._gen), out)
+
+    def invalidate(self) -> None:
+        """Mark every compute copy stale (called from an optimizer post-step hook: the fused multi-tensor
+        Adam updates parameters without touching their version counters)."""
+        self._gen += 1
+        for k in [k for k in self._tables if k[0] == "probe"]:
+            del self._tables[k]
 
     def clear(self):
         self._c.clear()
