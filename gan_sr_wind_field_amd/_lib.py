@@ -43,6 +43,13 @@ class Epilogue(C.Structure):
     ]
 
 
+class LreluMask(C.Structure):
+    """``wsr_lrelu_mask_t``."""
+
+    _fields_ = [("y", C.c_void_p), ("y_ctot", C.c_int32), ("y_off", C.c_int32), ("c0", C.c_int32), ("c1", C.c_int32),
+                ("slope", C.c_float)]
+
+
 _lib: Optional[C.CDLL] = None
 
 
@@ -70,7 +77,7 @@ def lib() -> C.CDLL:
         "wsr_conv3d_wgrad": [C.POINTER(ConvDesc), vp, vp, vp, vp],
         "wsr_conv3d_wgrad_tri": [C.POINTER(ConvDesc), vp, vp, vp, i32, i32, vp],
         "wsr_conv3d_fwd_tile": [C.POINTER(ConvDesc), vp, vp, vp, C.POINTER(Epilogue), vp],
-        "wsr_conv3d_dgrad_tile": [C.POINTER(ConvDesc), vp, vp, vp, f32, C.c_int, C.c_int, vp],
+        "wsr_conv3d_dgrad_tile": [C.POINTER(ConvDesc), vp, vp, vp, f32, C.c_int, C.c_int, C.POINTER(LreluMask), vp],
         "wsr_pack_filter_frag": [vp, vp, i32, i32, i32, i32, i32, i32, vp],
         "wsr_pack_filter_frag_multi": [vp, i32, vp],
         "wsr_pack_filter": [vp, vp, i32, i32, i32, i32, i32, i32, vp],

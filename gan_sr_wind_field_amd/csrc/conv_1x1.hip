@@ -10,6 +10,8 @@
 // exactly one wave - go from global memory straight to registers (16 voxels x 64 contiguous bytes per
 // wave-instruction), all K-steps of a 32-voxel strip in flight at once.  MFMA is issued as
 // D = W * X^T, so a lane holds 4 consecutive output channels of one voxel (8-byte stores).
+#include <cstdlib>
+
 #include "common.h"
 
 namespace {
@@ -26,6 +28,9 @@ struct C1Args {
   long nvox;
   int in_ctot, in_off, out_ctot, out_off, Cout;
   int nstrips;  // ceil(nvox / (16*TM))
+  const unsigned short* mask_y;  // LeakyReLU-backward mask on produced channels [mask_c0, mask_c1), or NULL
+  int mask_ctot, mask_off, mask_c0, mask_c1;
+  float mask_slope;
 };
 
 template <int TN, int TM, int KS>
@@ -93,6 +98,13 @@ __global__ __launch_bounds__(256) void conv1x1_kernel(const C1Args a) {
           const float4 r4 = ld4<BF16>(rp + 16 * j);
           o4.x += a.beta * r4.x; o4.y += a.beta * r4.y; o4.z += a.beta * r4.z; o4.w += a.beta * r4.w;
         }
+        if (a.mask_y && co0 >= a.mask_c0 && co0 < a.mask_c1) {
+          const float4 y4 = ld4<BF16>(a.mask_y + v * a.mask_ctot + a.mask_off + (co0 - a.mask_c0));
+          o4.x *= y4.x > 0.f ? 1.f : a.mask_slope;
+          o4.y *= y4.y > 0.f ? 1.f : a.mask_slope;
+          o4.z *= y4.z > 0.f ? 1.f : a.mask_slope;
+          o4.w *= y4.w > 0.f ? 1.f : a.mask_slope;
+        }
         st4<BF16>(o + 16 * j, o4);
       }
     }
@@ -113,7 +125,8 @@ int launch_c1(const C1Args& a0, hipStream_t st) {
     attr_done = true;
   }
   int grid = (a.nstrips + 3) / 4;
-  if (grid > 512) grid = 512;  // two workgroups per CU; the filter is staged once per workgroup
+  const int cap = getenv("WSR_C1_GRID") ? atoi(getenv("WSR_C1_GRID")) : 256;  // one workgroup per CU measured best (tuning aid)
+  if (grid > cap) grid = cap;  // the filter is staged once per workgroup
   hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds, st, a);
   WSR_LAUNCH_CHECK();
   return 0;
@@ -126,7 +139,7 @@ int launch_c1(const C1Args& a0, hipStream_t st) {
 int wsr_conv1x1_bf16(const unsigned short* in, int in_ctot, int in_off, int red, const unsigned short* wfrag,
                      unsigned short* out, int out_ctot, int out_off, int n_out, long nvox, const float* bias,
                      const unsigned short* res, int res_ctot, int res_off, float alpha, float beta, int act,
-                     float slope, hipStream_t st) {
+                     float slope, const wsr_lrelu_mask_t* mask, hipStream_t st) {
   if (red % 32 || red > 256 || n_out % 4 || n_out > 256) return WSR_EUNSUPPORTED;
   if (in_ctot % 8 || in_off % 8 || out_ctot % 4 || out_off % 4 || (res && (res_ctot % 4 || res_off % 4)))
     return WSR_EUNSUPPORTED;
@@ -136,6 +149,12 @@ int wsr_conv1x1_bf16(const unsigned short* in, int in_ctot, int in_off, int red,
   a.alpha = alpha; a.beta = beta; a.slope = slope; a.act = act;
   a.nvox = nvox;
   a.in_ctot = in_ctot; a.in_off = in_off; a.out_ctot = out_ctot; a.out_off = out_off; a.Cout = n_out;
+  if (mask) {
+    a.mask_y = (const unsigned short*)mask->y;
+    a.mask_ctot = mask->y_ctot; a.mask_off = mask->y_off;
+    a.mask_c0 = mask->c0; a.mask_c1 = mask->c1;
+    a.mask_slope = mask->slope;
+  }
   if (n_out % 16) return WSR_EUNSUPPORTED;  // the fragment-order filter must have exactly TN n-tiles
   const int nt = n_out / 16, ks = red / 32;
   if (nt == 8 && ks == 8) return launch_c1<8, 2, 8>(a, st);    // 256 -> 128 (LFF forward)

@@ -250,18 +250,24 @@ class ProgramBase:
             run()
 
     def dgrad(self, s: ConvSite, g: Tensor, g_off: int, dx: Tensor, dx_off: int, in_xyz, *, alpha: float = 1.0,
-              accumulate: bool = False, dx_planar: bool = False) -> None:
-        """dx[window] (+)= alpha * conv^T(g[window]);  in_xyz = stored input extent of the conv"""
+              accumulate: bool = False, dx_planar: bool = False, mask=None) -> None:
+        """dx[window] (+)= alpha * conv^T(g[window]);  in_xyz = stored input extent of the conv.
+        ``mask`` = (y, y_off, c0, c1): afterwards multiply channels [c0, c1) of the window by the
+        LeakyReLU derivative taken from channels [y_off, ...) of ``y`` (folded into the tile kernel's
+        epilogue; a separate pass on the generic path)."""
         B = g.shape[0]
         cin = s.cin if dx_planar else self.cp(s.cin)
         d = self._desc(s, B, tuple(in_xyz), s.cin if dx_planar else dx.shape[-1], 0 if dx_planar else dx_off,
                        g.shape[-1], g_off, cin=cin, cout=self.cp(s.cout))
 
         def run():
+            m = None if mask is None else (mask[0], mask[1], mask[2], mask[3], self.slope)
             if self.tile_ok(s) and ops.conv_dgrad_tile(d, g, self.filters.get_frag(s.weight, True), dx, alpha=alpha,
-                                                       accumulate=accumulate, dx_planar=dx_planar):
+                                                       accumulate=accumulate, dx_planar=dx_planar, mask=m):
                 return
             ops.conv_dgrad(d, g, self._wt(s), dx, alpha=alpha, accumulate=accumulate, dx_planar=dx_planar)
+            if mask is not None:
+                ops.lrelu_bwd_(dx, dx_off + mask[2], mask[0], mask[1], mask[3] - mask[2], self.slope)
 
         if self.launch_probe is not None:
             self.launch_probe("dgrad:" + s.name, run)
@@ -569,11 +575,18 @@ class GeneratorProgram(ProgramBase):
                 # LFF (1x1x1, bias): out = rdb_scale * (LFF(buf) + b) + x
                 self.wgrad(lff, buf, 0, go, 0, flat, sp, scratch, scale=rdb_scale)
                 sp.view(flat, lff.bias).copy_(go.float().sum(dim=(0, 1, 2, 3)) * rdb_scale)
-                self.dgrad(lff, go, 0, gd, 0, (X, Y, nz), alpha=rdb_scale)
-                for i in reversed(range(len(convs))):
+                # gd[off_i : off_i+gc] is the gradient w.r.t. the LeakyReLU output of growth conv i; it is
+                # complete once the LFF and the later convs have added into it, so the kernel that makes the
+                # last contribution applies the LeakyReLU derivative in its epilogue (window i = nconv-1: the
+                # LFF's input gradient; window i-1: the input gradient of conv i)
+                nc = len(convs)
+                last = nf + (nc - 1) * gc
+                self.dgrad(lff, go, 0, gd, 0, (X, Y, nz), alpha=rdb_scale,
+                           mask=(buf, last, last, last + gc) if nc else None)
+                for i in reversed(range(nc)):
                     off = nf + i * gc
-                    ops.lrelu_bwd_(gd, off, buf, off, gc, sl)
-                    self.dgrad(convs[i], gd, off, gd, 0, (X, Y, nz), accumulate=True)
+                    m = (buf, off - gc, off - gc, off) if i > 0 else None
+                    self.dgrad(convs[i], gd, off, gd, 0, (X, Y, nz), accumulate=True, mask=m)
                 # all growth-channel gradients of the block are final now: one stacked wgrad
                 self.wgrad_dense(convs, buf, gd, flat, sp, scratch)
                 ops.chan_axpby(go, 0, gd, 0, nf, alpha=1.0, beta=1.0)  # + grad through the dense input

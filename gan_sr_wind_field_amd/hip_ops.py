@@ -129,10 +129,19 @@ def conv_fwd_tile(desc: ConvDesc, x: Tensor, wfrag: Tensor, y: Tensor, *, bias: 
 
 
 def conv_dgrad_tile(desc: ConvDesc, dy: Tensor, wfrag_t: Tensor, dx: Tensor, *, alpha: float = 1.0,
-                    accumulate: bool = False, dx_planar: bool = False) -> bool:
+                    accumulate: bool = False, dx_planar: bool = False, mask=None) -> bool:
+    """``mask`` = (y, y_off, c0, c1, slope): fold ``leaky_relu_backward`` of produced channels [c0, c1) into
+    the epilogue, the mask taken from channels [y_off, y_off + c1 - c0) of the saved output ``y``."""
     _need_cuda(dy, wfrag_t, dx)
+    mp = None
+    if mask is not None:
+        y, y_off, c0, c1, slope = mask
+        _need_cuda(y)
+        m = _lib.LreluMask()
+        m.y, m.y_ctot, m.y_off, m.c0, m.c1, m.slope = y.data_ptr(), y.shape[-1], y_off, c0, c1, slope
+        mp = C.byref(m)
     rc = _lib.lib().wsr_conv3d_dgrad_tile(C.byref(desc), _p(dy), _p(wfrag_t), _p(dx), alpha, int(accumulate),
-                                          int(dx_planar), _stream())
+                                          int(dx_planar), mp, _stream())
     if rc == _lib.WSR_EUNSUPPORTED:
         return False
     check(rc, "conv3d_dgrad_tile")

@@ -98,8 +98,17 @@ int wsr_conv3d_dgrad(const wsr_conv_t* c, const void* dy, const void* wt, void* 
  * the caller then uses the generic entry points above.                          */
 int wsr_conv3d_fwd_tile(const wsr_conv_t* c, const void* x, const void* wfrag, void* y,
                         const wsr_epilogue_t* ep, void* stream);
+/* leaky_relu_backward folded into the input-gradient epilogue (optional, NULL = none): after the
+ * accumulation, produced channels [c0, c1) are multiplied by (y > 0 ? 1 : slope), y = channel
+ * y_off + (c - c0) of the saved forward output at the same voxel (NDHWC bf16, y_ctot channels).  This is
+ * the LeakyReLU of the layer whose OUTPUT gradient those channels are (dense-block growth channels). */
+typedef struct wsr_lrelu_mask {
+  const void* y;
+  int32_t y_ctot, y_off, c0, c1;
+  float slope;
+} wsr_lrelu_mask_t;
 int wsr_conv3d_dgrad_tile(const wsr_conv_t* c, const void* dy, const void* wfrag_t, void* dx, float alpha,
-                          int accumulate, int dx_planar, void* stream);
+                          int accumulate, int dx_planar, const wsr_lrelu_mask_t* mask, void* stream);
 int64_t wsr_frag_filter_elems(int32_t rows, int32_t red, int32_t taps);
 int wsr_pack_filter_frag(const float* w, void* out, int32_t Cout, int32_t Cin, int32_t KX, int32_t KY, int32_t KZ,
                          int32_t transpose, void* stream);
