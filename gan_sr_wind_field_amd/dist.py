@@ -53,10 +53,12 @@ class _BatchMean(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, t: Tensor, group):
-        packed = torch.stack([t.sum().float(), torch.tensor(float(t.numel()), device=t.device)])
-        dist.all_reduce(packed, group=group)
-        ctx.group, ctx.count, ctx.shape, ctx.dtype = group, float(packed[1]), t.shape, t.dtype
-        return (packed[0] / packed[1]).to(t.dtype)
+        # equal shards per rank: the global element count is numel * world (no device round trip)
+        total = t.sum().float().reshape(1)
+        dist.all_reduce(total, group=group)
+        count = float(t.numel() * dist.get_world_size(group))
+        ctx.group, ctx.count, ctx.shape, ctx.dtype = group, count, t.shape, t.dtype
+        return (total[0] / count).to(t.dtype)
 
     @staticmethod
     def backward(ctx, g: Tensor):
@@ -163,6 +165,7 @@ class DataParallel:
                 progD.grad_done_hook = lambda: self.grad_done("D")
                 if self.sync_bn:
                     progD.stat_allreduce = self.stat_allreduce
+                    progD.stat_world = self.world
             # the classifier head is ordinary torch autograd: reduce its 4 small tensors per step
             for p in gan.D.classifier.parameters():
                 p.register_post_accumulate_grad_hook(lambda p_: self._avg_async(p_.grad))

@@ -655,6 +655,8 @@ class DiscriminatorProgram(ProgramBase):
 
     #: set by dist.py: all-reduce (sum) of a small fp32 tensor across the DP group, or None
     stat_allreduce: Optional[Callable[[Tensor], None]] = None
+    #: ranks in that group (equal shards per rank)
+    stat_world: int = 1
 
     def __init__(self, layers: Sequence[DLayer], slope: float, dt: torch.dtype):
         super().__init__(dt)
@@ -710,13 +712,11 @@ class DiscriminatorProgram(ProgramBase):
                 ops.bn_stats(y, s1)
                 cdev = None
                 count = float(n)
-                if self.stat_allreduce is not None:  # SyncBN: sums and the voxel count over all ranks
-                    st[-1] = float(n)
-                    packed = torch.cat([s1, st[-1:]])
-                    self.stat_allreduce(packed)
-                    s1.copy_(packed[:-1])
-                    cdev = packed[-1:]
-                    count = float(cdev)  # (host value for the backward pass; a small sync per layer under DP)
+                if self.stat_allreduce is not None:
+                    # SyncBN: sums over all ranks.  Shards are equal (dist.py splits the batch evenly), so the
+                    # global voxel count is n * world - known on the host, no device round trip per layer
+                    self.stat_allreduce(s1)
+                    count = float(n) * self.stat_world
                 ops.bn_mean(s1, mean, count, cdev)
                 ops.bn_stats(y, s2, shift=mean)
                 if self.stat_allreduce is not None:
