@@ -85,6 +85,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_tile_kernel(const CtArgs a)
   constexpr int PL = 4 / TPK;      // octet planes per chunk
   constexpr int CK = 8 * PL;       // channels per chunk
   constexpr int NTW = WN * TN;     // n-tiles per workgroup
+  constexpr bool STAGGER = true;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int t = threadIdx.x, lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -240,18 +241,23 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_tile_kernel(const CtArgs a)
   const int total_phases = a.nchunks * nstages;
   int chunk = 0, st = 0;
   for (int ph = 0; ph < total_phases; ++ph) {
-    // ---- prefetch: next weight stage, and a slice of the next chunk's activations -------
-    if (ph + 1 < total_phases) {
-      const bool wrap = st + 1 == nstages;
-      w_issue(wrap ? chunk + 1 : chunk, wrap ? 0 : st + 1, (ph + 1) & 1);
-    }
-    if (a.xbufs == 2) {
-      if (chunk + 1 < a.nchunks) x_issue(chunk + 1, (chunk + 1) & 1, (HU * st) / nstages, (HU * (st + 1)) / nstages);
-    } else if (st == 0 && chunk > 0) {  // single activation buffer: reload it between chunks
+    // ---- prefetch: next weight stage, and a slice of the next chunk's activations.  The burst costs each
+    // wave several hundred issue cycles during which it feeds no MFMAs, so the two halves of the workgroup
+    // (waves w and w + WAVES/2 share a SIMD) take turns: the first half issues at the top of the phase, the
+    // second half in the middle of its K-step loop, and the other wave keeps the SIMD's matrix pipe busy.
+    if (a.xbufs != 2 && st == 0 && chunk > 0) {  // single activation buffer: reload it between chunks
       x_issue(chunk, 0, 0, HU);
       dma_wait();
       __syncthreads();
     }
+    auto burst = [&]() {
+      if (ph + 1 < total_phases) {
+        const bool wrap = st + 1 == nstages;
+        w_issue(wrap ? chunk + 1 : chunk, wrap ? 0 : st + 1, (ph + 1) & 1);
+      }
+      if (a.xbufs == 2 && chunk + 1 < a.nchunks)
+        x_issue(chunk + 1, (chunk + 1) & 1, (HU * st) / nstages, (HU * (st + 1)) / nstages);
+    };
 
     const char* wcur = Ws + (ph & 1) * stage_units * 1024 + (wn * TN) * 1024 + lane * 16;
     const char* xcur = Xs + (a.xbufs == 2 ? (chunk & 1) * xs_bytes : 0);
@@ -270,25 +276,33 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_tile_kernel(const CtArgs a)
 #pragma unroll
         for (int j = 0; j < TN; ++j) mma_chunk<BF16>(acc[i][j], wf[j], xf[i]);
     };
-    if constexpr (PIPE) {
-      // register double-buffering: the fragments of K-step t+1 are in flight during the MFMAs of K-step t
-      uint4 wA[TN], xA[TM], wB[TN], xB[TM];
-      load_frags(0, wA, xA);
-      int tsi = 0;
-      for (; tsi + 2 <= ts_end; tsi += 2) {
-        load_frags(tsi + 1, wB, xB);
-        mma_frags(wA, xA);
-        if (tsi + 2 < ts_end) load_frags(tsi + 2, wA, xA);
-        mma_frags(wB, xB);
+    auto run_ksteps = [&](int lo, int hi) {
+      if (lo >= hi) return;
+      if constexpr (PIPE) {
+        // register double-buffering: the fragments of K-step t+1 are in flight during the MFMAs of K-step t
+        uint4 wA[TN], xA[TM], wB[TN], xB[TM];
+        load_frags(lo, wA, xA);
+        int tsi = lo;
+        for (; tsi + 2 <= hi; tsi += 2) {
+          load_frags(tsi + 1, wB, xB);
+          mma_frags(wA, xA);
+          if (tsi + 2 < hi) load_frags(tsi + 2, wA, xA);
+          mma_frags(wB, xB);
+        }
+        if (tsi < hi) mma_frags(wA, xA);
+      } else {
+        for (int tsi = lo; tsi < hi; ++tsi) {
+          uint4 wf[TN], xf[TM];
+          load_frags(tsi, wf, xf);
+          mma_frags(wf, xf);
+        }
       }
-      if (tsi < ts_end) mma_frags(wA, xA);
-    } else {
-      for (int tsi = 0; tsi < ts_end; ++tsi) {
-        uint4 wf[TN], xf[TM];
-        load_frags(tsi, wf, xf);
-        mma_frags(wf, xf);
-      }
-    }
+    };
+    const int mid = (STAGGER && wave >= WAVES / 2) ? ts_end / 2 : 0;  // wave-uniform
+    if (mid == 0) burst();
+    run_ksteps(0, mid);
+    if (mid > 0) burst();
+    run_ksteps(mid, ts_end);
     dma_wait();  // this wave's prefetches have landed ...
     __syncthreads();  // ... and so have everybody else's; the buffers just read are free again
     if (++st == nstages) { st = 0; ++chunk; }
