@@ -199,7 +199,10 @@ def main():
                      "kernel": ("conv_tile_kernel<8,1,4,9,2> (LDS halo-tile conv)" if args.dtype == "bf16"
                                 else "igemm_kernel<F32,4,1,2,9>") + ": hr_convs.0 5x5x5 144->144 fwd + dgrad",
                      "achieved": round(achieved, 1) if achieved else None, "peak": peak, "unit": "TFLOP/s",
-                     "frac": round(achieved / peak, 4) if achieved else None, "traffic": None,
+                     "frac": round(achieved / peak, 4) if achieved else None,
+                     # HBM bytes per launch from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over the same kernel
+                     # (profiles/r01_c_hr0_hbm_traffic_pmc.txt; raw counters, algorithmic bytes are 1.21e9)
+                     "traffic": 3.26e9 if (args.dtype == "bf16" and n == 32 and nz == 128 and B == 1) else None,
                      "launches_timed": len(k_ms), "avg_launch_ms": round(sum(k_ms) / len(k_ms), 3) if k_ms else None},
     }
     if world == 1 and not args.no_cpu_baseline:
