@@ -32,12 +32,13 @@ int wsr_ct_run_n144(CtArgs& a, int tpk, hipStream_t st);    // conv_tile_n144.hi
 int wsr_ct_run_narrow(CtArgs& a, int tpk, hipStream_t st);  // conv_tile_narrow.hip
 int wsr_ct_run_wide(CtArgs& a, int tpk, hipStream_t st);    // conv_tile_wide.hip
 int wsr_ct_run_masked(CtArgs& a, int tpk, hipStream_t st);  // conv_tile_masked.hip
+int wsr_ct_run_narrow_masked(CtArgs& a, int tpk, hipStream_t st);  // conv_tile_narrow_masked.hip
 
 namespace {
 
 int dispatch_ct(CtArgs& a, int tpk, hipStream_t st) {
   const int N = a.Cout;
-  if (a.mask_y) return wsr_ct_run_masked(a, tpk, st);
+  if (a.mask_y) return N <= 64 ? wsr_ct_run_narrow_masked(a, tpk, st) : wsr_ct_run_masked(a, tpk, st);
   if (N <= 64) return wsr_ct_run_narrow(a, tpk, st);
   if (N == 144) return wsr_ct_run_n144(a, tpk, st);
   if (N <= 256) return wsr_ct_run_wide(a, tpk, st);
@@ -83,14 +84,21 @@ __global__ void pack_frag_kernel(const float* __restrict__ w, unsigned short* __
 __global__ void pack_frag_multi_kernel(const wsr_pack_job_t* __restrict__ jobs) {
   const wsr_pack_job_t j = jobs[blockIdx.y];
   const int taps = j.KX * j.KY * j.KZ;
-  const int rows = j.transpose ? j.Cin : j.Cout, red = j.transpose ? j.Cout : j.Cin;
+  const bool part = j.red_total > 0;  // one source of a stacked input-gradient filter
+  const int rows = part ? j.c_n : (j.transpose ? j.Cin : j.Cout);
+  const int red = part ? j.red_total : (j.transpose ? j.Cout : j.Cin);
   const int redp = (red + 7) / 8 * 8;
   const int TPK = taps == 1 ? (redp % 32 == 0 ? 1 : (redp % 16 == 0 ? 2 : 4)) : (redp % 16 == 0 ? 2 : 4);
   const int PL = 4 / TPK, CK = 8 * PL;
-  const int nchunks = (redp + CK - 1) / CK, nts = (taps + TPK - 1) / TPK, NT_total = (rows + 15) / 16;
+  const int nts = (taps + TPK - 1) / TPK, NT_total = (rows + 15) / 16;
+  // chunks this job writes (a part owns whole chunks: red_off and Cout are multiples of CK)
+  const int chunk0 = part ? j.red_off / CK : 0;
+  const int nchunks = part ? j.Cout / CK : (redp + CK - 1) / CK;
   const long total = (long)nchunks * nts * NT_total * 512;
   const float* __restrict__ w = j.w;
-  unsigned short* __restrict__ out = reinterpret_cast<unsigned short*>(j.out);
+  unsigned short* __restrict__ out = reinterpret_cast<unsigned short*>(j.out) + (long)chunk0 * nts * NT_total * 512;
+  const int c_lo = part ? j.c_lo : 0;
+  const int src_red = part ? j.Cout : red;
   for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
     const int e = (int)(idx & 7);
     const int lane = (int)((idx >> 3) & 63);
@@ -103,8 +111,8 @@ __global__ void pack_frag_multi_kernel(const wsr_pack_job_t* __restrict__ jobs) 
     const int c = chunk * CK + (g % PL) * 8 + e;
     const int n = nt * 16 + i;
     float v = 0.f;
-    if (tap < taps && c < red && n < rows)
-      v = j.transpose ? w[((long)c * j.Cin + n) * taps + (taps - 1 - tap)] : w[((long)n * j.Cin + c) * taps + tap];
+    if (tap < taps && c < src_red && n < rows)
+      v = j.transpose ? w[((long)c * j.Cin + c_lo + n) * taps + (taps - 1 - tap)] : w[((long)n * j.Cin + c) * taps + tap];
     out[idx] = f2bf(v);
   }
 }

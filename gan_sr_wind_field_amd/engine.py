@@ -30,6 +30,8 @@ from .hip_ops import ConvGeom
 Tensor = torch.Tensor
 
 #: debugging aid (tests set it): allocate work buffers filled with NaN instead of uninitialised
+#: group the input gradients of a dense block by produced window (WSR_STACK_DGRAD=0: one launch per conv)
+STACK_DGRAD = __import__("os").environ.get("WSR_STACK_DGRAD", "1") != "0"
 POISON_BUFFERS = bool(int(__import__("os").environ.get("WSR_POISON_BUFFERS", "0")))
 
 
@@ -82,17 +84,19 @@ class FilterCache:
         self._c[key] = (stamp, out)
         return out
 
-    def refresh_frags(self, wanted) -> None:
+    def refresh_frags(self, wanted, stacked=()) -> None:
         """Re-pack, in ONE launch, the fragment-order copies among ``wanted`` = [(param, transpose)] when any
         of them is stale (after an optimizer step that is all ~600 filters of the generator).  The device job
-        table is cached: it only holds pointers, which stay put while parameters and copies keep their storage."""
+        table is cached: it only holds pointers, which stay put while parameters and copies keep their storage.
+        ``stacked`` = [(key, parts, rows, red_total)] adds the stacked input-gradient filters of dense blocks
+        (``parts`` = [(param, c_lo, c_n, red_off)], see ``wsr_pack_job_t``); fetch them with :meth:`get_stacked`."""
         # cheap staleness probe first: one pass over the versions (an optimizer step bumps all of them)
-        kind = ("pack", len(wanted), sum(1 for _, tr in wanted if tr))
+        kind = ("pack", len(wanted), sum(1 for _, tr in wanted if tr), len(stacked))
         probe = (sum(p._version for p, _ in wanted), wanted[0][0].data_ptr(), wanted[-1][0].data_ptr())
         if self._tables.get(("probe",) + kind) == probe:
             return
         self._tables[("probe",) + kind] = probe
-        ptrs = [p.data_ptr() for p, _ in wanted]
+        ptrs = [p.data_ptr() for p, _ in wanted] + [p.data_ptr() for _, parts, _, _ in stacked for p, *_ in parts]
         key = tuple(ptrs) + tuple(tr for _, tr in wanted)
         cached = self._tables.get(kind)
         if cached is None or cached[0] != key:
@@ -106,11 +110,29 @@ class FilterCache:
                 out = hit[1] if hit is not None and hit[1].numel() == n and hit[1].device == w.device else \
                     torch.empty(n, dtype=torch.bfloat16, device=w.device)
                 jobs.append((w, out, tr))
-            cached = (key, ops.pack_job_table(jobs), [j[1] for j in jobs])
+            outs = [j[1] for j in jobs]
+            for skey, parts, rows, red_total in stacked:
+                w0 = parts[0][0].detach()
+                n = ops.frag_filter_elems_for(rows, red_total, w0[0, 0].numel())
+                hit = self._c.get((skey, "dstack"))
+                out = hit[1] if hit is not None and hit[1].numel() == n and hit[1].device == w0.device else \
+                    torch.empty(n, dtype=torch.bfloat16, device=w0.device)
+                for p, c_lo, c_n, red_off in parts:
+                    w = p.detach()
+                    if not w.is_contiguous():
+                        raise ValueError("conv filters must be contiguous")
+                    jobs.append((w, out, True, c_lo, c_n, red_off, red_total))
+                outs.append(out)
+            cached = (key, ops.pack_job_table(jobs), outs)
             self._tables[kind] = cached
         ops.pack_filter_frag_multi(cached[1])
         for (p, tr), out in zip(wanted, cached[2]):
             self._c[(id(p), "frag", tr)] = ((p._version, p.data_ptr(), p.device, self._gen), out)
+        for (skey, _, _, _), out in zip(stacked, cached[2][len(wanted):]):
+            self._c[(skey, "dstack")] = (None, out)
+
+    def get_stacked(self, skey) -> Tensor:
+        return self._c[(skey, "dstack")][1]
 
     def invalidate(self) -> None:
         """Mark every compute copy stale (called from an optimizer post-step hook: the fused multi-tensor
@@ -197,6 +219,7 @@ class ProgramBase:
         self._pending_unpack: list = []
         self._unpack_tables: Dict[tuple, Tensor] = {}
         self._scratch_elems_total = 0
+        self._stack_specs = None
 
     def cp(self, c: int) -> int:
         """channel count padded to whole 16-byte pieces"""
@@ -209,9 +232,15 @@ class ProgramBase:
             return
         sites = [s for s in self.conv_sites() if self.tile_ok(s)]
         wanted = [(s.weight, False) for s in sites]
+        stacked = ()
         if backward:
-            wanted += [(s.weight, True) for s in sites]
-        self.filters.refresh_frags(wanted)
+            stacked = self.stacked_dgrad_specs()
+            covered = {id(p) for _, parts, _, _ in stacked for p, *_ in parts}
+            wanted += [(s.weight, True) for s in sites if id(s.weight) not in covered]
+        self.filters.refresh_frags(wanted, stacked)
+
+    def stacked_dgrad_specs(self):
+        return ()
 
     def conv_sites(self) -> Sequence[ConvSite]:
         return getattr(self, "all_sites", [])
@@ -312,6 +341,60 @@ class ProgramBase:
             ops.conv_wgrad_tri(d, buf, gd, dw3, nf, gc)
         for i, c in enumerate(convs):
             self._pending_unpack.append((dw3[i * gc:(i + 1) * gc], space.view(flat, c.weight), 1.0))
+
+    # ---- stacked input gradient of a dense block ---------------------------------------------------
+    # Conv i of a block reads channels [0, nf + i*gc) of the dense buffer, so per-conv input gradients
+    # read-modify-write nf + i*gc channels each (nf*nc + gc*nc*(nc-1)/2 in total).  Grouped by PRODUCED
+    # window instead - window w = the output of conv w-1 (w = 0: the block input) - every window is
+    # written once, by one conv whose reduction runs over the output gradients of all convs i >= w,
+    # which sit side by side in channels [nf + w*gc, nf + nc*gc) of the gradient buffer: the same
+    # arithmetic, a third of the traffic, longer reductions.  Windows go last to first because window
+    # w's result (after its LeakyReLU mask) is the output gradient of conv w-1.
+    def dense_stackable(self, convs: Sequence[ConvSite]) -> bool:
+        if not (STACK_DGRAD and self.use_tile and self.dt == torch.bfloat16 and len(convs) > 1):
+            return False
+        nf, gc = convs[0].cin, convs[0].cout
+        return (gc % 16 == 0 and nf % 16 == 0 and gc <= 64 and nf <= 256 and convs[0].taps > 1 and all(
+            c.kernel == convs[0].kernel and c.stride == (1, 1, 1) and c.pad == convs[0].pad and c.cout == gc
+            and c.cin == nf + i * gc and not c.upsample for i, c in enumerate(convs)))
+
+    @staticmethod
+    def dense_windows(convs: Sequence[ConvSite]):
+        """[(w, c_lo, c_n, red)] - produced channel window and reduction width of each stacked stage"""
+        nf, gc, nc = convs[0].cin, convs[0].cout, len(convs)
+        return [(w, 0 if w == 0 else nf + (w - 1) * gc, nf if w == 0 else gc, (nc - w) * gc) for w in range(nc)]
+
+    def dense_dgrad_specs(self, convs: Sequence[ConvSite]):
+        gc = convs[0].cout
+        return [((id(convs[0].weight), w), [(convs[i].weight, c_lo, c_n, (i - w) * gc) for i in range(w, len(convs))],
+                 c_n, red) for w, c_lo, c_n, red in self.dense_windows(convs)]
+
+    def dgrad_dense(self, convs: Sequence[ConvSite], gd: Tensor, buf: Tensor, in_xyz) -> None:
+        """gd[..., :nf + (nc-1)*gc] += input gradients of all growth convs (gd[..., nf + i*gc:][:gc] = output
+        gradient of conv i, complete for i = nc-1 on entry); LeakyReLU derivative of ``buf`` applied to the
+        growth windows as they become final."""
+        nf, gc, nc = convs[0].cin, convs[0].cout, len(convs)
+        B, ctot = gd.shape[0], gd.shape[-1]
+        for w, c_lo, c_n, red in reversed(self.dense_windows(convs)):
+            geom = ConvGeom(c_n, red, convs[0].kernel, (1, 1, 1), convs[0].pad)
+            d = ops.make_desc(geom, self.dt, B, tuple(in_xyz), ctot, c_lo, ctot, nf + w * gc)
+            m = None if w == 0 else (buf, c_lo, 0, c_n, self.slope)
+            frag = self.filters.get_stacked((id(convs[0].weight), w))
+
+            def run():
+                if ops.conv_dgrad_tile(d, gd, frag, gd, alpha=1.0, accumulate=True, mask=m):
+                    return
+                for i in range(w, nc):  # generic kernels, one source conv at a time
+                    c = convs[i]
+                    di = self._desc(c, B, tuple(in_xyz), ctot, c_lo, ctot, nf + i * gc, cin=c_n, cout=self.cp(c.cout))
+                    ops.conv_dgrad(di, gd, self._wt(c)[c_lo:c_lo + c_n], gd, accumulate=True)
+                if m is not None:
+                    ops.lrelu_bwd_(gd, c_lo, buf, c_lo, c_n, self.slope)
+
+            if self.launch_probe is not None:
+                self.launch_probe(f"dgrad_dense{w}:" + convs[0].name, run)
+            else:
+                run()
 
     # ---- packed filter-gradient arena -------------------------------------------------------------
     # The wgrad kernels accumulate (float atomics) into packed [Cout][taps][Cin_p] buffers.  One arena per
@@ -583,10 +666,13 @@ class GeneratorProgram(ProgramBase):
                 last = nf + (nc - 1) * gc
                 self.dgrad(lff, go, 0, gd, 0, (X, Y, nz), alpha=rdb_scale,
                            mask=(buf, last, last, last + gc) if nc else None)
-                for i in reversed(range(nc)):
-                    off = nf + i * gc
-                    m = (buf, off - gc, off - gc, off) if i > 0 else None
-                    self.dgrad(convs[i], gd, off, gd, 0, (X, Y, nz), accumulate=True, mask=m)
+                if self.dense_stackable(convs):
+                    self.dgrad_dense(convs, gd, buf, (X, Y, nz))
+                else:
+                    for i in reversed(range(nc)):
+                        off = nf + i * gc
+                        m = (buf, off - gc, off - gc, off) if i > 0 else None
+                        self.dgrad(convs[i], gd, off, gd, 0, (X, Y, nz), accumulate=True, mask=m)
                 # all growth-channel gradients of the block are final now: one stacked wgrad
                 self.wgrad_dense(convs, buf, gd, flat, sp, scratch)
                 ops.chan_axpby(go, 0, gd, 0, nf, alpha=1.0, beta=1.0)  # + grad through the dense input
@@ -601,6 +687,14 @@ class GeneratorProgram(ProgramBase):
         if self.grad_done_hook is not None:
             self.grad_done_hook()
         return flat
+
+    def stacked_dgrad_specs(self):
+        key = (self.use_tile, STACK_DGRAD)
+        if self._stack_specs is None or self._stack_specs[0] != key:
+            specs = [sp for rdbs in self.rrdbs for convs, _, _ in rdbs if self.dense_stackable(convs)
+                     for sp in self.dense_dgrad_specs(convs)]
+            self._stack_specs = (key, specs)
+        return self._stack_specs[1]
 
     def _drop_padded(self, drop: Optional[Tensor], c: int) -> Optional[Tensor]:
         if drop is None or drop.shape[1] == c:

@@ -169,18 +169,31 @@ def frag_filter_elems(w: Tensor, transpose: bool) -> int:
     return int(_lib.lib().wsr_frag_filter_elems(rows, red, kx * ky * kz))
 
 
+def frag_filter_elems_for(rows: int, red: int, taps: int) -> int:
+    return int(_lib.lib().wsr_frag_filter_elems(rows, red, taps))
+
+
 def pack_job_table(jobs) -> Tensor:
-    """Device table of ``wsr_pack_job_t`` records for ``jobs`` = [(master fp32 weight, out bf16 tensor, transpose)].
-    The table only holds pointers and shapes, so it stays valid while those tensors keep their storage."""
+    """Device table of ``wsr_pack_job_t`` records for ``jobs`` = [(master fp32 weight, out bf16 tensor, transpose)]
+    or, for one source of a stacked dense-block input-gradient filter, [(weight, out, True, c_lo, c_n, red_off,
+    red_total)].  The table only holds pointers and shapes, so it stays valid while those tensors keep their storage."""
     import numpy as np
 
-    rec = np.zeros((len(jobs), 5), dtype=np.int64)  # 2 pointers + 6 int32
-    for r, (w, out, tr) in zip(rec, jobs):
+    rec = np.zeros((len(jobs), 7), dtype=np.int64)  # 2 pointers + 10 int32
+    for r, job in zip(rec, jobs):
+        w, out, tr = job[:3]
         cout, cin, kx, ky, kz = w.shape
         r[0], r[1] = w.data_ptr(), out.data_ptr()
         r[2] = cout | (cin << 32)
         r[3] = kx | (ky << 32)
         r[4] = kz | (int(tr) << 32)
+        if len(job) > 3:
+            c_lo, c_n, red_off, red_total = job[3:]
+            if not tr or cout % 16 or red_off % 16 or red_total % 16 or c_lo < 0 or c_lo + c_n > cin \
+                    or red_off + cout > red_total:
+                raise ValueError("bad stacked filter part")
+            r[5] = c_lo | (c_n << 32)
+            r[6] = red_off | (red_total << 32)
     return torch.from_numpy(rec).to(jobs[0][0].device)
 
 

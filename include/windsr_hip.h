@@ -118,6 +118,13 @@ typedef struct wsr_pack_job {
   const float* w;  /* master (Cout, Cin, KX, KY, KZ) fp32 */
   void* out;       /* wsr_frag_filter_elems(...) bf16 elements */
   int32_t Cout, Cin, KX, KY, KZ, transpose;
+  /* Stacked input-gradient filter of a residual dense block (torch_blocks.py:256-267), red_total > 0 and
+   * transpose = 1 only: the destination is the filter of ONE virtual conv whose reduction axis is the
+   * concatenation of the output channels of several growth convs (red_total of them, this job fills
+   * reduction channels [red_off, red_off + Cout)) and whose rows are input channels [c_lo, c_lo + c_n) of
+   * this job's conv.  Jobs of one destination write disjoint parts of it; red_off and Cout must be
+   * multiples of 16.  red_total = 0: a plain filter (the fields above).                              */
+  int32_t c_lo, c_n, red_off, red_total;
 } wsr_pack_job_t;
 int wsr_pack_filter_frag_multi(const wsr_pack_job_t* jobs_dev, int32_t n_jobs, void* stream);
 
