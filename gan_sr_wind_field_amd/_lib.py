@@ -11,7 +11,7 @@ import os
 from typing import Optional
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libwindsr_hip.so")
+LIB_PATH = os.environ.get("WSR_LIB_PATH") or os.path.join(_HERE, "csrc", "libwindsr_hip.so")  # (override: tuning builds)
 
 WSR_F32, WSR_BF16 = 0, 1
 WSR_EUNSUPPORTED = -2

@@ -40,7 +40,7 @@ int dispatch_ct(CtArgs& a, int tpk, hipStream_t st) {
   const int N = a.Cout;
   if (a.mask_y) return N <= 64 ? wsr_ct_run_narrow_masked(a, tpk, st) : wsr_ct_run_masked(a, tpk, st);
   if (N <= 64) return wsr_ct_run_narrow(a, tpk, st);
-  if (N == 144) return wsr_ct_run_n144(a, tpk, st);
+  if (N == 144 || (N > 64 && N < 144 && getenv("WSR_CT_BIG"))) return wsr_ct_run_n144(a, tpk, st);
   if (N <= 256) return wsr_ct_run_wide(a, tpk, st);
   return WSR_EUNSUPPORTED;
 }

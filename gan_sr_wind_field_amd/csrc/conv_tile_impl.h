@@ -54,12 +54,15 @@ struct CtArgs {
   int NT_total;     // 16-wide output-channel tiles
   int ngroups;      // n-tile groups (grid = ntiles * ngroups)
   int P;            // activation plane stride (bytes)
-  int off_mtab, off_htab, off_vtab, off_ttab, off_xs, off_ws;
+  int off_mtab, off_htab, off_ttab, off_xs, off_ws;
   int vec_ok;
   const unsigned short* mask_y;  // LeakyReLU-backward mask source (saved forward output) or NULL
   int mask_ctot, mask_off, mask_c0, mask_c1;
   float mask_slope;
   int xbufs;        // activation buffers in LDS: 2 = next chunk prefetched during the MFMAs
+  // ceil(2^32 / d) for the runtime divisors of the prologue (fdiv): tile / halo / tap extents, tile counts
+  unsigned mg_TZ, mg_TY, mg_Lz, mg_Ly, mg_KZ, mg_KY, mg_ng, mg_tz, mg_ty, mg_tx;
+  unsigned long long* stamps;  // -DWSR_CT_STAMPS builds: [workgroup][8] clock samples of wave 0 (else unused)
 };
 
 namespace {
@@ -79,6 +82,22 @@ __device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_addr) {
 }
 __device__ __forceinline__ void dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
+// In-kernel phase stamps (tuning builds only): wave 0 of every workgroup samples the 100 MHz wall clock
+// (slots 0-5) and the shader clock at entry / exit (slots 6-7).
+#ifdef WSR_CT_STAMPS
+#define CT_STAMP(k)                                                                                   \
+  do {                                                                                                \
+    if (a.stamps && threadIdx.x == 0) a.stamps[(size_t)blockIdx.x * 8 + (k)] = (k) >= 6 ? clock64() : wall_clock64(); \
+  } while (0)
+#else
+#define CT_STAMP(k) do {} while (0)
+#endif
+
+// n / d for n < 65536, d < 65536 with mg = ceil(2^32 / d) (exact: the error term n*(mg*d - 2^32) stays
+// below 2^32); d == 1 has no 32-bit multiplier and is passed through.
+__device__ __forceinline__ unsigned fdiv(unsigned n, unsigned d, unsigned mg) { return d == 1 ? n : __umulhi(n, mg); }
+static inline unsigned fdiv_magic(int d) { return d <= 1 ? 0u : (unsigned)(((1ull << 32) + d - 1) / d); }
+
 template <int WM, int WN, int TM, int TN, int TPK, bool PIPE, bool MASK>
 __global__ __launch_bounds__(WM * WN * 64) void conv_tile_kernel(const CtArgs a) {
   constexpr int WAVES = WM * WN, NT = WAVES * 64;
@@ -90,6 +109,8 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_tile_kernel(const CtArgs a)
   const int t = threadIdx.x, lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
   const int wm = wave / WN, wn = wave % WN;
+  CT_STAMP(0);
+  CT_STAMP(6);
 
   const int Lx = a.TX + a.KX - 1, Ly = a.TY + a.KY - 1, Lz = a.TZ + a.KZ - 1;
   const int L = Lx * Ly * Lz;
@@ -99,44 +120,20 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_tile_kernel(const CtArgs a)
 
   unsigned* mtab = reinterpret_cast<unsigned*>(smem + a.off_mtab);
   unsigned short* htab = reinterpret_cast<unsigned short*>(smem + a.off_htab);
-  unsigned* vtab = reinterpret_cast<unsigned*>(smem + a.off_vtab);
   int* ttab = reinterpret_cast<int*>(smem + a.off_ttab);
   char* Xs = smem + a.off_xs;
   char* Ws = smem + a.off_ws;
 
-  int bid = xcd_remap(blockIdx.x, gridDim.x);
-  const int ng = bid % a.ngroups;
-  const int tile = bid / a.ngroups;
-  int r = tile;
-  const int tz = r % a.tiles_z; r /= a.tiles_z;
-  const int ty = r % a.tiles_y; r /= a.tiles_y;
-  const int tx = r % a.tiles_x;
-  const int b = r / a.tiles_x;
+  const unsigned bid = (unsigned)xcd_remap(blockIdx.x, gridDim.x);
+  const unsigned tile = fdiv(bid, a.ngroups, a.mg_ng);
+  const int ng = (int)(bid - tile * a.ngroups);
+  unsigned r = tile, r2;
+  r2 = fdiv(r, a.tiles_z, a.mg_tz); const int tz = (int)(r - r2 * a.tiles_z); r = r2;
+  r2 = fdiv(r, a.tiles_y, a.mg_ty); const int ty = (int)(r - r2 * a.tiles_y); r = r2;
+  r2 = fdiv(r, a.tiles_x, a.mg_tx); const int tx = (int)(r - r2 * a.tiles_x);
+  const int b = (int)r2;
   const int x0 = tx * a.TX, y0 = ty * a.TY, z0 = tz * a.TZ;
   const int nt0 = ng * NTW;  // first n-tile of this workgroup
-
-  // ---- tables -----------------------------------------------------------------------
-  for (int m = t; m < MR; m += NT) {  // rows >= M (tile volume) are padding: flagged, read voxel 0
-    const int oz = m % a.TZ, q = m / a.TZ;
-    const int oy = q % a.TY, ox = q / a.TY;
-    mtab[m] = m < M ? (ox | (oy << 8) | (oz << 16)) : (1u << 24);
-    htab[m] = m < M ? (unsigned short)((ox * Ly + oy) * Lz + oz) : (unsigned short)0;
-  }
-  for (int v = t; v < L; v += NT) {
-    const int hz = v % Lz, q = v / Lz;
-    const int hy = q % Ly, hx = q / Ly;
-    vtab[v] = hx | (hy << 8) | (hz << 16);
-  }
-  for (int k = t; k < a.nts * TPK; k += NT) {
-    int off = 0;
-    if (k < taps) {
-      const int kz = k % a.KZ, q = k / a.KZ;
-      const int ky = q % a.KY, kx = q / a.KY;
-      off = (kx * Ly + ky) * Lz + kz;
-    }
-    ttab[k] = off;
-  }
-  __syncthreads();
 
   // ---- per-lane fragment geometry --------------------------------------------------------
   const int fr = lane & 15, fg = lane >> 4;
@@ -148,15 +145,6 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_tile_kernel(const CtArgs a)
   constexpr int RB = VM ? 32 : 16;  // bytes per voxel row
   const int lane_plane = VM ? (fg & 1) * 16 : (fg % PL) * a.P;
   const int lane_tsub = fg / PL;           // which of the K-step's TPK taps this lane's octet belongs to
-  int hb[TM];                              // byte offset of row `fr` of m-tile i in a plane
-#pragma unroll
-  for (int i = 0; i < TM; ++i) hb[i] = (int)htab[(wm * TM + i) * 16 + fr] * RB + lane_plane;
-
-  f32x4_t acc[TM][TN];
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
   const int U = a.ups ? 1 : 0;
   const int nstages = (a.nts + a.TS - 1) / a.TS;
@@ -182,6 +170,9 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_tile_kernel(const CtArgs a)
       }
     }
   };
+  // The first weight stage needs nothing computed here: its DMA flies while the tables are built.
+  w_issue(0, 0, 0);
+
   // The halo geometry is the same for every chunk, so each wave resolves the source of "its" DMA units
   // (u = wave + WAVES*k) once: element offset of the lane's voxel (or OOB), octet plane, LDS offset.
   constexpr int XK = 10;  // max units per wave per chunk (checked on the host)
@@ -204,9 +195,8 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_tile_kernel(const CtArgs a)
         dsto = pl * a.P + (u - pl * UPP) * 1024;
       }
       if (v < L) {
-        const unsigned hv = vtab[v];
-        const int gx = x0 - a.px + (int)(hv & 255), gy = y0 - a.py + (int)((hv >> 8) & 255),
-                  gz = z0 - a.pz + (int)(hv >> 16);
+        const unsigned q = fdiv((unsigned)v, Lz, a.mg_Lz), hx = fdiv(q, Ly, a.mg_Ly);
+        const int gx = x0 - a.px + (int)hx, gy = y0 - a.py + (int)(q - hx * Ly), gz = z0 - a.pz + (int)(v - q * Lz);
         if ((unsigned)gx < (unsigned)(a.Xi << U) && (unsigned)gy < (unsigned)(a.Yi << U) &&
             (unsigned)gz < (unsigned)a.Zi) {
           const long vox = (((long)b * a.Xi + (gx >> U)) * a.Yi + (gy >> U)) * a.Zi + gz;
@@ -232,11 +222,38 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_tile_kernel(const CtArgs a)
       }
     }
   };
-
+  CT_STAMP(1);
   x_issue(0, 0, 0, HU);
-  w_issue(0, 0, 0);
+  CT_STAMP(2);
+
+  // ---- tables (built under the first DMA) ---------------------------------------------------
+  for (int m = t; m < MR; m += NT) {  // rows >= M (tile volume) are padding: flagged, read voxel 0
+    const unsigned q = fdiv((unsigned)m, a.TZ, a.mg_TZ), ox = fdiv(q, a.TY, a.mg_TY);
+    const unsigned oz = m - q * a.TZ, oy = q - ox * a.TY;
+    mtab[m] = m < M ? (ox | (oy << 8) | (oz << 16)) : (1u << 24);
+    htab[m] = m < M ? (unsigned short)((ox * Ly + oy) * Lz + oz) : (unsigned short)0;
+  }
+  for (int k = t; k < a.nts * TPK; k += NT) {
+    int off = 0;
+    if (k < taps) {
+      const unsigned q = fdiv((unsigned)k, a.KZ, a.mg_KZ), kx = fdiv(q, a.KY, a.mg_KY);
+      off = (int)((kx * Ly + (q - kx * a.KY)) * Lz + (k - q * a.KZ));
+    }
+    ttab[k] = off;
+  }
   dma_wait();
   __syncthreads();
+  CT_STAMP(3);
+
+  int hb[TM];                              // byte offset of row `fr` of m-tile i in a plane
+#pragma unroll
+  for (int i = 0; i < TM; ++i) hb[i] = (int)htab[(wm * TM + i) * 16 + fr] * RB + lane_plane;
+
+  f32x4_t acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
   const int total_phases = a.nchunks * nstages;
   int chunk = 0, st = 0;
@@ -308,75 +325,103 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_tile_kernel(const CtArgs a)
     if (++st == nstages) { st = 0; ++chunk; }
   }
 
-  // ---- epilogue: acc[i][j][r] -> channel (nt0 + wn*TN + j)*16 + 4*fg + r, voxel row fr of m-tile i
+  CT_STAMP(4);
+  // ---- epilogue: acc[i][j][r] -> channel (nt0 + wn*TN + j)*16 + 4*fg + r, voxel row fr of m-tile i.
+  // No load may sit between two stores (the compiler cannot move it above a store that might alias, so
+  // every tile would pay a full memory round trip).  The n-tiles are walked one at a time; the operands
+  // of n-tile j+1 (bias, channel scale, residual and mask values of its TM rows) are fetched before the
+  // stores of n-tile j are issued.
   const long vox_per_b = (long)a.Xo * a.Yo * a.Zo;
+  const int cob = (nt0 + wn * TN) * 16 + fg * 4;  // this lane's first channel of n-tile j is cob + 16*j
+  const bool fast = a.vec_ok && !a.out_planar && (a.Cout & 3) == 0 && (a.mask_c1 & 3) == 0;
+  long mrow[TM];   // flat output voxel of row `fr` of m-tile i, or -1
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
     const unsigned mv = mtab[(wm * TM + i) * 16 + fr];
     const int gx = x0 + (int)(mv & 255), gy = y0 + (int)((mv >> 8) & 255), gz = z0 + (int)((mv >> 16) & 255);
-    if ((mv >> 24) || gx >= a.Xo || gy >= a.Yo || gz >= a.Zo) continue;
-    const long vi = ((long)gx * a.Yo + gy) * a.Zo + gz;
-    const long m = (long)b * vox_per_b + vi;
+    const bool ok = !(mv >> 24) && gx < a.Xo && gy < a.Yo && gz < a.Zo;
+    mrow[i] = ok ? (long)b * vox_per_b + ((long)gx * a.Yo + gy) * a.Zo + gz : -1;
+  }
+  float bb[2][4], ss[2][4];
+  uint2 rr[2][TM], yy[2][TM];
+  auto fetch = [&](int j, int s) {
+    const int co0 = cob + 16 * j;
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      const int co0 = (nt0 + wn * TN + j) * 16 + fg * 4;
-      if (co0 >= a.Cout) continue;
-      float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-      const int nval = (a.Cout - co0) < 4 ? (a.Cout - co0) : 4;
+    for (int q = 0; q < 4; ++q) {
+      const bool in = co0 + q < a.Cout;
+      bb[s][q] = (a.bias && in) ? a.bias[co0 + q] : 0.f;
+      ss[s][q] = ((a.chan_scale && in) ? a.chan_scale[(long)b * a.Cout + co0 + q] : 1.f) * a.alpha;
+    }
+    if (!fast || co0 >= a.Cout) return;
+    // LeakyReLU backward of the layer whose output gradient this is (channels [mask_c0, mask_c1)): the
+    // multiply by (y > 0 ? 1 : slope) happens in this epilogue, after the accumulation, not in its own pass
+    const bool masked = MASK && co0 >= a.mask_c0 && co0 < a.mask_c1;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      rr[s][i] = make_uint2(0u, 0u);
+      yy[s][i] = make_uint2(0x3F803F80u, 0x3F803F80u);  // +1: the derivative is 1 outside the mask window
+      if (mrow[i] < 0) continue;
+      if (a.res) rr[s][i] = *reinterpret_cast<const uint2*>(a.res + mrow[i] * a.res_ctot + a.res_off + co0);
+      if (masked)
+        yy[s][i] = *reinterpret_cast<const uint2*>(a.mask_y + mrow[i] * a.mask_ctot + a.mask_off + (co0 - a.mask_c0));
+    }
+  };
+  fetch(0, 0);
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int s = j & 1;
+    if (j + 1 < TN) fetch(j + 1, s ^ 1);
+    const int co0 = cob + 16 * j;
+    if (co0 >= a.Cout) continue;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      if (mrow[i] < 0) continue;
+      float v[4];
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        if (q < nval) {
-          float x = v[q];
-          if (a.bias) x += a.bias[co0 + q];
-          if (a.act) x = x > 0.f ? x : x * a.slope;
-          if (a.chan_scale) x *= a.chan_scale[(long)b * a.Cout + co0 + q];
-          v[q] = x * a.alpha;
-        }
+        float x = acc[i][j][q] + bb[s][q];
+        if (a.act) x = x > 0.f ? x : x * a.slope;
+        v[q] = x * ss[s][q];
       }
-      if (a.out_planar) {
-        float* o = reinterpret_cast<float*>(a.out);
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-          if (q < nval) o[((long)b * a.Cout + co0 + q) * vox_per_b + vi] = v[q];
-      } else {
-        unsigned short* o = reinterpret_cast<unsigned short*>(a.out) + m * a.out_ctot + a.out_off + co0;
-        const unsigned short* rp = a.res ? a.res + m * a.res_ctot + a.res_off + co0 : nullptr;
-        // LeakyReLU backward of the layer whose output gradient this is (channels [mask_c0, mask_c1)): the
-        // multiply by (y > 0 ? 1 : slope) happens here, after the accumulation, instead of in its own pass
-        const unsigned short* mp = nullptr;  // (compiled in only for MASK: it costs ~25 VGPRs in the epilogue)
-        if constexpr (MASK) {
-          if (co0 >= a.mask_c0 && co0 < a.mask_c1) mp = a.mask_y + m * a.mask_ctot + a.mask_off + (co0 - a.mask_c0);
+      if (fast) {
+        float4 o4 = make_float4(v[0], v[1], v[2], v[3]);
+        if (a.res) {
+          o4.x += a.beta * bf2f((unsigned short)(rr[s][i].x & 0xFFFFu));
+          o4.y += a.beta * bf2f((unsigned short)(rr[s][i].x >> 16));
+          o4.z += a.beta * bf2f((unsigned short)(rr[s][i].y & 0xFFFFu));
+          o4.w += a.beta * bf2f((unsigned short)(rr[s][i].y >> 16));
         }
-        if (nval == 4 && a.vec_ok) {
-          float4 o4 = make_float4(v[0], v[1], v[2], v[3]);
-          if (rp) {
-            const float4 r4 = ld4<BF16>(rp);
-            o4.x += a.beta * r4.x;
-            o4.y += a.beta * r4.y;
-            o4.z += a.beta * r4.z;
-            o4.w += a.beta * r4.w;
-          }
-          if (mp) {
-            const float4 y4 = ld4<BF16>(mp);
-            o4.x *= y4.x > 0.f ? 1.f : a.mask_slope;
-            o4.y *= y4.y > 0.f ? 1.f : a.mask_slope;
-            o4.z *= y4.z > 0.f ? 1.f : a.mask_slope;
-            o4.w *= y4.w > 0.f ? 1.f : a.mask_slope;
-          }
-          st4<BF16>(o, o4);
-        } else {
+        if constexpr (MASK) {  // bf16 sign test on the raw bits: y > 0 <=> sign clear and not zero
+          o4.x *= (short)(yy[s][i].x & 0xFFFFu) > 0 ? 1.f : a.mask_slope;
+          o4.y *= (int)yy[s][i].x > 0xFFFF ? 1.f : a.mask_slope;
+          o4.z *= (short)(yy[s][i].y & 0xFFFFu) > 0 ? 1.f : a.mask_slope;
+          o4.w *= (int)yy[s][i].y > 0xFFFF ? 1.f : a.mask_slope;
+        }
+        st4<BF16>(reinterpret_cast<unsigned short*>(a.out) + mrow[i] * a.out_ctot + a.out_off + co0, o4);
+        continue;
+      }
+      // general path: planar fp32 output (network boundary), channel tails, unaligned windows
+      const long vi = mrow[i] - (long)b * vox_per_b;
 #pragma unroll
-          for (int q = 0; q < 4; ++q)
-            if (q < nval) {
-              float x = v[q];
-              if (rp) x += a.beta * ldf<BF16>(rp + q);
-              if (mp && co0 + q < a.mask_c1) x *= ldf<BF16>(mp + q) > 0.f ? 1.f : a.mask_slope;
-              stf<BF16>(o + q, x);
-            }
+      for (int q = 0; q < 4; ++q) {
+        if (co0 + q >= a.Cout) continue;
+        float x = v[q];
+        if (a.out_planar) {
+          reinterpret_cast<float*>(a.out)[((long)b * a.Cout + co0 + q) * vox_per_b + vi] = x;
+        } else {
+          if (a.res) x += a.beta * ldf<BF16>(a.res + mrow[i] * a.res_ctot + a.res_off + co0 + q);
+          if constexpr (MASK) {
+            if (co0 + q >= a.mask_c0 && co0 + q < a.mask_c1)
+              x *= ldf<BF16>(a.mask_y + mrow[i] * a.mask_ctot + a.mask_off + (co0 + q - a.mask_c0)) > 0.f
+                       ? 1.f : a.mask_slope;
+          }
+          stf<BF16>(reinterpret_cast<unsigned short*>(a.out) + mrow[i] * a.out_ctot + a.out_off + co0 + q, x);
         }
       }
     }
   }
+  CT_STAMP(5);
+  CT_STAMP(7);
 }
 
 static inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
@@ -397,24 +442,22 @@ int launch_ct(CtArgs& a, hipStream_t st) {
   a.P = VM ? round_up(L * 32, 1024) : round_up(L * 16, 1024);  // whole 1 KB DMA units; == 0 (mod 256)
   a.off_mtab = 0;
   a.off_htab = M * 4;
-  a.off_vtab = round_up(a.off_htab + M * 2, 16);
-  a.off_ttab = a.off_vtab + L * 4;
+  a.off_ttab = round_up(a.off_htab + M * 2, 16);
   a.off_xs = round_up(a.off_ttab + a.nts * TPK * 4, 1024);
   // two activation buffers when that still leaves room for weight stages of >= 2 K-steps
   int ts_max = 0;
-  for (a.xbufs = 2; a.xbufs >= 1; --a.xbufs) {
+  const int xb_first = getenv("WSR_CT_XBUFS") ? atoi(getenv("WSR_CT_XBUFS")) : 2;  // tuning aid
+  for (a.xbufs = xb_first; a.xbufs >= 1; --a.xbufs) {
     a.off_ws = a.off_xs + a.xbufs * (VM ? 1 : PL) * a.P;
     const int avail = 160 * 1024 - a.off_ws;
     ts_max = avail / (2 * NTW * 1024);
     const int cap_kb = getenv("WSR_WSTAGE_KB") ? atoi(getenv("WSR_WSTAGE_KB")) : 48;  // tuning aid
     const int cap = cap_kb / NTW > 0 ? cap_kb / NTW : 1;  // <= 48 KB per weight stage (measured: up-convs +7 %, others flat)
     if (ts_max > cap) ts_max = cap;
-    if (ts_max >= 2 || (ts_max >= 1 && a.nts == 1)) break;
+    // (weight stages shorter than 3 K-steps cost more in barriers than the activation prefetch saves)
+    if (ts_max >= 3 || ts_max >= a.nts || a.xbufs == 1) break;
   }
-  if (a.xbufs < 1) {
-    a.xbufs = 1;
-    if (ts_max < 1) return WSR_EUNSUPPORTED;
-  }
+  if (ts_max < 1) return WSR_EUNSUPPORTED;
   if ((VM ? (L + 31) / 32 : ((L + 63) / 64) * PL) > 10 * WAVES) return WSR_EUNSUPPORTED;  // XK units per wave
   if ((long)a.B * a.Xi * a.Yi * a.Zi * a.in_ctot >= 0xFFFFFFFFL) return WSR_EUNSUPPORTED;  // 32-bit element offsets
   const int nph = (a.nts + ts_max - 1) / ts_max;
@@ -425,6 +468,18 @@ int launch_ct(CtArgs& a, hipStream_t st) {
   a.tiles_y = (a.Yo + a.TY - 1) / a.TY;
   a.tiles_z = (a.Zo + a.TZ - 1) / a.TZ;
   a.ntiles = a.B * a.tiles_x * a.tiles_y * a.tiles_z;
+  {  // fdiv operand range: n * d < 2^32 for the workgroup-index decode (the table divisions have n < 65536)
+    int dmax = a.ngroups;
+    if (a.tiles_z > dmax) dmax = a.tiles_z;
+    if (a.tiles_y > dmax) dmax = a.tiles_y;
+    if (a.tiles_x > dmax) dmax = a.tiles_x;
+    if ((long)a.ntiles * a.ngroups * dmax >= (1l << 32)) return WSR_EUNSUPPORTED;
+  }
+  a.mg_TZ = fdiv_magic(a.TZ); a.mg_TY = fdiv_magic(a.TY);
+  a.mg_Lz = fdiv_magic(a.TZ + a.KZ - 1); a.mg_Ly = fdiv_magic(a.TY + a.KY - 1);
+  a.mg_KZ = fdiv_magic(a.KZ); a.mg_KY = fdiv_magic(a.KY);
+  a.mg_ng = fdiv_magic(a.ngroups); a.mg_tz = fdiv_magic(a.tiles_z);
+  a.mg_ty = fdiv_magic(a.tiles_y); a.mg_tx = fdiv_magic(a.tiles_x);
   constexpr bool PIPE = TN <= 7;  // register budget: (TM+TN)*8 fragment + TM*TN*4 accumulator VGPRs
   if (a.mask_y && !MASK) return WSR_EUNSUPPORTED;
   auto kern = conv_tile_kernel<WM, WN, TM, TN, TPK, PIPE, MASK>;
@@ -435,6 +490,9 @@ int launch_ct(CtArgs& a, hipStream_t st) {
     if (e != hipSuccess) return (int)e;
     attr_done = true;
   }
+#ifdef WSR_CT_STAMPS
+  a.stamps = getenv("WSR_CT_STAMPS_PTR") ? (unsigned long long*)strtoull(getenv("WSR_CT_STAMPS_PTR"), nullptr, 0) : nullptr;
+#endif
   hipLaunchKernelGGL(kern, dim3((unsigned)(a.ntiles * a.ngroups)), dim3(WAVES * 64), lds, st, a);
   WSR_LAUNCH_CHECK();
   return 0;
