@@ -29,6 +29,7 @@
 #include "conv_tile_impl.h"
 
 int wsr_ct_run_n144(CtArgs& a, int tpk, hipStream_t st);    // conv_tile_n144.hip
+int wsr_ct_run_n128(CtArgs& a, int tpk, hipStream_t st);    // conv_tile_n128.hip
 int wsr_ct_run_narrow(CtArgs& a, int tpk, hipStream_t st);  // conv_tile_narrow.hip
 int wsr_ct_run_wide(CtArgs& a, int tpk, hipStream_t st);    // conv_tile_wide.hip
 int wsr_ct_run_masked(CtArgs& a, int tpk, hipStream_t st);  // conv_tile_masked.hip
@@ -40,7 +41,11 @@ int dispatch_ct(CtArgs& a, int tpk, hipStream_t st) {
   const int N = a.Cout;
   if (a.mask_y) return N <= 64 ? wsr_ct_run_narrow_masked(a, tpk, st) : wsr_ct_run_masked(a, tpk, st);
   if (N <= 64) return wsr_ct_run_narrow(a, tpk, st);
-  if (N == 144 || (N > 64 && N < 144 && getenv("WSR_CT_BIG"))) return wsr_ct_run_n144(a, tpk, st);
+  if (N == 144) return wsr_ct_run_n144(a, tpk, st);
+  if (N > 64 && N <= 128 && !getenv("WSR_CT_NO_N128")) {  // (the env switch is a tuning aid)
+    const int rc = wsr_ct_run_n128(a, tpk, st);
+    if (rc != WSR_EUNSUPPORTED) return rc;
+  }
   if (N <= 256) return wsr_ct_run_wide(a, tpk, st);
   return WSR_EUNSUPPORTED;
 }

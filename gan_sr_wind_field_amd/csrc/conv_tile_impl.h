@@ -62,6 +62,7 @@ struct CtArgs {
   int xbufs;        // activation buffers in LDS: 2 = next chunk prefetched during the MFMAs
   // ceil(2^32 / d) for the runtime divisors of the prologue (fdiv): tile / halo / tap extents, tile counts
   unsigned mg_TZ, mg_TY, mg_Lz, mg_Ly, mg_KZ, mg_KY, mg_ng, mg_tz, mg_ty, mg_tx;
+  int ablate;  // -DWSR_CT_STAMPS builds, timing only: skip 1 = activation prefetch, 2 = weight prefetch, 4 = LDS reads, 8 = MFMAs
   unsigned long long* stamps;  // -DWSR_CT_STAMPS builds: [workgroup][8] clock samples of wave 0 (else unused)
 };
 
@@ -177,7 +178,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_tile_kernel(const CtArgs a)
   // (u = wave + WAVES*k) once: element offset of the lane's voxel (or OOB), octet plane, LDS offset.
   constexpr int XK = 10;  // max units per wave per chunk (checked on the host)
   unsigned xoff[XK];
-  int xo8[XK], xdst[XK];
+  int xo8[VM ? 1 : XK], xdst[VM ? 1 : XK];  // voxel-major rows: octet = lane & 1, unit u lands at u KB
 #pragma unroll
   for (int k = 0; k < XK; ++k) {
     const int u = wave + WAVES * k;
@@ -188,7 +189,6 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_tile_kernel(const CtArgs a)
       if constexpr (VM) {
         pl = lane & 1;
         v = u * 32 + (lane >> 1);
-        dsto = u * 1024;
       } else {
         pl = u / UPP;
         v = (u - pl * UPP) * 64 + lane;
@@ -205,9 +205,12 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_tile_kernel(const CtArgs a)
       }
     }
     xoff[k] = off;
-    xo8[k] = 8 * pl;
-    xdst[k] = __builtin_amdgcn_readfirstlane(dsto);
+    if constexpr (!VM) {
+      xo8[k] = 8 * pl;
+      xdst[k] = __builtin_amdgcn_readfirstlane(dsto);
+    }
   }
+  if constexpr (VM) { xo8[0] = 8 * (lane & 1); xdst[0] = 0; }
   // units [u0, u1) of the activation chunk (with halo) -> Xs[buf]; out-of-range voxels read the zero page
   auto x_issue = [&](int chunk, int buf, int u0, int u1) {
     const unsigned dst = xs_lds + buf * xs_bytes;
@@ -215,10 +218,10 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_tile_kernel(const CtArgs a)
     for (int k = 0; k < XK; ++k) {
       const int u = wave + WAVES * k;
       if (u >= u0 && u < u1) {
-        const bool ok = xoff[k] != 0xFFFFFFFFu && chunk * CK + xo8[k] < a.cin_valid;
+        const bool ok = xoff[k] != 0xFFFFFFFFu && chunk * CK + xo8[VM ? 0 : k] < a.cin_valid;
         const unsigned short* src = ok ? a.in + (size_t)xoff[k] + chunk * CK
                                        : reinterpret_cast<const unsigned short*>(a.zero16);
-        glds16(src, dst + xdst[k]);
+        glds16(src, dst + (VM ? u * 1024 : xdst[VM ? 0 : k]));
       }
     }
   };
@@ -255,6 +258,9 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_tile_kernel(const CtArgs a)
 #pragma unroll
     for (int j = 0; j < TN; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
+#ifdef WSR_CT_STAMPS
+  long long st_dma = 0, st_bar = 0;  // shader cycles this wave spent waiting for its DMAs / at the phase barrier
+#endif
   const int total_phases = a.nchunks * nstages;
   int chunk = 0, st = 0;
   for (int ph = 0; ph < total_phases; ++ph) {
@@ -268,10 +274,17 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_tile_kernel(const CtArgs a)
       __syncthreads();
     }
     auto burst = [&]() {
+#ifdef WSR_CT_STAMPS
+      if (a.ablate & 2) goto skip_w;
+#endif
       if (ph + 1 < total_phases) {
         const bool wrap = st + 1 == nstages;
         w_issue(wrap ? chunk + 1 : chunk, wrap ? 0 : st + 1, (ph + 1) & 1);
       }
+#ifdef WSR_CT_STAMPS
+    skip_w:
+      if (a.ablate & 1) return;
+#endif
       if (a.xbufs == 2 && chunk + 1 < a.nchunks)
         x_issue(chunk + 1, (chunk + 1) & 1, (HU * st) / nstages, (HU * (st + 1)) / nstages);
     };
@@ -281,6 +294,9 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_tile_kernel(const CtArgs a)
     const int ts_end = min(a.TS, a.nts - st * a.TS);
     const int* tt = ttab + st * a.TS * TPK + lane_tsub;
     auto load_frags = [&](int tsi, uint4 (&wf)[TN], uint4 (&xf)[TM]) {
+#ifdef WSR_CT_STAMPS
+      if (a.ablate & 4) return;
+#endif
       const int toff = tt[tsi * TPK] * RB;
 #pragma unroll
       for (int j = 0; j < TN; ++j) wf[j] = *reinterpret_cast<const uint4*>(wcur + (tsi * NTW + j) * 1024);
@@ -288,6 +304,9 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_tile_kernel(const CtArgs a)
       for (int i = 0; i < TM; ++i) xf[i] = *reinterpret_cast<const uint4*>(xcur + hb[i] + toff);
     };
     auto mma_frags = [&](const uint4 (&wf)[TN], const uint4 (&xf)[TM]) {
+#ifdef WSR_CT_STAMPS
+      if (a.ablate & 8) return;
+#endif
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -320,8 +339,18 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_tile_kernel(const CtArgs a)
     run_ksteps(0, mid);
     if (mid > 0) burst();
     run_ksteps(mid, ts_end);
+#ifdef WSR_CT_STAMPS
+    const long long tw0 = clock64();
+#endif
     dma_wait();  // this wave's prefetches have landed ...
+#ifdef WSR_CT_STAMPS
+    const long long tw1 = clock64();
+#endif
     __syncthreads();  // ... and so have everybody else's; the buffers just read are free again
+#ifdef WSR_CT_STAMPS
+    st_dma += tw1 - tw0;
+    st_bar += clock64() - tw1;
+#endif
     if (++st == nstages) { st = 0; ++chunk; }
   }
 
@@ -422,6 +451,14 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_tile_kernel(const CtArgs a)
   }
   CT_STAMP(5);
   CT_STAMP(7);
+#ifdef WSR_CT_STAMPS
+  if (a.stamps && lane == 0 && (wave == 0 || wave == WAVES - 1)) {  // rows [grid + 2*wg + {0,1}]: first / last wave
+    unsigned long long* p = a.stamps + ((size_t)gridDim.x + 2 * blockIdx.x + (wave ? 1 : 0)) * 8;
+    p[0] = (unsigned long long)st_dma;
+    p[1] = (unsigned long long)st_bar;
+    p[2] = (unsigned long long)total_phases;
+  }
+#endif
 }
 
 static inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
@@ -491,6 +528,7 @@ int launch_ct(CtArgs& a, hipStream_t st) {
     attr_done = true;
   }
 #ifdef WSR_CT_STAMPS
+  a.ablate = getenv("WSR_CT_ABL") ? atoi(getenv("WSR_CT_ABL")) : 0;
   a.stamps = getenv("WSR_CT_STAMPS_PTR") ? (unsigned long long*)strtoull(getenv("WSR_CT_STAMPS_PTR"), nullptr, 0) : nullptr;
 #endif
   hipLaunchKernelGGL(kern, dim3((unsigned)(a.ntiles * a.ngroups)), dim3(WAVES * 64), lds, st, a);

@@ -8,7 +8,7 @@ template <int TPK>
 static int run(CtArgs& a, hipStream_t st) {
   const int N = a.Cout;
   (void)N;
-  if (!a.mask_y && N > 64 && N <= 144) { pick_tile(a, 512); return launch_ct<8, 1, 4, 9, TPK>(a, st); }
+  if (!a.mask_y && N == 144) { pick_tile(a, 512); return launch_ct<8, 1, 4, 9, TPK>(a, st); }
   return WSR_EUNSUPPORTED;
 }
 
