@@ -55,6 +55,8 @@ struct WgtArgs {
   int xs_bytes, buf_bytes;     // Xs image size (CT planes), Xs + Ys size (per buffer)
   int off_buf;                 // LDS carve (bytes); htab sits at 0
   int tri_base, tri_step;
+  unsigned long long* stamps;  // -DWSR_CT_STAMPS builds: [workgroup][8] clock samples (else unused)
+  int ablate;                  // -DWSR_CT_STAMPS builds, timing only: skip 1 = tile DMA, 4 = LDS reads, 8 = MFMAs
 };
 
 __device__ __forceinline__ uint4 tr_frag(const char* lo, const char* hi) {
@@ -78,6 +80,15 @@ __device__ __forceinline__ void dma_wait() { asm volatile("s_waitcnt vmcnt(0)" :
 
 // 32-byte block swizzle of the dy image: 8 consecutive voxels x one n-tile -> 8 distinct 32-byte bank slots
 // (128-byte rows, TN <= 4: two voxels per 256-byte bank row; 256-byte rows, TN = 8: one)
+#ifdef WSR_CT_STAMPS
+#define WG_STAMP(k)                                                                                    \
+  do {                                                                                                 \
+    if (a.stamps && threadIdx.x == 0) a.stamps[(size_t)blockIdx.x * 8 + (k)] = (k) >= 6 ? clock64() : wall_clock64(); \
+  } while (0)
+#else
+#define WG_STAMP(k) do {} while (0)
+#endif
+
 template <int TN> __device__ __forceinline__ int ysw(int v) { return TN <= 4 ? (v >> 1) & 3 : v & 7; }
 
 template <int TN, int SPW, int CT>
@@ -91,6 +102,8 @@ __global__ __launch_bounds__(512) void wgrad_tile_kernel(const WgtArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int t = threadIdx.x, lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  WG_STAMP(0);
+  WG_STAMP(6);
 
   const int Ly = a.TY + a.KY - 1, Lz = a.TZ + a.KZ - 1, Lx = a.TX + a.KX - 1;
   const int L = Lx * Ly * Lz;
@@ -242,42 +255,128 @@ __global__ __launch_bounds__(512) void wgrad_tile_kernel(const WgtArgs a) {
   const int G = lane >> 4, q = (lane & 15) >> 2, p = lane & 3;
   const int ksteps = M >> 5;
 
+  WG_STAMP(1);
+#ifdef WSR_CT_STAMPS
+  long long st_bar = 0;
+  int st_tiles = 0;
+#endif
+  // Operand pipeline of the contraction.  One slot is only TN MFMAs (64..128 matrix-pipe cycles) and an LDS
+  // round trip is longer than that, so nothing may be requested right before it is used: the x fragment of
+  // slot j+D and, one per slot, the dy fragments of the NEXT K-step are requested before the MFMAs of slot j
+  // (ring of R registers sets, R | SPW so that every K-step starts at ring slot 0; the scheduler is fenced
+  // because it otherwise sinks the requests back to their uses).  The last K-step of a tile prefetches a
+  // dummy (itself) instead of branching: uniform branches would cost the counted waits.
+  // (accumulator-heavy instantiations - the 5x5x5 kernels with 3 n-tiles - have no registers left for a
+  // second dy set and a ring: they fetch per slot, LEAN)
+  constexpr bool LEAN = SPW * TN * 4 >= 192;
+  constexpr int R = SPW % 7 == 0 ? 7 : (SPW % 4 == 0 ? 4 : 1);
+  constexpr int D = R > 3 ? 3 : R - 1;
+  struct KP { const char *xlo, *xhi, *rlo, *rhi; int slo, shi; };
+  auto kp_of = [&](const char* Xs, const char* Ys, int ks) {
+    const int m_lo = ks * 32 + 4 * G + q, m_hi = m_lo + 16;
+    KP k;
+    k.xlo = Xs + (int)htab[m_lo] * 32 + p * 8;
+    k.xhi = Xs + (int)htab[m_hi] * 32 + p * 8;
+    k.rlo = Ys + m_lo * RBY + p * 8;
+    k.rhi = Ys + m_hi * RBY + p * 8;
+    k.slo = ysw<TN>(m_lo);
+    k.shi = ysw<TN>(m_hi);
+    return k;
+  };
+#ifdef WSR_CT_STAMPS
+  const uint4 abl_frag = make_uint4(lane, 1u, 2u, 3u);
+  auto af_of = [&](const KP& k, int i) { return (a.ablate & 4) ? abl_frag : tr_frag(k.rlo + ((i ^ k.slo) << 5), k.rhi + ((i ^ k.shi) << 5)); };
+  auto bf_of = [&](const KP& k, int j) { return (a.ablate & 4) ? abl_frag : tr_frag(k.xlo + soff[j], k.xhi + soff[j]); };
+#else
+  auto af_of = [&](const KP& k, int i) { return tr_frag(k.rlo + ((i ^ k.slo) << 5), k.rhi + ((i ^ k.shi) << 5)); };
+  auto bf_of = [&](const KP& k, int j) { return tr_frag(k.xlo + soff[j], k.xhi + soff[j]); };
+#endif
+
   // Software pipeline over the tile list: iteration `it` prefetches tile s0 + it*S into buffer it&1 while
   // tile s0 + (it-1)*S is contracted out of the other buffer (one DMA call site, one MFMA call site).
   for (int it = 0;; ++it) {
     const int pre = s0 + it * a.S;
+#ifdef WSR_CT_STAMPS
+    if (pre < a.ntiles && !((a.ablate & 1) && it > 0)) issue_tile(pre, it & 1);
+#else
     if (pre < a.ntiles) issue_tile(pre, it & 1);
+#endif
     if (it > 0) {
       const char* Xs = buf0 + ((it - 1) & 1) * a.buf_bytes;
       const char* Ys = Xs + a.xs_bytes;
-      for (int ks = 0; ks < ksteps; ++ks) {
-        const int m_lo = ks * 32 + 4 * G + q, m_hi = m_lo + 16;
-        const char* xlo = Xs + (int)htab[m_lo] * 32 + p * 8;
-        const char* xhi = Xs + (int)htab[m_hi] * 32 + p * 8;
-        uint4 af[TN];
-        {
-          const char* rlo = Ys + m_lo * RBY + p * 8;
-          const char* rhi = Ys + m_hi * RBY + p * 8;
-          const int slo = ysw<TN>(m_lo), shi = ysw<TN>(m_hi);
+      if constexpr (LEAN) {
+        for (int ks = 0; ks < ksteps; ++ks) {
+          const KP k = kp_of(Xs, Ys, ks);
+          uint4 af[TN];
 #pragma unroll
-          for (int i = 0; i < TN; ++i) af[i] = tr_frag(rlo + ((i ^ slo) << 5), rhi + ((i ^ shi) << 5));
+          for (int i = 0; i < TN; ++i) af[i] = af_of(k, i);
+#pragma unroll
+          for (int j = 0; j < SPW; ++j) {
+            const uint4 bf = bf_of(k, j);
+#pragma unroll
+            for (int i = 0; i < TN; ++i)
+              acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, af[i]),
+                                                                  __builtin_bit_cast(bf16x8_t, bf), acc[j][i], 0, 0, 0);
+          }
         }
-        // branch-free over slots and n-tiles: a slot past the end re-reads tap 0 into accumulators that are
-        // never flushed, an n-tile the triangular structure does not need is computed and dropped at the flush
+      } else {
+      KP kc = kp_of(Xs, Ys, 0);
+      uint4 afA[TN], afB[TN], ring[R], nb;
+#pragma unroll
+      for (int i = 0; i < TN; ++i) afA[i] = af_of(kc, i);
+#pragma unroll
+      for (int d = 0; d < (R > 1 ? D : 1); ++d) ring[d] = bf_of(kc, d);
+      // one K-step: consumes afc, requests afn (the next K-step's dy fragments)
+      auto step = [&](int ks, uint4 (&afc)[TN], uint4 (&afn)[TN]) {
+        const KP kn = kp_of(Xs, Ys, ks + 1 < ksteps ? ks + 1 : ks);
+        if constexpr (R == 1) nb = bf_of(kn, 0);
+
 #pragma unroll
         for (int j = 0; j < SPW; ++j) {
-          const uint4 bf = tr_frag(xlo + soff[j], xhi + soff[j]);
+          if constexpr (R > 1) {
+            const int f = j + D;
+            if (f < SPW) ring[f % R] = bf_of(kc, f);
+            else ring[f % R] = bf_of(kn, f - SPW);
+          }
+          if (j < TN) afn[j] = af_of(kn, j);
+          __builtin_amdgcn_sched_barrier(0);
+          // branch-free over slots and n-tiles: a slot past the end re-reads tap 0 into accumulators that are
+          // never flushed, an n-tile the triangular structure does not need is computed and dropped at the flush
+#ifdef WSR_CT_STAMPS
+          if (a.ablate & 8) continue;
+#endif
 #pragma unroll
           for (int i = 0; i < TN; ++i)
-            acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, af[i]),
-                                                                __builtin_bit_cast(bf16x8_t, bf), acc[j][i], 0, 0, 0);
+            acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, afc[i]),
+                                                                __builtin_bit_cast(bf16x8_t, ring[j % R]), acc[j][i], 0, 0,
+                                                                0);
+          __builtin_amdgcn_sched_barrier(0);
         }
+        if constexpr (SPW < TN) {  // (1x1x1 kernels: more n-tiles than slots)
+#pragma unroll
+          for (int i = SPW; i < TN; ++i) afn[i] = af_of(kn, i);
+        }
+        if constexpr (R == 1) ring[0] = nb;
+        kc = kn;
+      };
+      for (int ks = 0; ks < ksteps; ks += 2) {
+        step(ks, afA, afB);
+        if (ks + 1 < ksteps) step(ks + 1, afB, afA);
+      }
       }
     }
+#ifdef WSR_CT_STAMPS
+    const long long tw0 = clock64();
+#endif
     dma_wait();
     __syncthreads();  // the prefetched tile has landed for everybody; the buffer just read is free again
+#ifdef WSR_CT_STAMPS
+    st_bar += clock64() - tw0;
+    ++st_tiles;
+#endif
     if (pre >= a.ntiles) break;
   }
+  WG_STAMP(2);
 
   // ---- add this workgroup's partial sums: acc[j][i][r] -> n = n0+16i+4G+r, c = c0+16ct+(lane&15)
 #pragma unroll
@@ -297,6 +396,14 @@ __global__ __launch_bounds__(512) void wgrad_tile_kernel(const WgtArgs a) {
       }
     }
   }
+  WG_STAMP(3);
+  WG_STAMP(7);
+#ifdef WSR_CT_STAMPS
+  if (a.stamps && threadIdx.x == 0) {
+    a.stamps[(size_t)blockIdx.x * 8 + 4] = (unsigned long long)st_bar;
+    a.stamps[(size_t)blockIdx.x * 8 + 5] = (unsigned long long)st_tiles;
+  }
+#endif
 }
 
 static inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
@@ -372,6 +479,10 @@ int launch_tile(WgtArgs& a, hipStream_t st) {
     if (e != hipSuccess) return (int)e;
     attr_done = true;
   }
+#ifdef WSR_CT_STAMPS
+  a.stamps = getenv("WSR_CT_STAMPS_PTR") ? (unsigned long long*)strtoull(getenv("WSR_CT_STAMPS_PTR"), nullptr, 0) : nullptr;
+  a.ablate = getenv("WSR_CT_ABL") ? atoi(getenv("WSR_CT_ABL")) : 0;
+#endif
   hipLaunchKernelGGL(kern, dim3((unsigned)(combos * a.S)), dim3(WAVES * 64), lds, st, a);
   WSR_LAUNCH_CHECK();
   return 0;

@@ -301,6 +301,37 @@ __global__ void adam_kernel(float* p, const float* __restrict__ g, float* m, flo
   }
 }
 
+
+// per-channel sum over voxels of an NDHWC window: thread = (voxel lane, 4-channel group); partial sums are
+// combined in LDS and added to out[] with one float atomic per channel and workgroup
+template <class T>
+__global__ __launch_bounds__(256) void chan_sum_kernel(const typename T::elem* __restrict__ x, int ctot, int off, int C,
+                                                      long nvox, float scale, float* __restrict__ out) {
+  __shared__ float4 part[256];
+  const int groups = C >> 2;              // 4-channel groups (<= 256)
+  const int lanes = 256 / groups;         // voxel lanes per workgroup
+  const int g = threadIdx.x % groups, vl = threadIdx.x / groups;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (vl < lanes) {
+    for (long v = (long)blockIdx.x * lanes + vl; v < nvox; v += (long)gridDim.x * lanes) {
+      const float4 a = ld4<T>(x + v * ctot + off + 4 * g);
+      acc.x += a.x; acc.y += a.y; acc.z += a.z; acc.w += a.w;
+    }
+  }
+  part[threadIdx.x] = acc;
+  __syncthreads();
+  if (vl == 0) {
+    for (int l = 1; l < lanes; ++l) {
+      const float4 a = part[l * groups + g];
+      acc.x += a.x; acc.y += a.y; acc.z += a.z; acc.w += a.w;
+    }
+    atomicAdd(out + 4 * g + 0, acc.x * scale);
+    atomicAdd(out + 4 * g + 1, acc.y * scale);
+    atomicAdd(out + 4 * g + 2, acc.z * scale);
+    atomicAdd(out + 4 * g + 3, acc.w * scale);
+  }
+}
+
 }  // namespace
 
 #define DISPATCH_T(dtype, CALL_BF16, CALL_F32) \
@@ -526,6 +557,25 @@ extern "C" int wsr_adam_step(float* p, const float* g, float* m, float* v, int64
   const double bc2 = 1.0 - pow((double)beta2, (double)step);
   hipLaunchKernelGGL(adam_kernel, dim3(ew_grid(n)), dim3(EW_BLOCK), 0, as_stream(stream), p, g, m, v, (long)n,
                      (float)(lr / bc1), beta1, beta2, eps, weight_decay, (float)sqrt(bc2));
+  WSR_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int wsr_chan_sum(const void* x, int32_t x_ctot, int32_t x_off, int32_t C, int64_t nvox, float scale,
+                            float* out, int32_t dtype, void* stream) {
+  if (!x || !out || C <= 0 || nvox <= 0 || x_off < 0 || x_off + C > x_ctot) return WSR_EINVAL;
+  if (C % 4 || C > 1024 || x_ctot % 4 || x_off % 4) return WSR_EUNSUPPORTED;
+  hipError_t e = hipMemsetAsync(out, 0, sizeof(float) * C, as_stream(stream));
+  if (e != hipSuccess) return (int)e;
+  const int groups = C / 4, lanes = 256 / groups;
+  long grid = (nvox + (long)lanes * 64 - 1) / ((long)lanes * 64);  // >= 64 voxels per thread
+  if (grid > 1024) grid = 1024;
+  if (grid < 1) grid = 1;
+  DISPATCH_T(dtype,
+             hipLaunchKernelGGL(chan_sum_kernel<BF16>, dim3((unsigned)grid), dim3(256), 0, as_stream(stream),
+                                (const unsigned short*)x, x_ctot, x_off, C, (long)nvox, scale, out),
+             hipLaunchKernelGGL(chan_sum_kernel<F32>, dim3((unsigned)grid), dim3(256), 0, as_stream(stream),
+                                (const float*)x, x_ctot, x_off, C, (long)nvox, scale, out));
   WSR_LAUNCH_CHECK();
   return 0;
 }

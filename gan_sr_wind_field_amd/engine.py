@@ -657,7 +657,9 @@ class GeneratorProgram(ProgramBase):
                 buf = bufs[bi]
                 # LFF (1x1x1, bias): out = rdb_scale * (LFF(buf) + b) + x
                 self.wgrad(lff, buf, 0, go, 0, flat, sp, scratch, scale=rdb_scale)
-                sp.view(flat, lff.bias).copy_(go.float().sum(dim=(0, 1, 2, 3)) * rdb_scale)
+                gb = sp.view(flat, lff.bias)
+                if not ops.chan_sum(go, 0, nf, gb, scale=rdb_scale):
+                    gb.copy_(go.float().sum(dim=(0, 1, 2, 3)) * rdb_scale)
                 # gd[off_i : off_i+gc] is the gradient w.r.t. the LeakyReLU output of growth conv i; it is
                 # complete once the LFF and the later convs have added into it, so the kernel that makes the
                 # last contribution applies the LeakyReLU derivative in its epilogue (window i = nconv-1: the

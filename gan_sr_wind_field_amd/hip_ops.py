@@ -290,6 +290,20 @@ def chan_axpby(dst: Tensor, d_off: int, src: Tensor, s_off: int, C_: int, alpha:
                                     beta, dtype_id(dst.dtype), _stream()), "chan_axpby")
 
 
+def chan_sum(x: Tensor, x_off: int, C_: int, out: Tensor, scale: float = 1.0) -> bool:
+    """``out[c] = scale * sum_voxels x[..., x_off + c]`` (fp32, overwritten); False when the kernel does not
+    cover the shape (channel counts that are not multiples of 4)."""
+    _need_cuda(x, out)
+    if out.dtype != torch.float32 or not out.is_contiguous() or out.numel() != C_:
+        raise ValueError("chan_sum wants a contiguous fp32 output of C elements")
+    nvox = x.numel() // x.shape[-1]
+    rc = _lib.lib().wsr_chan_sum(_p(x), x.shape[-1], x_off, C_, nvox, scale, _p(out), dtype_id(x.dtype), _stream())
+    if rc == _lib.WSR_EUNSUPPORTED:
+        return False
+    check(rc, "chan_sum")
+    return True
+
+
 def upsample2_bwd(dy: Tensor, dx: Tensor) -> Tensor:
     B, X, Y, Z, C_ = dx.shape
     check(_lib.lib().wsr_upsample2_bwd(_p(dy), _p(dx), B, X, Y, Z, C_, dtype_id(dx.dtype), _stream()),

@@ -426,3 +426,18 @@ def test_conv_tile_shapes_vs_cpu(hip, name, cin, cout, k, xyz, B, ups):
     xg = xr.clone().requires_grad_(True)
     F.conv3d(xg, w, None, 1, p).backward(gy)
     assert rel_l2(from_ndhwc(dxb, 8, cin), xg.grad) < 4e-3, name
+
+
+@pytest.mark.parametrize("dt,C,ctot,off,nvox", [(torch.bfloat16, 128, 128, 0, 32 * 32 * 16), (torch.bfloat16, 32, 256, 96, 1000),
+                                               (torch.float32, 48, 64, 8, 777), (torch.float32, 4, 8, 4, 5)])
+def test_chan_sum_bias_gradient(hip, dt, C, ctot, off, nvox):
+    """LFF bias gradient (torch_blocks.py:278 backward): scaled per-channel sum of an NDHWC window, fp32 out"""
+    from gan_sr_wind_field_amd import hip_ops as o
+
+    g = torch.Generator(device="cuda:0").manual_seed(5)
+    x = torch.randn((1, nvox, 1, 1, ctot), device="cuda:0", generator=g).to(dt)
+    out = torch.full((C,), float("nan"), device="cuda:0")
+    assert o.chan_sum(x, off, C, out, scale=0.2)
+    want = 0.2 * x[..., off:off + C].double().sum(dim=(0, 1, 2, 3))
+    assert rel_l2(out, want.float()) < 1e-5
+    assert not o.chan_sum(x[..., :6].contiguous(), 0, 6, torch.empty(6, device="cuda:0"))  # C % 4: caller falls back
