@@ -55,6 +55,8 @@ struct WgtArgs {
   int xs_bytes, buf_bytes;     // Xs image size (CT planes), Xs + Ys size (per buffer)
   int off_buf;                 // LDS carve (bytes); htab sits at 0
   int tri_base, tri_step;
+  int n_active;                 // > 0: only these (n-chunk, c-chunk) pairs have work (block-triangular launches)
+  unsigned char act_nc[64], act_cc[64];
   unsigned long long* stamps;  // -DWSR_CT_STAMPS builds: [workgroup][8] clock samples (else unused)
   int ablate;                  // -DWSR_CT_STAMPS builds, timing only: skip 1 = tile DMA, 4 = LDS reads, 8 = MFMAs
 };
@@ -116,10 +118,18 @@ __global__ __launch_bounds__(512) void wgrad_tile_kernel(const WgtArgs a) {
 
   // ---- which chunk pair / spatial slice ------------------------------------------
   int bid = xcd_remap(blockIdx.x, gridDim.x);
-  const int cc = bid % a.c_chunks;
-  bid /= a.c_chunks;
-  const int nc = bid % a.n_chunks;
-  const int s0 = bid / a.n_chunks;
+  int cc, nc, s0;
+  if (a.n_active > 0) {  // pairs the triangular structure leaves empty are not launched at all
+    const int pr = bid % a.n_active;
+    s0 = bid / a.n_active;
+    cc = a.act_cc[pr];
+    nc = a.act_nc[pr];
+  } else {
+    cc = bid % a.c_chunks;
+    bid /= a.c_chunks;
+    nc = bid % a.n_chunks;
+    s0 = bid / a.n_chunks;
+  }
   const int c0 = cc * 16 * CT, n0 = nc * 16 * TN;
 
   // block-triangular structure: n-tile i is needed iff c0 < tri_base + tri_step*conv(n)
@@ -145,44 +155,56 @@ __global__ __launch_bounds__(512) void wgrad_tile_kernel(const WgtArgs a) {
   }
 
   // ---- DMA geometry of this lane, resolved once (tiles differ only in their origin) ------------
-  // geo = x | y<<8 | z<<16 | valid<<24 | (channel offset / 8)<<25 of what this lane fetches in unit k
+  // Per 1 KB unit k: geo = x | y<<8 | z<<16 | valid<<24 of the (halo) voxel this lane fetches, and rel = its
+  // element offset from the tile's first (halo) voxel, channel included.  Per tile only a scalar base, the
+  // add, and - for tiles that touch the volume border - three range checks remain.
+  const int U = a.ups ? 1 : 0;
+  const int parx = U ? ((-a.px) & 1) : 0, pary = U ? ((-a.py) & 1) : 0;  // parity of x0 - px (TX, TY even when up-sampled)
   const int XUP = (L + XRPU - 1) / XRPU;  // 1 KB units per c-tile plane of the x image
   const int XU = XUP * CT;
   const int YU = (M + YRPU - 1) / YRPU;   // ... of the dy image
   unsigned xgeo[XK], ygeo[YK];
+  int xrel[XK], yrel[YK];
 #pragma unroll
   for (int k = 0; k < XK; ++k) {
     const int u = wave + WAVES * k;
     unsigned geo = 0;
+    int rel = 0;
     if (u < XU) {
       const int ct = u / XUP;
       const int h = (u - ct * XUP) * XRPU + (lane >> 1);  // halo voxel = LDS row of plane ct
       const int ch8 = 2 * ct + (lane & 1);
-      if (h < L) {
-        const int hz = h % Lz, q = h / Lz;
-        const int hy = q % Ly, hx = q / Ly;
-        geo = hx | (hy << 8) | (hz << 16) | (1u << 24) | ((unsigned)ch8 << 25);
+      if (h < L && c0 + 8 * ch8 < a.Cin) {
+        const int hz = h % Lz, qq = h / Lz;
+        const int hy = qq % Ly, hx = qq / Ly;
+        geo = hx | (hy << 8) | (hz << 16) | (1u << 24);
+        rel = ((((hx + parx) >> U) * a.Yi + ((hy + pary) >> U)) * a.Zi + hz) * a.in_ctot + 8 * ch8;
       }
     }
     xgeo[k] = geo;
+    xrel[k] = rel;
   }
 #pragma unroll
   for (int k = 0; k < YK; ++k) {
     const int u = wave + WAVES * k;
     unsigned geo = 0;
+    int rel = 0;
     if (u < YU) {
-      const int v = u * YRPU + lane / (RBY / 16), s = lane % (RBY / 16);
-      const int b32 = (s >> 1) ^ ysw<TN>(v);
-      if (v < M && b32 < TN) {
-        const int oz = v % a.TZ, q = v / a.TZ;
-        const int oy = q % a.TY, ox = q / a.TY;
-        geo = ox | (oy << 8) | (oz << 16) | (1u << 24) | ((unsigned)(2 * b32 + (s & 1)) << 25);
+      const int v = u * YRPU + lane / (RBY / 16), sl = lane % (RBY / 16);
+      const int b32 = (sl >> 1) ^ ysw<TN>(v);
+      const int oct = 2 * b32 + (sl & 1);
+      // channel windows are whole octets here (the host routes anything else to the per-tap kernel)
+      if (v < M && b32 < TN && n0 + 8 * oct < a.Cout) {
+        const int oz = v % a.TZ, qq = v / a.TZ;
+        const int oy = qq % a.TY, ox = qq / a.TY;
+        geo = ox | (oy << 8) | (oz << 16) | (1u << 24);
+        rel = ((ox * a.Yo + oy) * a.Zo + oz) * a.out_ctot + 8 * oct;
       }
     }
     ygeo[k] = geo;
+    yrel[k] = rel;
   }
 
-  const int U = a.ups ? 1 : 0;
   const unsigned short* zsrc = reinterpret_cast<const unsigned short*>(a.zero16);
   auto issue_tile = [&](int tile, int buf) {
     int r = tile;
@@ -193,37 +215,42 @@ __global__ __launch_bounds__(512) void wgrad_tile_kernel(const WgtArgs a) {
     const int x0 = tx * a.TX, y0 = ty * a.TY, z0 = tz * a.TZ;
     const unsigned dstx = buf_lds + buf * a.buf_bytes;
     const unsigned dsty = dstx + a.xs_bytes;
+    {  // x image with halo: halo voxel h sits at (x0 - px + hx, ...) of the (up-sampled) input
+      const int lox = a.px - x0, loy = a.py - y0, loz = a.pz - z0;  // first in-range halo coordinate
+      const int sx_ = a.Xi << U, sy_ = a.Yi << U;
+      const bool inner = lox <= 0 && Lx - lox <= sx_ && loy <= 0 && Ly - loy <= sy_ && loz <= 0 && Lz - loz <= a.Zi;
+      const long base = ((((long)b * a.Xi + ((x0 - a.px - parx) >> U)) * a.Yi + ((y0 - a.py - pary) >> U)) * a.Zi +
+                         (z0 - a.pz)) * a.in_ctot + a.in_off + c0;
+      const unsigned short* bp = a.x + base;
 #pragma unroll
-    for (int k = 0; k < XK; ++k) {
-      const int u = wave + WAVES * k;
-      if (u < XU) {
-        const unsigned geo = xgeo[k];
-        const int gx = x0 - a.px + (int)(geo & 255), gy = y0 - a.py + (int)((geo >> 8) & 255),
-                  gz = z0 - a.pz + (int)((geo >> 16) & 255);
-        const unsigned short* src = zsrc;
-        const int c = c0 + 8 * (int)(geo >> 25);
-        if (((geo >> 24) & 1) && (unsigned)gx < (unsigned)(a.Xi << U) && (unsigned)gy < (unsigned)(a.Yi << U) &&
-            (unsigned)gz < (unsigned)a.Zi && c < a.Cin) {
-          const long vox = (((long)b * a.Xi + (gx >> U)) * a.Yi + (gy >> U)) * a.Zi + gz;
-          src = a.x + vox * a.in_ctot + a.in_off + c;
+      for (int k = 0; k < XK; ++k) {
+        const int u = wave + WAVES * k;
+        if (u < XU) {
+          const unsigned geo = xgeo[k];
+          bool ok = (geo >> 24) & 1;
+          if (!inner)
+            ok = ok && (unsigned)((int)(geo & 255) - lox) < (unsigned)sx_ &&
+                 (unsigned)((int)((geo >> 8) & 255) - loy) < (unsigned)sy_ &&
+                 (unsigned)((int)((geo >> 16) & 255) - loz) < (unsigned)a.Zi;
+          glds16(ok ? bp + xrel[k] : zsrc, __builtin_amdgcn_readfirstlane(dstx + u * 1024));
         }
-        glds16(src, __builtin_amdgcn_readfirstlane(dstx + u * 1024));
       }
     }
+    {  // dy image: tile voxels only
+      const int hix = a.Xo - x0, hiy = a.Yo - y0, hiz = a.Zo - z0;
+      const bool inner = a.TX <= hix && a.TY <= hiy && a.TZ <= hiz;
+      const long base = ((((long)b * a.Xo + x0) * a.Yo + y0) * a.Zo + z0) * a.out_ctot + a.out_off + n0;
+      const unsigned short* bp = a.dy + base;
 #pragma unroll
-    for (int k = 0; k < YK; ++k) {
-      const int u = wave + WAVES * k;
-      if (u < YU) {
-        const unsigned geo = ygeo[k];
-        const int gx = x0 + (int)(geo & 255), gy = y0 + (int)((geo >> 8) & 255), gz = z0 + (int)((geo >> 16) & 255);
-        const unsigned short* src = zsrc;
-        const int n = n0 + 8 * (int)(geo >> 25);
-        // channel windows are whole octets here (the host routes anything else to the per-tap kernel)
-        if (((geo >> 24) & 1) && gx < a.Xo && gy < a.Yo && gz < a.Zo && n < a.Cout) {
-          const long vox = (((long)b * a.Xo + gx) * a.Yo + gy) * a.Zo + gz;
-          src = a.dy + vox * a.out_ctot + a.out_off + n;
+      for (int k = 0; k < YK; ++k) {
+        const int u = wave + WAVES * k;
+        if (u < YU) {
+          const unsigned geo = ygeo[k];
+          bool ok = (geo >> 24) & 1;
+          if (!inner)
+            ok = ok && (int)(geo & 255) < hix && (int)((geo >> 8) & 255) < hiy && (int)((geo >> 16) & 255) < hiz;
+          glds16(ok ? bp + yrel[k] : zsrc, __builtin_amdgcn_readfirstlane(dsty + u * 1024));
         }
-        glds16(src, __builtin_amdgcn_readfirstlane(dsty + u * 1024));
       }
     }
   };
@@ -433,6 +460,7 @@ int launch_tile(WgtArgs& a, hipStream_t st) {
       const int tx = cand[ci][0], ty = cand[ci][1];
       const int M = tx * ty * tz;
       if (M & 31) continue;
+      if (a.ups && ((tx | ty) & 1)) continue;  // the x0 - px parity must not depend on the tile
       const int L = (tx + a.KX - 1) * (ty + a.KY - 1) * (tz + a.KZ - 1);
       const int xs = CT * round_up(L * 32, 1024), ys = round_up(M * (TN <= 4 ? 128 : 256), 1024);
       if (xs / 1024 > 6 * WAVES || ys / 1024 > 5 * WAVES || L > 65535) continue;
@@ -458,7 +486,27 @@ int launch_tile(WgtArgs& a, hipStream_t st) {
   a.tiles_y = (a.Yo + a.TY - 1) / a.TY;
   a.tiles_z = (a.Zo + a.TZ - 1) / a.TZ;
   a.ntiles = a.B * a.tiles_x * a.tiles_y * a.tiles_z;
-  const int combos = a.n_chunks * a.c_chunks;
+  int combos = a.n_chunks * a.c_chunks;
+  a.n_active = 0;
+  if (a.tri_step > 0 && combos <= 64) {  // same predicate as the kernel's `act`
+    for (int nc = 0; nc < a.n_chunks; ++nc)
+      for (int cc = 0; cc < a.c_chunks; ++cc) {
+        bool any = false;
+        for (int i = 0; i < TN; ++i) {
+          const int n = nc * 16 * TN + 16 * i;
+          if (n >= a.Cout) continue;
+          const int n_last = (n + 15 < a.Cout) ? n + 15 : a.Cout - 1;
+          any = any || cc * 16 * CT < a.tri_base + a.tri_step * (n_last / a.tri_step);
+        }
+        if (any) {
+          a.act_nc[a.n_active] = (unsigned char)nc;
+          a.act_cc[a.n_active] = (unsigned char)cc;
+          ++a.n_active;
+        }
+      }
+    if (a.n_active == 0) return 0;
+    combos = a.n_active;
+  }
   // Spatial split S: ONE round of workgroups (one is resident per CU: 148 KB of LDS).  Measured on the
   // dense-block and the 5x5x5 wgrad: launches of <= 256 workgroups are fastest, a launch just over a
   // multiple of 256 is up to 1.6x slower (a nearly empty extra round), and more, smaller workgroups
