@@ -33,7 +33,7 @@ struct C1Args {
   float mask_slope;
 };
 
-template <int TN, int TM, int KS>
+template <int TN, int TM, int KS, bool MASK>
 __global__ __launch_bounds__(256) void conv1x1_kernel(const C1Args a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];  // KS * TN fragments of 1 KB
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -46,10 +46,13 @@ __global__ __launch_bounds__(256) void conv1x1_kernel(const C1Args a) {
   __syncthreads();
   const char* wl = smem + lane * 16;
 
-  for (int strip = blockIdx.x * 4 + wave; strip < a.nstrips; strip += gridDim.x * 4) {
+  // Per strip: every load (activation fragments, bias, residual, mask values) is requested before the first
+  // store - a load placed after a store cannot be hoisted by the compiler (possible aliasing) and would
+  // cost a memory round trip per tile.  (Prefetching the next strip's fragments into a second register set
+  // was measured slower: 128 more VGPRs spill.)
+  const int stride = gridDim.x * 4;
+  auto load_x = [&](int strip, uint4 (&xf)[KS][TM]) {
     const long v0 = (long)strip * (16 * TM);
-    // ---- all activation fragments of the strip: voxel row fr of m-tile i, K-octet fg of K-step ks
-    uint4 xf[KS][TM];
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
       const long v = v0 + 16 * i + fr;
@@ -57,11 +60,40 @@ __global__ __launch_bounds__(256) void conv1x1_kernel(const C1Args a) {
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) xf[ks][i] = *reinterpret_cast<const uint4*>(p + ks * 32);
     }
+  };
+  auto do_strip = [&](int strip, const uint4 (&xf)[KS][TM]) {
+    const long v0 = (long)strip * (16 * TM);
+    // The accumulators start from bias + (beta/alpha) * residual (this kernel takes a residual only without
+    // an activation), so neither needs registers of its own next to the two fragment sets; the mask values
+    // of the strip (input-gradient launches) are requested here, before any store.
     f32x4_t acc[TM][TN];
+    uint2 yy[TM][MASK ? TN : 1];
+    const float rscale = a.res ? a.beta / a.alpha : 0.f;
 #pragma unroll
-    for (int i = 0; i < TM; ++i)
+    for (int i = 0; i < TM; ++i) {
+      const long v = v0 + 16 * i + fr;
+      const bool vok = v < a.nvox;
 #pragma unroll
-      for (int j = 0; j < TN; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+      for (int j = 0; j < TN; ++j) {
+        const int co0 = 16 * j + 4 * fg;
+        const bool ok = vok && co0 < a.Cout;
+        float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (a.bias && co0 < a.Cout) b4 = *reinterpret_cast<const float4*>(a.bias + co0);
+        if (a.res && ok) {
+          const uint2 r2 = *reinterpret_cast<const uint2*>(a.res + v * a.res_ctot + a.res_off + co0);
+          b4.x += rscale * bf2f((unsigned short)(r2.x & 0xFFFFu));
+          b4.y += rscale * bf2f((unsigned short)(r2.x >> 16));
+          b4.z += rscale * bf2f((unsigned short)(r2.y & 0xFFFFu));
+          b4.w += rscale * bf2f((unsigned short)(r2.y >> 16));
+        }
+        acc[i][j] = f32x4_t{b4.x, b4.y, b4.z, b4.w};
+        if constexpr (MASK) {
+          yy[i][j] = make_uint2(0x3F803F80u, 0x3F803F80u);  // +1: derivative 1 outside the mask window
+          if (ok && co0 >= a.mask_c0 && co0 < a.mask_c1)
+            yy[i][j] = *reinterpret_cast<const uint2*>(a.mask_y + v * a.mask_ctot + a.mask_off + (co0 - a.mask_c0));
+        }
+      }
+    }
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
 #pragma unroll
@@ -77,16 +109,11 @@ __global__ __launch_bounds__(256) void conv1x1_kernel(const C1Args a) {
       const long v = v0 + 16 * i + fr;
       if (v >= a.nvox) continue;
       unsigned short* o = a.out + v * a.out_ctot + a.out_off + 4 * fg;
-      const unsigned short* rp = a.res ? a.res + v * a.res_ctot + a.res_off + 4 * fg : nullptr;
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
         const int co0 = 16 * j + 4 * fg;
         if (co0 >= a.Cout) continue;  // Cout is a multiple of 4 here (checked on the host)
         float4 o4 = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
-        if (a.bias) {
-          const float4 b4 = *reinterpret_cast<const float4*>(a.bias + co0);
-          o4.x += b4.x; o4.y += b4.y; o4.z += b4.z; o4.w += b4.w;
-        }
         if (a.act) {
           o4.x = o4.x > 0.f ? o4.x : o4.x * a.slope;
           o4.y = o4.y > 0.f ? o4.y : o4.y * a.slope;
@@ -94,29 +121,29 @@ __global__ __launch_bounds__(256) void conv1x1_kernel(const C1Args a) {
           o4.w = o4.w > 0.f ? o4.w : o4.w * a.slope;
         }
         o4.x *= a.alpha; o4.y *= a.alpha; o4.z *= a.alpha; o4.w *= a.alpha;
-        if (rp) {
-          const float4 r4 = ld4<BF16>(rp + 16 * j);
-          o4.x += a.beta * r4.x; o4.y += a.beta * r4.y; o4.z += a.beta * r4.z; o4.w += a.beta * r4.w;
-        }
-        if (a.mask_y && co0 >= a.mask_c0 && co0 < a.mask_c1) {
-          const float4 y4 = ld4<BF16>(a.mask_y + v * a.mask_ctot + a.mask_off + (co0 - a.mask_c0));
-          o4.x *= y4.x > 0.f ? 1.f : a.mask_slope;
-          o4.y *= y4.y > 0.f ? 1.f : a.mask_slope;
-          o4.z *= y4.z > 0.f ? 1.f : a.mask_slope;
-          o4.w *= y4.w > 0.f ? 1.f : a.mask_slope;
+        if constexpr (MASK) {  // bf16 sign test on the raw bits: y > 0 <=> sign clear and not zero
+          o4.x *= (short)(yy[i][j].x & 0xFFFFu) > 0 ? 1.f : a.mask_slope;
+          o4.y *= (int)yy[i][j].x > 0xFFFF ? 1.f : a.mask_slope;
+          o4.z *= (short)(yy[i][j].y & 0xFFFFu) > 0 ? 1.f : a.mask_slope;
+          o4.w *= (int)yy[i][j].y > 0xFFFF ? 1.f : a.mask_slope;
         }
         st4<BF16>(o + 16 * j, o4);
       }
     }
+  };
+  for (int strip = blockIdx.x * 4 + wave; strip < a.nstrips; strip += stride) {
+    uint4 xa[KS][TM];
+    load_x(strip, xa);
+    do_strip(strip, xa);
   }
 }
 
-template <int TN, int TM, int KS>
+template <int TN, int TM, int KS, bool MASK>
 int launch_c1(const C1Args& a0, hipStream_t st) {
   C1Args a = a0;
   a.nstrips = (int)((a.nvox + 16 * TM - 1) / (16 * TM));
   const size_t lds = (size_t)KS * TN * 1024;
-  auto kern = conv1x1_kernel<TN, TM, KS>;
+  auto kern = conv1x1_kernel<TN, TM, KS, MASK>;
   static bool attr_done = false;
   if (!attr_done) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -157,8 +184,15 @@ int wsr_conv1x1_bf16(const unsigned short* in, int in_ctot, int in_off, int red,
   }
   if (n_out % 16) return WSR_EUNSUPPORTED;  // the fragment-order filter must have exactly TN n-tiles
   const int nt = n_out / 16, ks = red / 32;
-  if (nt == 8 && ks == 8) return launch_c1<8, 2, 8>(a, st);    // 256 -> 128 (LFF forward)
-  if (nt == 16 && ks == 4) return launch_c1<16, 1, 4>(a, st);  // 128 -> 256 (LFF input gradient)
-  if (nt == 8 && ks == 4) return launch_c1<8, 2, 4>(a, st);    // 128 -> 128
+  if (a.res && (a.act || a.alpha == 0.f)) return WSR_EUNSUPPORTED;  // residual is folded into the accumulator start
+  if (a.bias && ((size_t)a.bias & 15)) return WSR_EUNSUPPORTED;
+  if (!mask) {
+    if (nt == 8 && ks == 8) return launch_c1<8, 2, 8, false>(a, st);    // 256 -> 128 (LFF forward)
+    if (nt == 16 && ks == 4) return launch_c1<16, 1, 4, false>(a, st);  // 128 -> 256
+    if (nt == 8 && ks == 4) return launch_c1<8, 2, 4, false>(a, st);    // 128 -> 128
+  } else {
+    if (nt == 16 && ks == 4) return launch_c1<16, 1, 4, true>(a, st);   // 128 -> 256 (LFF input gradient)
+    if (nt == 8 && ks == 4) return launch_c1<8, 2, 4, true>(a, st);
+  }
   return WSR_EUNSUPPORTED;
 }

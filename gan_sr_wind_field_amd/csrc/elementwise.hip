@@ -313,7 +313,16 @@ __global__ __launch_bounds__(256) void chan_sum_kernel(const typename T::elem* _
   const int g = threadIdx.x % groups, vl = threadIdx.x / groups;
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
   if (vl < lanes) {
-    for (long v = (long)blockIdx.x * lanes + vl; v < nvox; v += (long)gridDim.x * lanes) {
+    const long step = (long)gridDim.x * lanes;
+    long v = (long)blockIdx.x * lanes + vl;
+    for (; v + 7 * step < nvox; v += 8 * step) {  // eight independent loads in flight
+      float4 t[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) t[u] = ld4<T>(x + (v + u * step) * ctot + off + 4 * g);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { acc.x += t[u].x; acc.y += t[u].y; acc.z += t[u].z; acc.w += t[u].w; }
+    }
+    for (; v < nvox; v += step) {
       const float4 a = ld4<T>(x + v * ctot + off + 4 * g);
       acc.x += a.x; acc.y += a.y; acc.z += a.z; acc.w += a.w;
     }
@@ -568,8 +577,8 @@ extern "C" int wsr_chan_sum(const void* x, int32_t x_ctot, int32_t x_off, int32_
   hipError_t e = hipMemsetAsync(out, 0, sizeof(float) * C, as_stream(stream));
   if (e != hipSuccess) return (int)e;
   const int groups = C / 4, lanes = 256 / groups;
-  long grid = (nvox + (long)lanes * 64 - 1) / ((long)lanes * 64);  // >= 64 voxels per thread
-  if (grid > 1024) grid = 1024;
+  long grid = (nvox + (long)lanes * 16 - 1) / ((long)lanes * 16);  // >= 16 voxels per thread
+  if (grid > 2048) grid = 2048;
   if (grid < 1) grid = 1;
   DISPATCH_T(dtype,
              hipLaunchKernelGGL(chan_sum_kernel<BF16>, dim3((unsigned)grid), dim3(256), 0, as_stream(stream),
