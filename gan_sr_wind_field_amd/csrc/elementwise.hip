@@ -341,6 +341,49 @@ __global__ __launch_bounds__(256) void chan_sum_kernel(const typename T::elem* _
   }
 }
 
+
+// z-fold / z-unfold (see windsr_hip.h): planar tensors are (B, channels, planes, Z) with z contiguous
+__global__ void zfold_kernel(const float* __restrict__ t, float* __restrict__ y, const float* __restrict__ bias, int B,
+                             int C, int KZ, int pz, long planes, int Z) {
+  const long total = (long)B * C * planes * Z;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int z = (int)(i % Z);
+    const long r = i / Z;
+    const long p = r % planes;
+    const long bc = r / planes;
+    const int c = (int)(bc % C);
+    const long b = bc / C;
+    float acc = bias ? bias[c] : 0.f;
+    const float* tp = t + ((b * C + c) * KZ * planes + p) * Z;
+    for (int kz = 0; kz < KZ; ++kz) {
+      const int zz = z + kz - pz;
+      if ((unsigned)zz < (unsigned)Z) acc += tp[(long)kz * planes * Z + zz];
+    }
+    y[i] = acc;
+  }
+}
+
+template <class T>
+__global__ void zunfold_kernel(const float* __restrict__ g, typename T::elem* __restrict__ d, int B, int C, int KZ, int pz,
+                               long planes, int Z, int d_ctot, int d_off, int cfill) {
+  const long total = (long)B * planes * Z * cfill;
+  const int CK = C * KZ;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int ch = (int)(i % cfill);
+    const long v = i / cfill;  // (b, p, z)
+    float x = 0.f;
+    if (ch < CK) {
+      const int c = ch / KZ, kz = ch - c * KZ;
+      const int z = (int)(v % Z);
+      const long bp = v / Z;
+      const long p = bp % planes, b = bp / planes;
+      const int zz = z - kz + pz;
+      if ((unsigned)zz < (unsigned)Z) x = g[((b * C + c) * planes + p) * Z + zz];
+    }
+    stf<T>(d + v * d_ctot + d_off + ch, x);
+  }
+}
+
 }  // namespace
 
 #define DISPATCH_T(dtype, CALL_BF16, CALL_F32) \
@@ -585,6 +628,30 @@ extern "C" int wsr_chan_sum(const void* x, int32_t x_ctot, int32_t x_off, int32_
                                 (const unsigned short*)x, x_ctot, x_off, C, (long)nvox, scale, out),
              hipLaunchKernelGGL(chan_sum_kernel<F32>, dim3((unsigned)grid), dim3(256), 0, as_stream(stream),
                                 (const float*)x, x_ctot, x_off, C, (long)nvox, scale, out));
+  WSR_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int wsr_zfold(const float* t, float* y, const float* bias, int32_t B, int32_t C, int32_t KZ, int32_t pz,
+                         int64_t planes, int32_t Z, void* stream) {
+  if (!t || !y || B <= 0 || C <= 0 || KZ <= 0 || pz < 0 || planes <= 0 || Z <= 0) return WSR_EINVAL;
+  const long total = (long)B * C * planes * Z;
+  hipLaunchKernelGGL(zfold_kernel, dim3(ew_grid(total)), dim3(EW_BLOCK), 0, as_stream(stream), t, y, bias, B, C, KZ,
+                     pz, (long)planes, Z);
+  WSR_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int wsr_zunfold(const float* g, void* d, int32_t B, int32_t C, int32_t KZ, int32_t pz, int64_t planes,
+                           int32_t Z, int32_t d_ctot, int32_t d_off, int32_t c_fill, int32_t dtype, void* stream) {
+  if (!g || !d || B <= 0 || C <= 0 || KZ <= 0 || pz < 0 || planes <= 0 || Z <= 0) return WSR_EINVAL;
+  if (c_fill < C * KZ || d_off < 0 || d_off + c_fill > d_ctot) return WSR_EINVAL;
+  const long total = (long)B * planes * Z * c_fill;
+  DISPATCH_T(dtype,
+             hipLaunchKernelGGL(zunfold_kernel<BF16>, dim3(ew_grid(total)), dim3(EW_BLOCK), 0, as_stream(stream), g,
+                                (unsigned short*)d, B, C, KZ, pz, (long)planes, Z, d_ctot, d_off, c_fill),
+             hipLaunchKernelGGL(zunfold_kernel<F32>, dim3(ew_grid(total)), dim3(EW_BLOCK), 0, as_stream(stream), g,
+                                (float*)d, B, C, KZ, pz, (long)planes, Z, d_ctot, d_off, c_fill));
   WSR_LAUNCH_CHECK();
   return 0;
 }

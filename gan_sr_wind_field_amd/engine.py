@@ -32,6 +32,8 @@ Tensor = torch.Tensor
 #: debugging aid (tests set it): allocate work buffers filled with NaN instead of uninitialised
 #: group the input gradients of a dense block by produced window (WSR_STACK_DGRAD=0: one launch per conv)
 STACK_DGRAD = __import__("os").environ.get("WSR_STACK_DGRAD", "1") != "0"
+#: run the last conv of the generator in its z-folded form (WSR_ZFOLD=0: plain 5x5x5 conv with 3 outputs)
+ZFOLD = __import__("os").environ.get("WSR_ZFOLD", "1") != "0"
 POISON_BUFFERS = bool(int(__import__("os").environ.get("WSR_POISON_BUFFERS", "0")))
 
 
@@ -304,8 +306,8 @@ class ProgramBase:
             run()
 
     def wgrad(self, s: ConvSite, x: Tensor, x_off: int, g: Tensor, g_off: int, flat: Tensor, space: GradSpace,
-              scratch: Tensor, scale: float = 1.0) -> None:
-        """master-layout gradient slot of s.weight = scale * wgrad(x[window], g[window])"""
+              scratch: Tensor, scale: float = 1.0, dst: Optional[Tensor] = None) -> None:
+        """master-layout gradient slot of s.weight (or ``dst``) = scale * wgrad(x[window], g[window])"""
         B = x.shape[0]
         cin_p = self.cp(s.cin)
         d = self._desc(s, B, tuple(x.shape[1:4]), x.shape[-1], x_off, g.shape[-1], g_off, cin=cin_p)
@@ -314,7 +316,8 @@ class ProgramBase:
             self.launch_probe("wgrad:" + s.name, lambda: ops.conv_wgrad(d, x, g, dwp))
         else:
             ops.conv_wgrad(d, x, g, dwp)
-        self._pending_unpack.append((dwp.view(s.cout, s.taps, cin_p), space.view(flat, s.weight), scale))
+        self._pending_unpack.append((dwp.view(s.cout, s.taps, cin_p),
+                                     space.view(flat, s.weight) if dst is None else dst, scale))
 
     def wgrad_dense(self, convs: Sequence[ConvSite], buf: Tensor, gd: Tensor, flat: Tensor, space: GradSpace,
                     scratch: Tensor) -> None:
@@ -477,6 +480,17 @@ class GeneratorProgram(ProgramBase):
         self.terrain1 = site_from_conv("terrain_convs.1.0", G.terrain_convs[1][0])
         self.hr0 = site_from_conv("hr_convs.0.0", G.hr_convs[0][0])
         self.hr1 = site_from_conv("hr_convs.2", G.hr_convs[2])
+        # z-folded twin of hr1 (see wsr_zfold): a (KX,KY,1) conv with cout*KZ outputs whose filter is a
+        # permuted copy of hr1's, refreshed when that changes
+        self.hr1z: Optional[ConvSite] = None
+        self._hr1z_stamp = None
+        self._hr1z_grad: Optional[Tensor] = None
+        k = self.hr1.kernel
+        if k[2] > 1 and self.hr1.cout * k[2] <= 16 and self.hr1.stride == (1, 1, 1) and not self.hr1.upsample:
+            w = self.hr1.weight
+            wz = torch.empty((self.hr1.cout * k[2], self.hr1.cin, k[0], k[1], 1), dtype=torch.float32, device=w.device)
+            self.hr1z = ConvSite("hr_convs.2.zfold", wz, None, (k[0], k[1], 1), (1, 1, 1),
+                                 (self.hr1.pad[0], self.hr1.pad[1], 0))
         self.nf = self.feature.cout
         self.gc = self.rrdbs[0][0][0][0].cout if self.rrdbs and self.rrdbs[0][0][0] else 0
         self.tf = self.terrain1.cout
@@ -496,11 +510,34 @@ class GeneratorProgram(ProgramBase):
         self.param_list = order
         self.all_sites = ([self.feature, self.lr_conv, self.terrain0, self.terrain1, self.hr0, self.hr1] + self.ups
                           + [c for rdbs in self.rrdbs for convs, lff, _ in rdbs for c in convs + [lff]])
+        if self.hr1z is not None:
+            self.all_sites.append(self.hr1z)
         self._scratch_elems = self.wgrad_scratch_elems(self.all_sites, self.e)
         if self.rrdbs and self.rrdbs[0][0][0]:
             c = self.rrdbs[0][0][0]
             self._scratch_elems = max(self._scratch_elems, len(c) * c[0].cout * c[0].taps * self.cp(c[-1].cin))
         self._scratch_elems_total = sum(s.cout * s.taps * self.cp(s.cin) for s in self.all_sites)
+
+    def zfold_active(self) -> bool:
+        return ZFOLD and self.hr1z is not None and self.tile_ok(self.hr1z)
+
+    def conv_sites(self) -> Sequence[ConvSite]:
+        zf = self.zfold_active()
+        return [s for s in self.all_sites if s is not (self.hr1 if zf else self.hr1z)]
+
+    def refresh_filters(self, backward: bool) -> None:
+        if self.zfold_active():  # hr1's filter in the folded arrangement [c*KZ + kz][ci][kx][ky][0]
+            w = self.hr1.weight
+            wz = self.hr1z.weight
+            if wz.device != w.device:
+                wz = self.hr1z.weight = torch.empty_like(wz, device=w.device)
+                self._hr1z_stamp = None
+            stamp = (w._version, w.data_ptr(), self.filters._gen)
+            if stamp != self._hr1z_stamp:
+                kx, ky, kz = self.hr1.kernel
+                wz.view(self.hr1.cout, kz, self.hr1.cin, kx, ky).copy_(w.detach().permute(0, 4, 1, 2, 3))
+                self._hr1z_stamp = stamp
+        super().refresh_filters(backward)
 
     # ---- forward -------------------------------------------------------------------
     def forward(self, x: Tensor, Z: Tensor, training: bool, save: bool, drop_scale: Optional[Tensor]):
@@ -560,7 +597,14 @@ class GeneratorProgram(ProgramBase):
         h = self._empty((B, sX, sY, nz, cat_c), x, zero=cat_c != nf + tf)
         self.conv(self.hr0, hcat, 0, h, 0, act=True, slope=sl, chan_scale=drop_scale)
         out = torch.empty((B, self.hr1.cout, sX, sY, nz), dtype=torch.float32, device=x.device)
-        self.conv(self.hr1, h, 0, out, 0, out_planar=True)
+        if self.zfold_active():
+            kz = self.hr1.kernel[2]
+            parts = torch.empty((B, self.hr1.cout * kz, sX, sY, nz), dtype=torch.float32, device=x.device)
+            self.conv(self.hr1z, h, 0, parts, 0, out_planar=True)
+            ops.zfold(parts, out, self.hr1.bias.detach() if self.hr1.bias is not None else None, kz, self.hr1.pad[2])
+            del parts
+        else:
+            self.conv(self.hr1, h, 0, out, 0, out_planar=True)
         saved = None
         if save:
             saved = dict(x_nd=x_nd, first=first, bufs=bufs, t_last=t_last, s=s, up_io=up_io, hcat=hcat, z_nd=z_nd,
@@ -593,15 +637,29 @@ class GeneratorProgram(ProgramBase):
 
         g_out = g_out.contiguous().float()
         # ---- hr1 (k5, bias, planar out)
-        co_p = self.cp(self.hr1.cout)
-        g3 = self._empty((B, sX, sY, nz, co_p), g_out)
-        ops.planar_to_ndhwc(g_out, g3, 0, co_p)
         h, hcat = saved["h"], saved["hcat"]
-        self.wgrad(self.hr1, h, 0, g3, 0, flat, sp, scratch)
-        sp.view(flat, self.hr1.bias).copy_(g_out.sum(dim=(0, 2, 3, 4)))
         cat_c = h.shape[-1]
         gh = self._empty(h.shape, g_out)
-        self.dgrad(self.hr1, g3, 0, gh, 0, (sX, sY, nz))
+        if self.zfold_active():  # adjoint of the folded forward: dy un-folded into cout*KZ channels
+            kx, ky, kz = self.hr1.kernel
+            cz = self.hr1.cout * kz
+            cz_p = self.cp(cz)
+            g3 = self._empty((B, sX, sY, nz, cz_p), g_out)
+            ops.zunfold(g_out, g3, kz, self.hr1.pad[2], 0, cz_p)
+            if self._hr1z_grad is None or self._hr1z_grad.device != dev:
+                self._hr1z_grad = torch.empty_like(self.hr1z.weight, device=dev)
+            self.wgrad(self.hr1z, h, 0, g3, 0, flat, sp, scratch, dst=self._hr1z_grad)
+            self.dgrad(self.hr1z, g3, 0, gh, 0, (sX, sY, nz))
+            self.flush_unpack()
+            sp.view(flat, self.hr1.weight).copy_(
+                self._hr1z_grad.view(self.hr1.cout, kz, self.hr1.cin, kx, ky).permute(0, 2, 3, 4, 1))
+        else:
+            co_p = self.cp(self.hr1.cout)
+            g3 = self._empty((B, sX, sY, nz, co_p), g_out)
+            ops.planar_to_ndhwc(g_out, g3, 0, co_p)
+            self.wgrad(self.hr1, h, 0, g3, 0, flat, sp, scratch)
+            self.dgrad(self.hr1, g3, 0, gh, 0, (sX, sY, nz))
+        sp.view(flat, self.hr1.bias).copy_(g_out.sum(dim=(0, 2, 3, 4)))
         ready(self.hr1.weight, self.hr1.bias)
         del g3
         # ---- hr0 (k5 + LReLU + Dropout3d mask)

@@ -311,6 +311,34 @@ def upsample2_bwd(dy: Tensor, dx: Tensor) -> Tensor:
     return dx
 
 
+def zfold(t: Tensor, y: Tensor, bias: Optional[Tensor], kz: int, pz: int) -> Tensor:
+    """``y[b,c,x,y,z] = bias[c] + sum_k t[b, c*kz+k, x, y, z+k-pz]`` - planar fp32 (see ``wsr_zfold``)."""
+    _need_cuda(t, y)
+    B, C_ = y.shape[:2]
+    if t.dtype != torch.float32 or y.dtype != torch.float32 or not (t.is_contiguous() and y.is_contiguous()) \
+            or t.shape[1] != C_ * kz or t.shape[2:] != y.shape[2:]:
+        raise ValueError("zfold wants contiguous fp32 (B, C*kz, X, Y, Z) -> (B, C, X, Y, Z)")
+    Z = y.shape[-1]
+    planes = y[0, 0].numel() // Z
+    check(_lib.lib().wsr_zfold(_p(t), _p(y), _p(bias) if bias is not None else None, B, C_, kz, pz, planes, Z,
+                               _stream()), "zfold")
+    return y
+
+
+def zunfold(g: Tensor, d: Tensor, kz: int, pz: int, d_off: int = 0, c_fill: Optional[int] = None) -> Tensor:
+    """adjoint of :func:`zfold` into an NDHWC window: ``d[b,x,y,z, c*kz+k] = g[b,c,x,y, z-k+pz]``"""
+    _need_cuda(g, d)
+    if g.dtype != torch.float32 or not g.is_contiguous():
+        raise ValueError("planar tensors are contiguous fp32 (B, C, X, Y, Z)")
+    B, C_ = g.shape[:2]
+    Z = g.shape[-1]
+    planes = g[0, 0].numel() // Z
+    c_fill = C_ * kz if c_fill is None else c_fill
+    check(_lib.lib().wsr_zunfold(_p(g), _p(d), B, C_, kz, pz, planes, Z, d.shape[-1], d_off, c_fill,
+                                 dtype_id(d.dtype), _stream()), "zunfold")
+    return d
+
+
 def planar_to_ndhwc(src: Tensor, dst: Tensor, d_off: int = 0, c_fill: Optional[int] = None) -> Tensor:
     """fp32 (B, C, X, Y, Z) contiguous -> channel window of an NDHWC tensor."""
     _need_cuda(src, dst)

@@ -192,6 +192,18 @@ int wsr_planar_to_ndhwc(const float* src, void* dst, int32_t B, int32_t C, int64
 int wsr_ndhwc_to_planar(const void* src, float* dst, int32_t B, int32_t C, int64_t vox_per_b,
                         int32_t s_ctot, int32_t s_off, int32_t dtype, void* stream);
 
+/* z-folded form of a conv with very few output channels (the last conv of the generator, 144 -> 3,
+ * 5x5x5, Generator_3D_Resnet_ESRGAN.py:120-127): the KZ taps along z become output channels of a
+ * (KX,KY,1) conv with C*KZ outputs - 15 instead of 3 of the 16 columns of an MFMA tile do work, a fifth
+ * of the K-steps - and the z taps are summed afterwards:
+ *   fold  : y[b,c,p,z]        = bias[c] + sum_kz t[b, c*KZ+kz, p, z + kz - pz]      (planar fp32, p = x*Y+y)
+ *   unfold: d[b,p,z, c*KZ+kz] = g[b,c,p, z - kz + pz]   (its adjoint: planar fp32 -> NDHWC `dtype`;
+ *           channels [C*KZ, c_fill) are written as zeros); out-of-range z contributes 0.          */
+int wsr_zfold(const float* t, float* y, const float* bias, int32_t B, int32_t C, int32_t KZ, int32_t pz,
+              int64_t planes, int32_t Z, void* stream);
+int wsr_zunfold(const float* g, void* d, int32_t B, int32_t C, int32_t KZ, int32_t pz, int64_t planes, int32_t Z,
+                int32_t d_ctot, int32_t d_off, int32_t c_fill, int32_t dtype, void* stream);
+
 /* BatchNorm3d (torch_blocks.py:20-25) on NDHWC tensors, fp32 statistics.
  * stats: sums[2*C] += {sum d, sum d^2}, d = x - shift[c] (shift NULL = 0; caller
  * zeroes sums).  Two calls - shift 0, then shift = mean - give a cancellation-free

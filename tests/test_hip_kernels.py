@@ -441,3 +441,32 @@ def test_chan_sum_bias_gradient(hip, dt, C, ctot, off, nvox):
     want = 0.2 * x[..., off:off + C].double().sum(dim=(0, 1, 2, 3))
     assert rel_l2(out, want.float()) < 1e-5
     assert not o.chan_sum(x[..., :6].contiguous(), 0, 6, torch.empty(6, device="cuda:0"))  # C % 4: caller falls back
+
+
+def test_zfold_and_its_adjoint(hip):
+    """z-folded last conv: fold sums the KZ z-taps kept as channels, unfold is its adjoint (windsr_hip.h)"""
+    from gan_sr_wind_field_amd import hip_ops as o
+
+    B, C, KZ, pz, X, Y, Z = 2, 3, 5, 2, 4, 3, 7
+    g = torch.Generator(device="cuda:0").manual_seed(11)
+    t = torch.randn((B, C * KZ, X, Y, Z), device="cuda:0", generator=g)
+    bias = torch.randn(C, device="cuda:0", generator=g)
+    y = torch.empty((B, C, X, Y, Z), device="cuda:0")
+    o.zfold(t, y, bias, KZ, pz)
+    want = bias.view(1, C, 1, 1, 1).expand(B, C, X, Y, Z).clone()
+    tp = F.pad(t, (pz, KZ - 1 - pz))
+    for c in range(C):
+        for k in range(KZ):
+            want[:, c] += tp[:, c * KZ + k, :, :, k:k + Z]
+    assert rel_l2(y, want) < 1e-6
+    # adjoint: <fold(t) - bias, gy> == <t, unfold(gy)>
+    gy = torch.randn((B, C, X, Y, Z), device="cuda:0", generator=g)
+    d = torch.full((B, X, Y, Z, 16), float("nan"), device="cuda:0")
+    o.zunfold(gy, d, KZ, pz, 0, 16)
+    assert torch.equal(d[..., 15], torch.zeros_like(d[..., 15]))
+    lhs = ((y - bias.view(1, C, 1, 1, 1)) * gy).sum()
+    rhs = (t.permute(0, 2, 3, 4, 1) * d[..., :15]).sum()
+    assert abs(float(lhs - rhs)) < 1e-3 * abs(float(lhs))
+    db = torch.empty((B, X, Y, Z, 16), device="cuda:0", dtype=torch.bfloat16)
+    o.zunfold(gy, db, KZ, pz, 0, 16)
+    assert rel_l2(db.float(), d) < 4e-3

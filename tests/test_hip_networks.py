@@ -334,3 +334,32 @@ def test_generator_bf16_stacked_dense_input_gradient(hip, monkeypatch, nf, gc, n
     for k in grads["fp32"]:
         e_s, e_p = rel_l2(grads["stacked"][k], grads["fp32"][k]), rel_l2(grads["perconv"][k], grads["fp32"][k])
         assert e_s < max(1.5 * e_p, 2e-2), (k, e_s, e_p)
+
+
+def test_generator_bf16_zfolded_last_conv(hip, monkeypatch):
+    """hr_convs.2 (144 -> 3, 5x5x5) as a (5,5,1) conv with 15 outputs + z-fold against the plain kernel:
+    same outputs and gradients up to the bf16 rounding of the operands (the partial sums stay fp32)."""
+    from gan_sr_wind_field_amd import engine
+
+    spec = onets.GSpec(upscale=4, in_channels=4, out_channels=3, nf=16, n_rrdb=1, hr_kern=5, gc=8, tf=8)
+    LR, HR, Z, x, y = ogan.synthetic_batch(2, 6, 5, 4, seed=12)
+    gy = torch.randn(2, 3, 24, 24, 5, generator=torch.Generator().manual_seed(4)).to(DEV)
+    res = {}
+    for zf in (True, False):
+        monkeypatch.setattr(engine, "ZFOLD", zf)
+        G, _ = build_G(spec, torch.bfloat16, 33)
+        G.eval()
+        seen = []
+        G.program().launch_probe = lambda tag, fn: (seen.append(tag), fn())
+        out = G(LR.to(DEV), Z.to(DEV))
+        (out * gy).sum().backward()
+        assert any("zfold" in t for t in seen) == zf
+        res[zf] = (out.detach(), {k: p.grad.clone() for k, p in G.named_parameters()})
+        if zf:  # the folded filter follows a parameter update
+            with torch.no_grad():
+                G.hr_convs[2].weight.mul_(2.0)
+            assert rel_l2(G(LR.to(DEV), Z.to(DEV)) - G.hr_convs[2].bias.view(1, 3, 1, 1, 1),
+                          2.0 * (out.detach() - G.hr_convs[2].bias.view(1, 3, 1, 1, 1))) < 1e-5
+    assert rel_l2(res[True][0], res[False][0]) < 1e-5
+    for k in res[True][1]:
+        assert rel_l2(res[True][1][k], res[False][1][k]) < 2e-2, k
