@@ -85,7 +85,7 @@ def lib() -> C.CDLL:
         "wsr_unpack_wgrad_multi": [vp, i32, vp],
         "wsr_lrelu_bwd_inplace": [vp, i32, i32, vp, i32, i32, i32, i64, f32, vp, i64, i32, vp],
         "wsr_chan_axpby": [vp, i32, i32, vp, i32, i32, i32, i64, f32, f32, i32, vp],
-        "wsr_chan_sum": [vp, i32, i32, i32, i64, f32, vp, i32, vp],
+        "wsr_chan_sum": [vp, i32, i32, i32, i64, f32, vp, vp, i32, vp],
         "wsr_upsample2_bwd": [vp, vp, i32, i32, i32, i32, i32, i32, vp],
         "wsr_planar_to_ndhwc": [vp, vp, i32, i32, i64, i32, i32, i32, i32, vp],
         "wsr_ndhwc_to_planar": [vp, vp, i32, i32, i64, i32, i32, i32, vp],

@@ -302,12 +302,12 @@ __global__ void adam_kernel(float* p, const float* __restrict__ g, float* m, flo
 }
 
 
-// per-channel sum over voxels of an NDHWC window: thread = (voxel lane, 4-channel group); partial sums are
-// combined in LDS and added to out[] with one float atomic per channel and workgroup
+// per-channel sum over voxels of an NDHWC window, pass 1: thread = (voxel lane, 4-channel group); the
+// workgroup's partial sums go to row blockIdx.x of `part` (no atomics: C addresses would serialise them)
 template <class T>
 __global__ __launch_bounds__(256) void chan_sum_kernel(const typename T::elem* __restrict__ x, int ctot, int off, int C,
-                                                      long nvox, float scale, float* __restrict__ out) {
-  __shared__ float4 part[256];
+                                                      long nvox, float* __restrict__ part) {
+  __shared__ float4 sh[256];
   const int groups = C >> 2;              // 4-channel groups (<= 256)
   const int lanes = 256 / groups;         // voxel lanes per workgroup
   const int g = threadIdx.x % groups, vl = threadIdx.x / groups;
@@ -327,20 +327,42 @@ __global__ __launch_bounds__(256) void chan_sum_kernel(const typename T::elem* _
       acc.x += a.x; acc.y += a.y; acc.z += a.z; acc.w += a.w;
     }
   }
-  part[threadIdx.x] = acc;
+  sh[threadIdx.x] = acc;
   __syncthreads();
   if (vl == 0) {
     for (int l = 1; l < lanes; ++l) {
-      const float4 a = part[l * groups + g];
+      const float4 a = sh[l * groups + g];
       acc.x += a.x; acc.y += a.y; acc.z += a.z; acc.w += a.w;
     }
-    atomicAdd(out + 4 * g + 0, acc.x * scale);
-    atomicAdd(out + 4 * g + 1, acc.y * scale);
-    atomicAdd(out + 4 * g + 2, acc.z * scale);
-    atomicAdd(out + 4 * g + 3, acc.w * scale);
+    *reinterpret_cast<float4*>(part + (long)blockIdx.x * C + 4 * g) = acc;
   }
 }
 
+// pass 2: out[c] = scale * sum over rows of part[row][c]; one workgroup, thread = (row lane, channel)
+__global__ __launch_bounds__(1024) void chan_sum_final_kernel(const float* __restrict__ part, int rows, int C, float scale,
+                                                             float* __restrict__ out) {
+  __shared__ float sh[1024];
+  const int lanes = 1024 / C;  // C <= 1024
+  const int c = threadIdx.x % C, rl = threadIdx.x / C;
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  if (rl < lanes) {
+    int r = rl;
+    for (; r + 3 * lanes < rows; r += 4 * lanes) {
+      a0 += part[(long)r * C + c];
+      a1 += part[(long)(r + lanes) * C + c];
+      a2 += part[(long)(r + 2 * lanes) * C + c];
+      a3 += part[(long)(r + 3 * lanes) * C + c];
+    }
+    for (; r < rows; r += lanes) a0 += part[(long)r * C + c];
+  }
+  sh[threadIdx.x] = (a0 + a1) + (a2 + a3);
+  __syncthreads();
+  if (rl == 0) {
+    float a = sh[c];
+    for (int l = 1; l < lanes; ++l) a += sh[l * C + c];
+    out[c] = scale * a;
+  }
+}
 
 // z-fold / z-unfold (see windsr_hip.h): planar tensors are (B, channels, planes, Z) with z contiguous
 __global__ void zfold_kernel(const float* __restrict__ t, float* __restrict__ y, const float* __restrict__ bias, int B,
@@ -614,20 +636,21 @@ extern "C" int wsr_adam_step(float* p, const float* g, float* m, float* v, int64
 }
 
 extern "C" int wsr_chan_sum(const void* x, int32_t x_ctot, int32_t x_off, int32_t C, int64_t nvox, float scale,
-                            float* out, int32_t dtype, void* stream) {
-  if (!x || !out || C <= 0 || nvox <= 0 || x_off < 0 || x_off + C > x_ctot) return WSR_EINVAL;
+                            float* out, float* partials, int32_t dtype, void* stream) {
+  if (!x || !out || !partials || C <= 0 || nvox <= 0 || x_off < 0 || x_off + C > x_ctot) return WSR_EINVAL;
   if (C % 4 || C > 1024 || x_ctot % 4 || x_off % 4) return WSR_EUNSUPPORTED;
-  hipError_t e = hipMemsetAsync(out, 0, sizeof(float) * C, as_stream(stream));
-  if (e != hipSuccess) return (int)e;
   const int groups = C / 4, lanes = 256 / groups;
   long grid = (nvox + (long)lanes * 16 - 1) / ((long)lanes * 16);  // >= 16 voxels per thread
-  if (grid > 2048) grid = 2048;
+  if (grid > WSR_CHAN_SUM_ROWS) grid = WSR_CHAN_SUM_ROWS;
   if (grid < 1) grid = 1;
   DISPATCH_T(dtype,
              hipLaunchKernelGGL(chan_sum_kernel<BF16>, dim3((unsigned)grid), dim3(256), 0, as_stream(stream),
-                                (const unsigned short*)x, x_ctot, x_off, C, (long)nvox, scale, out),
+                                (const unsigned short*)x, x_ctot, x_off, C, (long)nvox, partials),
              hipLaunchKernelGGL(chan_sum_kernel<F32>, dim3((unsigned)grid), dim3(256), 0, as_stream(stream),
-                                (const float*)x, x_ctot, x_off, C, (long)nvox, scale, out));
+                                (const float*)x, x_ctot, x_off, C, (long)nvox, partials));
+  WSR_LAUNCH_CHECK();
+  hipLaunchKernelGGL(chan_sum_final_kernel, dim3(1), dim3(1024), 0, as_stream(stream), partials, (int)grid, C, scale,
+                     out);
   WSR_LAUNCH_CHECK();
   return 0;
 }

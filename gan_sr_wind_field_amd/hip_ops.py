@@ -290,6 +290,10 @@ def chan_axpby(dst: Tensor, d_off: int, src: Tensor, s_off: int, C_: int, alpha:
                                     beta, dtype_id(dst.dtype), _stream()), "chan_axpby")
 
 
+CHAN_SUM_ROWS = 512  # WSR_CHAN_SUM_ROWS
+_chan_sum_ws: dict = {}  # per-device scratch of the two-pass channel sum (stream-ordered re-use)
+
+
 def chan_sum(x: Tensor, x_off: int, C_: int, out: Tensor, scale: float = 1.0) -> bool:
     """``out[c] = scale * sum_voxels x[..., x_off + c]`` (fp32, overwritten); False when the kernel does not
     cover the shape (channel counts that are not multiples of 4)."""
@@ -297,7 +301,11 @@ def chan_sum(x: Tensor, x_off: int, C_: int, out: Tensor, scale: float = 1.0) ->
     if out.dtype != torch.float32 or not out.is_contiguous() or out.numel() != C_:
         raise ValueError("chan_sum wants a contiguous fp32 output of C elements")
     nvox = x.numel() // x.shape[-1]
-    rc = _lib.lib().wsr_chan_sum(_p(x), x.shape[-1], x_off, C_, nvox, scale, _p(out), dtype_id(x.dtype), _stream())
+    ws = _chan_sum_ws.get(x.device)
+    if ws is None or ws.numel() < CHAN_SUM_ROWS * C_:
+        ws = _chan_sum_ws[x.device] = torch.empty(CHAN_SUM_ROWS * max(C_, 256), dtype=torch.float32, device=x.device)
+    rc = _lib.lib().wsr_chan_sum(_p(x), x.shape[-1], x_off, C_, nvox, scale, _p(out), _p(ws), dtype_id(x.dtype),
+                                 _stream())
     if rc == _lib.WSR_EUNSUPPORTED:
         return False
     check(rc, "chan_sum")

@@ -179,9 +179,12 @@ int wsr_chan_axpby(void* dst, int32_t d_ctot, int32_t d_off, const void* src, in
                    void* stream);
 /* Bias gradient of a conv (aten::convolution_backward's third output; the LFF bias of a residual dense
  * block, torch_blocks.py:278): out[c] = scale * sum over voxels of x[v, x_off + c], fp32.  `out` is
- * overwritten.  C must be a multiple of 4 and <= 1024 (WSR_EUNSUPPORTED otherwise).               */
+ * overwritten.  Two passes (per-workgroup partial rows, then a column sum: float atomics on C addresses
+ * serialise) through `partials`, a caller-owned scratch of WSR_CHAN_SUM_ROWS * C floats.  C must be a
+ * multiple of 4 and <= 1024 (WSR_EUNSUPPORTED otherwise).                                          */
+#define WSR_CHAN_SUM_ROWS 512
 int wsr_chan_sum(const void* x, int32_t x_ctot, int32_t x_off, int32_t C, int64_t nvox, float scale, float* out,
-                 int32_t dtype, void* stream);
+                 float* partials, int32_t dtype, void* stream);
 /* backward of nearest x(2,2,1) up-sampling: dx[b,x,y,z,c] = sum of the 4 dy    */
 int wsr_upsample2_bwd(const void* dy, void* dx, int32_t B, int32_t Xi, int32_t Yi, int32_t Zi,
                       int32_t C, int32_t dtype, void* stream);
