@@ -93,7 +93,7 @@ __device__ __forceinline__ void dma_wait() { asm volatile("s_waitcnt vmcnt(0)" :
 
 template <int TN> __device__ __forceinline__ int ysw(int v) { return TN <= 4 ? (v >> 1) & 3 : v & 7; }
 
-template <int TN, int SPW, int CT>
+template <int TN, int SPW, int CT, bool Z16>
 __global__ __launch_bounds__(512) void wgrad_tile_kernel(const WgtArgs a) {
   constexpr int WAVES = 8, NT = 512;
   constexpr int XRPU = 32;            // x rows (32 B) per 1 KB DMA unit
@@ -299,25 +299,52 @@ __global__ __launch_bounds__(512) void wgrad_tile_kernel(const WgtArgs a) {
   constexpr int R = SPW % 7 == 0 ? 7 : (SPW % 4 == 0 ? 4 : 1);
   constexpr int D = R > 3 ? 3 : R - 1;
   struct KP { const char *xlo, *xhi, *rlo, *rhi; int slo, shi; };
+  // Voxel <-> MFMA k mapping of a 32-voxel K-step.  Z16 (tile z extent a multiple of 16, every shipped
+  // shape): lane group G takes voxels 16*(G>>1) + 4*(G&1) + q and the same + 8 - both in ONE z column, so the
+  // second transposing read of a fragment is the first one's address + a compile-time constant (8 rows:
+  // 256 B in the x image, 8 dy rows with an unchanged swizzle) and costs no address arithmetic.  Otherwise
+  // voxels 4G + q and + 16 through the halo table.
   auto kp_of = [&](const char* Xs, const char* Ys, int ks) {
-    const int m_lo = ks * 32 + 4 * G + q, m_hi = m_lo + 16;
+    const int m_lo = Z16 ? ks * 32 + 16 * (G >> 1) + 4 * (G & 1) + q : ks * 32 + 4 * G + q;
+    const int m_hi = m_lo + (Z16 ? 8 : 16);
     KP k;
     k.xlo = Xs + (int)htab[m_lo] * 32 + p * 8;
-    k.xhi = Xs + (int)htab[m_hi] * 32 + p * 8;
     k.rlo = Ys + m_lo * RBY + p * 8;
-    k.rhi = Ys + m_hi * RBY + p * 8;
     k.slo = ysw<TN>(m_lo);
-    k.shi = ysw<TN>(m_hi);
+    if constexpr (Z16) {
+      k.xhi = k.xlo + 8 * 32;
+      k.rhi = k.rlo + 8 * RBY;
+      k.shi = k.slo;
+    } else {
+      k.xhi = Xs + (int)htab[m_hi] * 32 + p * 8;
+      k.rhi = Ys + m_hi * RBY + p * 8;
+      k.shi = ysw<TN>(m_hi);
+    }
     return k;
   };
+  constexpr int XHI = 8 * 32, RHI = 8 * RBY;
+  auto af_of = [&](const KP& k, int i) {
 #ifdef WSR_CT_STAMPS
-  const uint4 abl_frag = make_uint4(lane, 1u, 2u, 3u);
-  auto af_of = [&](const KP& k, int i) { return (a.ablate & 4) ? abl_frag : tr_frag(k.rlo + ((i ^ k.slo) << 5), k.rhi + ((i ^ k.shi) << 5)); };
-  auto bf_of = [&](const KP& k, int j) { return (a.ablate & 4) ? abl_frag : tr_frag(k.xlo + soff[j], k.xhi + soff[j]); };
-#else
-  auto af_of = [&](const KP& k, int i) { return tr_frag(k.rlo + ((i ^ k.slo) << 5), k.rhi + ((i ^ k.shi) << 5)); };
-  auto bf_of = [&](const KP& k, int j) { return tr_frag(k.xlo + soff[j], k.xhi + soff[j]); };
+    if (a.ablate & 4) return make_uint4(lane, 1u, 2u, 3u);
 #endif
+    if constexpr (Z16) {
+      const char* lo = k.rlo + ((i ^ k.slo) << 5);
+      return tr_frag(lo, lo + RHI);
+    } else {
+      return tr_frag(k.rlo + ((i ^ k.slo) << 5), k.rhi + ((i ^ k.shi) << 5));
+    }
+  };
+  auto bf_of = [&](const KP& k, int j) {
+#ifdef WSR_CT_STAMPS
+    if (a.ablate & 4) return make_uint4(lane, 1u, 2u, 3u);
+#endif
+    if constexpr (Z16) {
+      const char* lo = k.xlo + soff[j];
+      return tr_frag(lo, lo + XHI);
+    } else {
+      return tr_frag(k.xlo + soff[j], k.xhi + soff[j]);
+    }
+  };
 
   // Software pipeline over the tile list: iteration `it` prefetches tile s0 + it*S into buffer it&1 while
   // tile s0 + (it-1)*S is contracted out of the other buffer (one DMA call site, one MFMA call site).
@@ -519,13 +546,14 @@ int launch_tile(WgtArgs& a, hipStream_t st) {
     const int v = atoi(ov);
     if (v >= 1 && v <= a.ntiles) a.S = v;
   }
-  auto kern = wgrad_tile_kernel<TN, SPW, CT>;
-  static bool attr_done = false;  // raise the dynamic-LDS cap once per instantiation
-  if (!attr_done) {
+  const bool z16 = a.TZ % 16 == 0;
+  auto kern = z16 ? wgrad_tile_kernel<TN, SPW, CT, true> : wgrad_tile_kernel<TN, SPW, CT, false>;
+  static bool attr_done[2] = {false, false};  // raise the dynamic-LDS cap once per instantiation
+  if (!attr_done[z16]) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        160 * 1024);
     if (e != hipSuccess) return (int)e;
-    attr_done = true;
+    attr_done[z16] = true;
   }
 #ifdef WSR_CT_STAMPS
   a.stamps = getenv("WSR_CT_STAMPS_PTR") ? (unsigned long long*)strtoull(getenv("WSR_CT_STAMPS_PTR"), nullptr, 0) : nullptr;
