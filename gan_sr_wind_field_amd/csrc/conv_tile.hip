@@ -89,36 +89,40 @@ __global__ void pack_frag_kernel(const float* __restrict__ w, unsigned short* __
 __global__ void pack_frag_multi_kernel(const wsr_pack_job_t* __restrict__ jobs) {
   const wsr_pack_job_t j = jobs[blockIdx.y];
   const int taps = j.KX * j.KY * j.KZ;
-  const bool part = j.red_total > 0;  // one source of a stacked input-gradient filter
-  const int rows = part ? j.c_n : (j.transpose ? j.Cin : j.Cout);
+  const bool part = j.red_total > 0;  // one source of a stacked dense-block filter
+  const int rows = part ? (j.transpose ? j.c_n : j.rows_total) : (j.transpose ? j.Cin : j.Cout);
   const int red = part ? j.red_total : (j.transpose ? j.Cout : j.Cin);
   const int redp = (red + 7) / 8 * 8;
   const int TPK = taps == 1 ? (redp % 32 == 0 ? 1 : (redp % 16 == 0 ? 2 : 4)) : (redp % 16 == 0 ? 2 : 4);
   const int PL = 4 / TPK, CK = 8 * PL;
   const int nts = (taps + TPK - 1) / TPK, NT_total = (rows + 15) / 16;
-  // chunks this job writes (a part owns whole chunks: red_off and Cout are multiples of CK)
-  const int chunk0 = part ? j.red_off / CK : 0;
-  const int nchunks = part ? j.Cout / CK : (redp + CK - 1) / CK;
-  const long total = (long)nchunks * nts * NT_total * 512;
-  const float* __restrict__ w = j.w;
-  unsigned short* __restrict__ out = reinterpret_cast<unsigned short*>(j.out) + (long)chunk0 * nts * NT_total * 512;
+  // the sub-block this job writes: chunks [chunk0, chunk0 + nchunks), n-tiles [nt0, nt0 + ntl)
+  const int chunk0 = part && j.transpose ? j.red_off / CK : 0;
+  const int nchunks = part ? (j.transpose ? j.Cout / CK : (redp + CK - 1) / CK) : (redp + CK - 1) / CK;
+  const int nt0 = part && !j.transpose ? j.row_off / 16 : 0;
+  const int ntl = part && !j.transpose ? (j.Cout + 15) / 16 : NT_total;
+  const int src_rows = j.transpose ? (part ? j.c_n : j.Cin) : j.Cout;   // rows the source block has
+  const int src_red = j.transpose ? j.Cout : (part ? j.c_n : j.Cin);    // reduction channels it has
   const int c_lo = part ? j.c_lo : 0;
-  const int src_red = part ? j.Cout : red;
+  const long total = (long)nchunks * nts * ntl * 512;
+  const float* __restrict__ w = j.w;
+  unsigned short* __restrict__ out = reinterpret_cast<unsigned short*>(j.out);
   for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
     const int e = (int)(idx & 7);
     const int lane = (int)((idx >> 3) & 63);
     long q = idx >> 9;
-    const int nt = (int)(q % NT_total); q /= NT_total;
+    const int nt = (int)(q % ntl); q /= ntl;
     const int ts = (int)(q % nts);
     const int chunk = (int)(q / nts);
     const int i = lane & 15, g = lane >> 4;
     const int tap = ts * TPK + g / PL;
-    const int c = chunk * CK + (g % PL) * 8 + e;
-    const int n = nt * 16 + i;
+    const int c = chunk * CK + (g % PL) * 8 + e;  // reduction channel within the source block
+    const int n = nt * 16 + i;                     // row within the source block
     float v = 0.f;
-    if (tap < taps && c < src_red && n < rows)
-      v = j.transpose ? w[((long)c * j.Cin + c_lo + n) * taps + (taps - 1 - tap)] : w[((long)n * j.Cin + c) * taps + tap];
-    out[idx] = f2bf(v);
+    if (tap < taps && c < src_red && n < src_rows)
+      v = j.transpose ? w[((long)c * j.Cin + c_lo + n) * taps + (taps - 1 - tap)]
+                      : w[((long)n * j.Cin + c_lo + c) * taps + tap];
+    out[(((long)(chunk0 + chunk) * nts + ts) * NT_total + nt0 + nt) * 512 + lane * 8 + e] = f2bf(v);
   }
 }
 
@@ -185,6 +189,8 @@ static int run_conv_tile(CtArgs& a, int red, hipStream_t st) {
               (!a.res || (a.res_ctot % 4 == 0 && a.res_off % 4 == 0)))
                  ? 1
                  : 0;
+  if (a.act == 2 && !(a.vec_ok && (a.Cout & 3) == 0)) return WSR_EUNSUPPORTED;  // vector epilogue only
+  if (a.act_c1 != 0x7FFFFFFF && (a.act_c1 & 3)) return WSR_EINVAL;
   return dispatch_ct(a, tpk, st);
 }
 
@@ -212,6 +218,8 @@ extern "C" int wsr_conv3d_fwd_tile(const wsr_conv_t* c, const void* x, const voi
     a.beta = ep->beta;
     a.slope = ep->slope;
     a.act = ep->act;
+    a.act_c1 = ep->act_c1 > 0 ? ep->act_c1 : 0x7FFFFFFF;
+    if (a.act == 2 && (!a.res || ep->out_planar)) return WSR_EINVAL;
     a.out_planar = ep->out_planar;
     if (a.res && (a.res_off < 0 || a.res_off + c->Cout > a.res_ctot)) return WSR_EINVAL;
   }
@@ -222,7 +230,8 @@ extern "C" int wsr_conv3d_fwd_tile(const wsr_conv_t* c, const void* x, const voi
   a.Cout = c->Cout; a.out_ctot = c->out_ctot; a.out_off = c->out_off;
   a.KX = c->KX; a.KY = c->KY; a.KZ = c->KZ;
   a.px = c->px; a.py = c->py; a.pz = c->pz;
-  if (c->KX * c->KY * c->KZ == 1 && !a.ups && !a.out_planar && !a.chan_scale && (c->px | c->py | c->pz) == 0) {
+  if (c->KX * c->KY * c->KZ == 1 && !a.ups && !a.out_planar && !a.chan_scale && (c->px | c->py | c->pz) == 0 &&
+      a.act <= 1 && a.act_c1 == 0x7FFFFFFF) {
     const int rc = wsr_conv1x1_bf16(a.in, a.in_ctot, a.in_off, c->Cin, a.wf, (unsigned short*)a.out, a.out_ctot,
                                     a.out_off, a.Cout, (long)c->B * c->Xo * c->Yo * c->Zo, a.bias, a.res, a.res_ctot,
                                     a.res_off, a.alpha, a.beta, a.act, a.slope, nullptr, as_stream(stream));
@@ -245,6 +254,7 @@ extern "C" int wsr_conv3d_dgrad_tile(const wsr_conv_t* c, const void* dy, const 
   a.wf = (const unsigned short*)wfrag_t;
   a.out = dx;
   a.alpha = alpha;
+  a.act_c1 = 0x7FFFFFFF;
   a.out_planar = dx_planar ? 1 : 0;
   if (accumulate) {
     if (dx_planar) return WSR_EUNSUPPORTED;

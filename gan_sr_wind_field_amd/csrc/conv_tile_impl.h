@@ -41,7 +41,8 @@ struct CtArgs {
   const unsigned short* res;
   int res_ctot, res_off;
   float alpha, beta, slope;
-  int act, out_planar;
+  int act, out_planar;            // act: 0 none, 1 LeakyReLU, 2 LeakyReLU after the residual add
+  int act_c1;                     // bias + activation apply to channels < act_c1 (others: raw sums)
   int B, Xi, Yi, Zi, Xo, Yo, Zo, ups;
   int in_ctot, in_off, nchunks;   // reduction channels = nchunks * CK, window [in_off, ...)
   int cin_valid;                  // channels of the window that exist in memory (multiple of 8)
@@ -378,7 +379,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_tile_kernel(const CtArgs a)
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const bool in = co0 + q < a.Cout;
-      bb[s][q] = (a.bias && in) ? a.bias[co0 + q] : 0.f;
+      bb[s][q] = (a.bias && in && co0 + q < a.act_c1) ? a.bias[co0 + q] : 0.f;
       ss[s][q] = ((a.chan_scale && in) ? a.chan_scale[(long)b * a.Cout + co0 + q] : 1.f) * a.alpha;
     }
     if (!fast || co0 >= a.Cout) return;
@@ -406,10 +407,24 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_tile_kernel(const CtArgs a)
     for (int i = 0; i < TM; ++i) {
       if (mrow[i] < 0) continue;
       float v[4];
+      const bool act_here = a.act && co0 < a.act_c1;  // (act_c1 is a multiple of 4)
+      if (fast && a.act == 2) {  // second stage of a split conv: the partial sums in `res` join before the activation
+        const float r4[4] = {bf2f((unsigned short)(rr[s][i].x & 0xFFFFu)), bf2f((unsigned short)(rr[s][i].x >> 16)),
+                             bf2f((unsigned short)(rr[s][i].y & 0xFFFFu)), bf2f((unsigned short)(rr[s][i].y >> 16))};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          float x = acc[i][j][q] + bb[s][q] + a.beta * r4[q];
+          x = x > 0.f ? x : x * a.slope;
+          v[q] = x * ss[s][q];
+        }
+        st4<BF16>(reinterpret_cast<unsigned short*>(a.out) + mrow[i] * a.out_ctot + a.out_off + co0,
+                  make_float4(v[0], v[1], v[2], v[3]));
+        continue;
+      }
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         float x = acc[i][j][q] + bb[s][q];
-        if (a.act) x = x > 0.f ? x : x * a.slope;
+        if (act_here) x = x > 0.f ? x : x * a.slope;
         v[q] = x * ss[s][q];
       }
       if (fast) {

@@ -32,6 +32,9 @@ Tensor = torch.Tensor
 #: debugging aid (tests set it): allocate work buffers filled with NaN instead of uninitialised
 #: group the input gradients of a dense block by produced window (WSR_STACK_DGRAD=0: one launch per conv)
 STACK_DGRAD = __import__("os").environ.get("WSR_STACK_DGRAD", "1") != "0"
+#: split the growth convs of a dense block into one conv over the block input + narrow convs over the growth
+#: channels (WSR_STACK_FWD=0: one launch per conv over its whole input window)
+STACK_FWD = __import__("os").environ.get("WSR_STACK_FWD", "1") != "0"
 #: run the last conv of the generator in its z-folded form (WSR_ZFOLD=0: plain 5x5x5 conv with 3 outputs)
 ZFOLD = __import__("os").environ.get("WSR_ZFOLD", "1") != "0"
 POISON_BUFFERS = bool(int(__import__("os").environ.get("WSR_POISON_BUFFERS", "0")))
@@ -90,8 +93,9 @@ class FilterCache:
         """Re-pack, in ONE launch, the fragment-order copies among ``wanted`` = [(param, transpose)] when any
         of them is stale (after an optimizer step that is all ~600 filters of the generator).  The device job
         table is cached: it only holds pointers, which stay put while parameters and copies keep their storage.
-        ``stacked`` = [(key, parts, rows, red_total)] adds the stacked input-gradient filters of dense blocks
-        (``parts`` = [(param, c_lo, c_n, red_off)], see ``wsr_pack_job_t``); fetch them with :meth:`get_stacked`."""
+        ``stacked`` = [(key, parts, rows, red_total)] adds the stacked filters of dense blocks (``parts`` =
+        [(param, transpose, c_lo, c_n, red_off, row_off)], see ``wsr_pack_job_t``); fetch them with
+        :meth:`get_stacked`."""
         # cheap staleness probe first: one pass over the versions (an optimizer step bumps all of them)
         kind = ("pack", len(wanted), sum(1 for _, tr in wanted if tr), len(stacked))
         probe = (sum(p._version for p, _ in wanted), wanted[0][0].data_ptr(), wanted[-1][0].data_ptr())
@@ -119,11 +123,11 @@ class FilterCache:
                 hit = self._c.get((skey, "dstack"))
                 out = hit[1] if hit is not None and hit[1].numel() == n and hit[1].device == w0.device else \
                     torch.empty(n, dtype=torch.bfloat16, device=w0.device)
-                for p, c_lo, c_n, red_off in parts:
+                for p, tr, c_lo, c_n, red_off, row_off in parts:
                     w = p.detach()
                     if not w.is_contiguous():
                         raise ValueError("conv filters must be contiguous")
-                    jobs.append((w, out, True, c_lo, c_n, red_off, red_total))
+                    jobs.append((w, out, tr, c_lo, c_n, red_off, red_total, row_off, rows))
                 outs.append(out)
             cached = (key, ops.pack_job_table(jobs), outs)
             self._tables[kind] = cached
@@ -222,6 +226,7 @@ class ProgramBase:
         self._unpack_tables: Dict[tuple, Tensor] = {}
         self._scratch_elems_total = 0
         self._stack_specs = None
+        self._stack_fwd_specs = None
 
     def cp(self, c: int) -> int:
         """channel count padded to whole 16-byte pieces"""
@@ -233,15 +238,21 @@ class ProgramBase:
         if not (self.use_tile and self.dt == torch.bfloat16):
             return
         sites = [s for s in self.conv_sites() if self.tile_ok(s)]
-        wanted = [(s.weight, False) for s in sites]
-        stacked = ()
+        fstack = list(self.stacked_fwd_specs())
+        fcov = {id(p) for _, parts, _, _ in fstack for p, *_ in parts}
+        wanted = [(s.weight, False) for s in sites if id(s.weight) not in fcov]
+        stacked = fstack
         if backward:
-            stacked = self.stacked_dgrad_specs()
-            covered = {id(p) for _, parts, _, _ in stacked for p, *_ in parts}
+            dstack = list(self.stacked_dgrad_specs())
+            covered = {id(p) for _, parts, _, _ in dstack for p, *_ in parts}
             wanted += [(s.weight, True) for s in sites if id(s.weight) not in covered]
+            stacked = fstack + dstack
         self.filters.refresh_frags(wanted, stacked)
 
     def stacked_dgrad_specs(self):
+        return ()
+
+    def stacked_fwd_specs(self):
         return ()
 
     def conv_sites(self) -> Sequence[ConvSite]:
@@ -354,7 +365,7 @@ class ProgramBase:
     # arithmetic, a third of the traffic, longer reductions.  Windows go last to first because window
     # w's result (after its LeakyReLU mask) is the output gradient of conv w-1.
     def dense_stackable(self, convs: Sequence[ConvSite]) -> bool:
-        if not (STACK_DGRAD and self.use_tile and self.dt == torch.bfloat16 and len(convs) > 1):
+        if not (self.use_tile and self.dt == torch.bfloat16 and len(convs) > 1):
             return False
         nf, gc = convs[0].cin, convs[0].cout
         return (gc % 16 == 0 and nf % 16 == 0 and gc <= 64 and nf <= 256 and convs[0].taps > 1 and all(
@@ -369,8 +380,60 @@ class ProgramBase:
 
     def dense_dgrad_specs(self, convs: Sequence[ConvSite]):
         gc = convs[0].cout
-        return [((id(convs[0].weight), w), [(convs[i].weight, c_lo, c_n, (i - w) * gc) for i in range(w, len(convs))],
+        return [((id(convs[0].weight), w),
+                 [(convs[i].weight, True, c_lo, c_n, (i - w) * gc, 0) for i in range(w, len(convs))],
                  c_n, red) for w, c_lo, c_n, red in self.dense_windows(convs)]
+
+    # ---- split forward of a dense block --------------------------------------------------------------
+    # Every growth conv reads the block input (channels [0, nf)); that part of all nc convs is ONE conv with
+    # nc*gc outputs - a 512-voxel x 128-channel tile runs at ~1.0 PFLOP/s where the 32-output kernels reach
+    # ~0.75 - whose raw sums land in the growth windows (bias + LeakyReLU only on conv 0, which has no other
+    # input).  Conv i >= 1 then only adds its reduction over the growth channels [nf, nf + i*gc) and applies
+    # bias + LeakyReLU after the sum (`act = 2`).  The partial sums pass through bf16 once.
+    def dense_fwd_specs(self, convs: Sequence[ConvSite]):
+        nf, gc, nc = convs[0].cin, convs[0].cout, len(convs)
+        specs = [((id(convs[0].weight), "pre"), [(c.weight, False, 0, nf, 0, i * gc) for i, c in enumerate(convs)],
+                  nc * gc, nf)]
+        specs += [((id(convs[0].weight), "grow", i), [(convs[i].weight, False, nf, i * gc, 0, 0)], gc, i * gc)
+                  for i in range(1, nc)]
+        return specs
+
+    def conv_dense(self, convs: Sequence[ConvSite], buf: Tensor) -> bool:
+        """all growth convs of a block on ``buf`` (block input in channels [0, nf)); False = nothing was
+        launched (shape outside the tile kernels) and the caller runs the convs one by one"""
+        nf, gc, nc = convs[0].cin, convs[0].cout, len(convs)
+        B, ctot = buf.shape[0], buf.shape[-1]
+        xyz = tuple(buf.shape[1:4])
+        k, pad, sl = convs[0].kernel, convs[0].pad, self.slope
+        d = ops.make_desc(ConvGeom(nf, nc * gc, k, (1, 1, 1), pad), self.dt, B, xyz, ctot, 0, ctot, nf)
+        b0 = convs[0].bias.detach() if convs[0].bias is not None else None
+        pre = self.filters.get_stacked((id(convs[0].weight), "pre"))
+        done = []
+
+        def run_pre():
+            done.append(ops.conv_fwd_tile(d, buf, pre, buf, bias=b0, act=True, slope=sl, act_c1=gc))
+
+        if self.launch_probe is not None:
+            self.launch_probe("fwd_dense_pre:" + convs[0].name, run_pre)
+        else:
+            run_pre()
+        if not done[0]:
+            return False
+        for i in range(1, nc):
+            di = ops.make_desc(ConvGeom(i * gc, gc, k, (1, 1, 1), pad), self.dt, B, xyz, ctot, nf, ctot, nf + i * gc)
+            bi = convs[i].bias.detach() if convs[i].bias is not None else None
+            fr = self.filters.get_stacked((id(convs[0].weight), "grow", i))
+
+            def run(di=di, bi=bi, fr=fr, off=nf + i * gc):
+                if not ops.conv_fwd_tile(di, buf, fr, buf, bias=bi, res=buf, res_off=off, beta=1.0, act=2, slope=sl):
+                    raise RuntimeError("split dense-block conv: second stage outside the tile kernels "
+                                       "(set WSR_STACK_FWD=0)")
+
+            if self.launch_probe is not None:
+                self.launch_probe(f"fwd_dense_grow{i}:" + convs[0].name, run)
+            else:
+                run()
+        return True
 
     def dgrad_dense(self, convs: Sequence[ConvSite], gd: Tensor, buf: Tensor, in_xyz) -> None:
         """gd[..., :nf + (nc-1)*gc] += input gradients of all growth convs (gd[..., nf + i*gc:][:gc] = output
@@ -561,8 +624,9 @@ class GeneratorProgram(ProgramBase):
         for rdbs, rr_scale in zip(self.rrdbs, self.rrdb_scales):
             rr_in = buf
             for convs, lff, rdb_scale in rdbs:
-                for i, c in enumerate(convs):
-                    self.conv(c, buf, 0, buf, nf + i * gc, act=True, slope=sl)
+                if not (STACK_FWD and self.dense_stackable(convs) and self.conv_dense(convs, buf)):
+                    for i, c in enumerate(convs):
+                        self.conv(c, buf, 0, buf, nf + i * gc, act=True, slope=sl)
                 seen += 1
                 nb = self._empty((B, X, Y, nz, nf if seen == total_rdbs else dense), x)
                 # x + rdb_scale * (LFF(dense) + b)
@@ -726,7 +790,7 @@ class GeneratorProgram(ProgramBase):
                 last = nf + (nc - 1) * gc
                 self.dgrad(lff, go, 0, gd, 0, (X, Y, nz), alpha=rdb_scale,
                            mask=(buf, last, last, last + gc) if nc else None)
-                if self.dense_stackable(convs):
+                if STACK_DGRAD and self.dense_stackable(convs):
                     self.dgrad_dense(convs, gd, buf, (X, Y, nz))
                 else:
                     for i in reversed(range(nc)):
@@ -748,10 +812,18 @@ class GeneratorProgram(ProgramBase):
             self.grad_done_hook()
         return flat
 
+    def stacked_fwd_specs(self):
+        key = (self.use_tile, STACK_FWD)
+        if self._stack_fwd_specs is None or self._stack_fwd_specs[0] != key:
+            specs = [sp for rdbs in self.rrdbs for convs, _, _ in rdbs if STACK_FWD and self.dense_stackable(convs)
+                     for sp in self.dense_fwd_specs(convs)]
+            self._stack_fwd_specs = (key, specs)
+        return self._stack_fwd_specs[1]
+
     def stacked_dgrad_specs(self):
         key = (self.use_tile, STACK_DGRAD)
         if self._stack_specs is None or self._stack_specs[0] != key:
-            specs = [sp for rdbs in self.rrdbs for convs, _, _ in rdbs if self.dense_stackable(convs)
+            specs = [sp for rdbs in self.rrdbs for convs, _, _ in rdbs if STACK_DGRAD and self.dense_stackable(convs)
                      for sp in self.dense_dgrad_specs(convs)]
             self._stack_specs = (key, specs)
         return self._stack_specs[1]

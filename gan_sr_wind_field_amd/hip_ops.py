@@ -109,10 +109,11 @@ def conv_fwd(desc: ConvDesc, x: Tensor, w: Tensor, y: Tensor, *, bias: Optional[
 
 def conv_fwd_tile(desc: ConvDesc, x: Tensor, wfrag: Tensor, y: Tensor, *, bias: Optional[Tensor] = None,
                   chan_scale: Optional[Tensor] = None, res: Optional[Tensor] = None, res_off: int = 0,
-                  alpha: float = 1.0, beta: float = 0.0, act: bool = False, slope: float = 0.2,
-                  out_planar: bool = False) -> bool:
+                  alpha: float = 1.0, beta: float = 0.0, act=False, slope: float = 0.2,
+                  out_planar: bool = False, act_c1: int = 0) -> bool:
     """LDS halo-tile forward conv (bf16, stride 1).  Returns False when the shape is outside
-    the tile kernels (the caller then uses :func:`conv_fwd`)."""
+    the tile kernels (the caller then uses :func:`conv_fwd`).  ``act`` = 2 / ``act_c1``: the two stages of a
+    split dense-block conv (see ``wsr_epilogue_t``)."""
     _need_cuda(x, wfrag, y, bias, chan_scale, res)
     ep = Epilogue()
     ep.bias, ep.chan_scale, ep.res = _p(bias), _p(chan_scale), _p(res)
@@ -121,6 +122,7 @@ def conv_fwd_tile(desc: ConvDesc, x: Tensor, wfrag: Tensor, y: Tensor, *, bias: 
     ep.alpha, ep.beta = alpha, beta
     ep.act, ep.slope = int(act), slope
     ep.out_planar = int(out_planar)
+    ep.act_c1 = act_c1
     rc = _lib.lib().wsr_conv3d_fwd_tile(C.byref(desc), _p(x), _p(wfrag), _p(y), C.byref(ep), _stream())
     if rc == _lib.WSR_EUNSUPPORTED:
         return False
@@ -175,11 +177,12 @@ def frag_filter_elems_for(rows: int, red: int, taps: int) -> int:
 
 def pack_job_table(jobs) -> Tensor:
     """Device table of ``wsr_pack_job_t`` records for ``jobs`` = [(master fp32 weight, out bf16 tensor, transpose)]
-    or, for one source of a stacked dense-block input-gradient filter, [(weight, out, True, c_lo, c_n, red_off,
-    red_total)].  The table only holds pointers and shapes, so it stays valid while those tensors keep their storage."""
+    or, for one source of a stacked dense-block filter, [(weight, out, transpose, c_lo, c_n, red_off, red_total,
+    row_off, rows_total)].  The table only holds pointers and shapes, so it stays valid while those tensors keep
+    their storage."""
     import numpy as np
 
-    rec = np.zeros((len(jobs), 7), dtype=np.int64)  # 2 pointers + 10 int32
+    rec = np.zeros((len(jobs), 8), dtype=np.int64)  # 2 pointers + 12 int32
     for r, job in zip(rec, jobs):
         w, out, tr = job[:3]
         cout, cin, kx, ky, kz = w.shape
@@ -188,12 +191,17 @@ def pack_job_table(jobs) -> Tensor:
         r[3] = kx | (ky << 32)
         r[4] = kz | (int(tr) << 32)
         if len(job) > 3:
-            c_lo, c_n, red_off, red_total = job[3:]
-            if not tr or cout % 16 or red_off % 16 or red_total % 16 or c_lo < 0 or c_lo + c_n > cin \
-                    or red_off + cout > red_total:
+            c_lo, c_n, red_off, red_total, row_off, rows_total = job[3:]
+            bad = cout % 16 or red_total % 16 or c_lo < 0 or c_lo + c_n > cin
+            if tr:
+                bad = bad or red_off % 16 or red_off + cout > red_total or rows_total != c_n
+            else:
+                bad = bad or red_off or red_total != c_n or row_off % 16 or row_off + cout > rows_total
+            if bad:
                 raise ValueError("bad stacked filter part")
             r[5] = c_lo | (c_n << 32)
             r[6] = red_off | (red_total << 32)
+            r[7] = row_off | (rows_total << 32)
     return torch.from_numpy(rec).to(jobs[0][0].device)
 
 

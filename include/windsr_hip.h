@@ -64,9 +64,13 @@ typedef struct wsr_epilogue {
   const void* res;          /* NDHWC tensor of `dtype`, or NULL                 */
   int32_t res_ctot, res_off;
   float alpha, beta;
-  int32_t act;              /* 0 none, 1 leaky-relu                             */
+  int32_t act;              /* 0 none, 1 leaky-relu, 2 leaky-relu AFTER the residual: y = alpha*lrelu(acc + bias +
+                               beta*res) (tile kernels only) - the second stage of a split dense-block conv whose
+                               partial sums over the block input are already in `res` (= the output window) */
   float slope;
   int32_t out_planar;       /* 1: y is fp32 planar (B, Cout, Xo, Yo, Zo)        */
+  int32_t act_c1;           /* > 0 (tile kernels only): bias and activation apply to channels < act_c1 only, the rest
+                               are stored as raw sums - the first stage of a split dense-block conv            */
 } wsr_epilogue_t;
 
 int wsr_abi_version(void);
@@ -118,13 +122,16 @@ typedef struct wsr_pack_job {
   const float* w;  /* master (Cout, Cin, KX, KY, KZ) fp32 */
   void* out;       /* wsr_frag_filter_elems(...) bf16 elements */
   int32_t Cout, Cin, KX, KY, KZ, transpose;
-  /* Stacked input-gradient filter of a residual dense block (torch_blocks.py:256-267), red_total > 0 and
-   * transpose = 1 only: the destination is the filter of ONE virtual conv whose reduction axis is the
-   * concatenation of the output channels of several growth convs (red_total of them, this job fills
-   * reduction channels [red_off, red_off + Cout)) and whose rows are input channels [c_lo, c_lo + c_n) of
-   * this job's conv.  Jobs of one destination write disjoint parts of it; red_off and Cout must be
-   * multiples of 16.  red_total = 0: a plain filter (the fields above).                              */
-  int32_t c_lo, c_n, red_off, red_total;
+  /* Sub-block of a stacked filter of a residual dense block (torch_blocks.py:256-267), red_total > 0: the
+   * destination is the filter of ONE virtual conv with rows_total rows and red_total reduction channels,
+   * several jobs fill disjoint parts of it.
+   *   transpose = 1 (stacked input gradient): this conv's output channels are reduction channels
+   *     [red_off, red_off + Cout) and its input channels [c_lo, c_lo + c_n) the rows (rows_total = c_n);
+   *   transpose = 0 (split forward conv): this conv's output channels are rows [row_off, row_off + Cout) and
+   *     its input channels [c_lo, c_lo + c_n) the whole reduction axis (red_total = c_n, red_off = 0).
+   * Offsets and extents that index whole chunks / n-tiles must be multiples of 16.  red_total = 0: a plain
+   * filter (the fields above).                                                                        */
+  int32_t c_lo, c_n, red_off, red_total, row_off, rows_total;
 } wsr_pack_job_t;
 int wsr_pack_filter_frag_multi(const wsr_pack_job_t* jobs_dev, int32_t n_jobs, void* stream);
 

@@ -363,3 +363,43 @@ def test_generator_bf16_zfolded_last_conv(hip, monkeypatch):
     assert rel_l2(res[True][0], res[False][0]) < 1e-5
     for k in res[True][1]:
         assert rel_l2(res[True][1][k], res[False][1][k]) < 2e-2, k
+
+
+@pytest.mark.parametrize("nf,gc,n_rrdb", [(32, 16, 1), (128, 32, 1)])
+def test_generator_bf16_split_dense_forward(hip, monkeypatch, nf, gc, n_rrdb):
+    """Growth convs of a dense block as one conv over the block input + narrow second stages
+    (engine.conv_dense) against one launch per conv: outputs and gradients at the bf16 distance from the
+    fp32 program, and the stacked filters follow a parameter update."""
+    from gan_sr_wind_field_amd import engine
+
+    spec = onets.GSpec(upscale=4, in_channels=4, out_channels=3, nf=nf, n_rrdb=n_rrdb, hr_kern=5, gc=gc, tf=8)
+    LR, HR, Z, x, y = ogan.synthetic_batch(1, 8, 6, 4, seed=41)
+    gy = torch.randn(1, 3, 32, 32, 6, generator=torch.Generator().manual_seed(6)).to(DEV)
+    res, tags = {}, {}
+    for mode in ("fp32", "split", "perconv"):
+        monkeypatch.setattr(engine, "STACK_FWD", mode != "perconv")
+        G, _ = build_G(spec, torch.float32 if mode == "fp32" else torch.bfloat16, 27)
+        G.eval()
+        seen = []
+        G.program().launch_probe = lambda tag, fn: (seen.append(tag.split(":")[0]), fn())
+        out = G(LR.to(DEV), Z.to(DEV))
+        (out * gy).sum().backward()
+        tags[mode] = list(seen)
+        res[mode] = (out.detach(), {k: p.grad.clone() for k, p in G.named_parameters()})
+        if mode == "split":
+            with torch.no_grad():
+                for p in G.parameters():
+                    p.mul_(0.8)
+            o2 = G(LR.to(DEV), Z.to(DEV)).detach()
+            monkeypatch.setattr(engine, "STACK_FWD", False)
+            assert rel_l2(o2, G(LR.to(DEV), Z.to(DEV)).detach()) < 2e-2
+    n_rdb = 3 * n_rrdb
+    assert sum(t == "fwd_dense_pre" for t in tags["split"]) == n_rdb
+    assert sum(t.startswith("fwd_dense_grow") for t in tags["split"]) == 3 * n_rdb
+    assert not any(t.startswith("fwd_dense") for t in tags["perconv"] + tags["fp32"])
+    e_s, e_p = rel_l2(res["split"][0], res["fp32"][0]), rel_l2(res["perconv"][0], res["fp32"][0])
+    assert e_s < max(1.5 * e_p, 1e-2), (e_s, e_p)
+    for k in res["fp32"][1]:
+        e_s = rel_l2(res["split"][1][k], res["fp32"][1][k])
+        e_p = rel_l2(res["perconv"][1][k], res["fp32"][1][k])
+        assert e_s < max(1.5 * e_p, 2e-2), (k, e_s, e_p)
