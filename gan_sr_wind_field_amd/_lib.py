@@ -40,6 +40,7 @@ class Epilogue(C.Structure):
         ("bias", C.c_void_p), ("chan_scale", C.c_void_p), ("res", C.c_void_p),
         ("res_ctot", C.c_int32), ("res_off", C.c_int32), ("alpha", C.c_float), ("beta", C.c_float),
         ("act", C.c_int32), ("slope", C.c_float), ("out_planar", C.c_int32), ("act_c1", C.c_int32),
+        ("res2", C.c_void_p), ("res2_ctot", C.c_int32), ("res2_off", C.c_int32), ("beta2", C.c_float),
     ]
 
 

@@ -22,7 +22,10 @@ struct C1Args {
   unsigned short* out;
   const float* bias;
   const unsigned short* res;
-  int res_ctot, res_off;
+  int res_ctot, res_off, res_c1;  // residual on produced channels < res_c1 only
+  const unsigned short* res2;     // second residual (all produced channels), or NULL
+  int res2_ctot, res2_off;
+  float beta2;
   float alpha, beta, slope;
   int act;
   long nvox;
@@ -33,15 +36,15 @@ struct C1Args {
   float mask_slope;
 };
 
-template <int TN, int TM, int KS, bool MASK>
-__global__ __launch_bounds__(256) void conv1x1_kernel(const C1Args a) {
+template <int TN, int TM, int KS, bool MASK, int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void conv1x1_kernel(const C1Args a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];  // KS * TN fragments of 1 KB
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int fr = lane & 15, fg = lane >> 4;
   {  // stage the filter: linear copy of KS*TN KB
     const uint4* src = reinterpret_cast<const uint4*>(a.wf);
     uint4* dst = reinterpret_cast<uint4*>(smem);
-    for (int i = t; i < KS * TN * 64; i += 256) dst[i] = src[i];
+    for (int i = t; i < KS * TN * 64; i += WAVES * 64) dst[i] = src[i];
   }
   __syncthreads();
   const char* wl = smem + lane * 16;
@@ -50,7 +53,7 @@ __global__ __launch_bounds__(256) void conv1x1_kernel(const C1Args a) {
   // store - a load placed after a store cannot be hoisted by the compiler (possible aliasing) and would
   // cost a memory round trip per tile.  (Prefetching the next strip's fragments into a second register set
   // was measured slower: 128 more VGPRs spill.)
-  const int stride = gridDim.x * 4;
+  const int stride = gridDim.x * WAVES;
   auto load_x = [&](int strip, uint4 (&xf)[KS][TM]) {
     const long v0 = (long)strip * (16 * TM);
 #pragma unroll
@@ -68,7 +71,7 @@ __global__ __launch_bounds__(256) void conv1x1_kernel(const C1Args a) {
     // of the strip (input-gradient launches) are requested here, before any store.
     f32x4_t acc[TM][TN];
     uint2 yy[TM][MASK ? TN : 1];
-    const float rscale = a.res ? a.beta / a.alpha : 0.f;
+    const float rscale = a.res ? a.beta / a.alpha : 0.f, rscale2 = a.res2 ? a.beta2 / a.alpha : 0.f;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
       const long v = v0 + 16 * i + fr;
@@ -79,12 +82,19 @@ __global__ __launch_bounds__(256) void conv1x1_kernel(const C1Args a) {
         const bool ok = vok && co0 < a.Cout;
         float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
         if (a.bias && co0 < a.Cout) b4 = *reinterpret_cast<const float4*>(a.bias + co0);
-        if (a.res && ok) {
+        if (a.res && ok && co0 < a.res_c1) {
           const uint2 r2 = *reinterpret_cast<const uint2*>(a.res + v * a.res_ctot + a.res_off + co0);
           b4.x += rscale * bf2f((unsigned short)(r2.x & 0xFFFFu));
           b4.y += rscale * bf2f((unsigned short)(r2.x >> 16));
           b4.z += rscale * bf2f((unsigned short)(r2.y & 0xFFFFu));
           b4.w += rscale * bf2f((unsigned short)(r2.y >> 16));
+        }
+        if (a.res2 && ok) {
+          const uint2 r2 = *reinterpret_cast<const uint2*>(a.res2 + v * a.res2_ctot + a.res2_off + co0);
+          b4.x += rscale2 * bf2f((unsigned short)(r2.x & 0xFFFFu));
+          b4.y += rscale2 * bf2f((unsigned short)(r2.x >> 16));
+          b4.z += rscale2 * bf2f((unsigned short)(r2.y & 0xFFFFu));
+          b4.w += rscale2 * bf2f((unsigned short)(r2.y >> 16));
         }
         acc[i][j] = f32x4_t{b4.x, b4.y, b4.z, b4.w};
         if constexpr (MASK) {
@@ -131,7 +141,7 @@ __global__ __launch_bounds__(256) void conv1x1_kernel(const C1Args a) {
       }
     }
   };
-  for (int strip = blockIdx.x * 4 + wave; strip < a.nstrips; strip += stride) {
+  for (int strip = blockIdx.x * WAVES + wave; strip < a.nstrips; strip += stride) {
     uint4 xa[KS][TM];
     load_x(strip, xa);
     do_strip(strip, xa);
@@ -143,7 +153,8 @@ int launch_c1(const C1Args& a0, hipStream_t st) {
   C1Args a = a0;
   a.nstrips = (int)((a.nvox + 16 * TM - 1) / (16 * TM));
   const size_t lds = (size_t)KS * TN * 1024;
-  auto kern = conv1x1_kernel<TN, TM, KS, MASK>;
+  constexpr int WAVES = 4;  // (8 waves halve the register budget: the up-front loads of a strip then spill)
+  auto kern = conv1x1_kernel<TN, TM, KS, MASK, WAVES>;
   static bool attr_done = false;
   if (!attr_done) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -151,10 +162,10 @@ int launch_c1(const C1Args& a0, hipStream_t st) {
     if (e != hipSuccess) return (int)e;
     attr_done = true;
   }
-  int grid = (a.nstrips + 3) / 4;
+  int grid = (a.nstrips + WAVES - 1) / WAVES;
   const int cap = getenv("WSR_C1_GRID") ? atoi(getenv("WSR_C1_GRID")) : 256;  // one workgroup per CU measured best (tuning aid)
   if (grid > cap) grid = cap;  // the filter is staged once per workgroup
-  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds, st, a);
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(WAVES * 64), lds, st, a);
   WSR_LAUNCH_CHECK();
   return 0;
 }
@@ -165,14 +176,17 @@ int launch_c1(const C1Args& a0, hipStream_t st) {
 // `red` = reduction channels (multiple of 32), `n_out` = produced channels.
 int wsr_conv1x1_bf16(const unsigned short* in, int in_ctot, int in_off, int red, const unsigned short* wfrag,
                      unsigned short* out, int out_ctot, int out_off, int n_out, long nvox, const float* bias,
-                     const unsigned short* res, int res_ctot, int res_off, float alpha, float beta, int act,
-                     float slope, const wsr_lrelu_mask_t* mask, hipStream_t st) {
+                     const unsigned short* res, int res_ctot, int res_off, int res_c1, float alpha, float beta, int act,
+                     float slope, const wsr_lrelu_mask_t* mask, const unsigned short* res2, int res2_ctot, int res2_off,
+                     float beta2, hipStream_t st) {
   if (red % 32 || red > 256 || n_out % 4 || n_out > 256) return WSR_EUNSUPPORTED;
   if (in_ctot % 8 || in_off % 8 || out_ctot % 4 || out_off % 4 || (res && (res_ctot % 4 || res_off % 4)))
     return WSR_EUNSUPPORTED;
   C1Args a{};
   a.in = in; a.wf = wfrag; a.out = out; a.bias = bias; a.res = res;
-  a.res_ctot = res_ctot; a.res_off = res_off;
+  a.res_ctot = res_ctot; a.res_off = res_off; a.res_c1 = res_c1;
+  a.res2 = res2; a.res2_ctot = res2_ctot; a.res2_off = res2_off; a.beta2 = beta2;
+  if (res2 && (res2_ctot % 4 || res2_off % 4)) return WSR_EUNSUPPORTED;
   a.alpha = alpha; a.beta = beta; a.slope = slope; a.act = act;
   a.nvox = nvox;
   a.in_ctot = in_ctot; a.in_off = in_off; a.out_ctot = out_ctot; a.out_off = out_off; a.Cout = n_out;
@@ -184,7 +198,7 @@ int wsr_conv1x1_bf16(const unsigned short* in, int in_ctot, int in_off, int red,
   }
   if (n_out % 16) return WSR_EUNSUPPORTED;  // the fragment-order filter must have exactly TN n-tiles
   const int nt = n_out / 16, ks = red / 32;
-  if (a.res && (a.act || a.alpha == 0.f)) return WSR_EUNSUPPORTED;  // residual is folded into the accumulator start
+  if ((a.res || a.res2) && (a.act || a.alpha == 0.f)) return WSR_EUNSUPPORTED;  // residuals are folded into the accumulator start
   if (a.bias && ((size_t)a.bias & 15)) return WSR_EUNSUPPORTED;
   if (!mask) {
     if (nt == 8 && ks == 8) return launch_c1<8, 2, 8, false>(a, st);    // 256 -> 128 (LFF forward)

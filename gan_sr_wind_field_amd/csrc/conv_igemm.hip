@@ -376,7 +376,7 @@ extern "C" int wsr_conv3d_fwd(const wsr_conv_t* c, const void* x, const void* w,
     a.alpha = ep->alpha;
     a.beta = ep->beta;
     a.slope = ep->slope;
-    if (ep->act > 1 || ep->act_c1 > 0) return WSR_EUNSUPPORTED;  // split dense-block stages: tile kernels only
+    if (ep->act > 1 || ep->act_c1 > 0 || ep->res2) return WSR_EUNSUPPORTED;  // tile / streaming kernels only
     a.act = ep->act;
     a.out_planar = ep->out_planar;
     if (a.res && (a.res_off < 0 || a.res_off + c->Cout > a.res_ctot)) return WSR_EINVAL;

@@ -196,8 +196,9 @@ static int run_conv_tile(CtArgs& a, int red, hipStream_t st) {
 
 int wsr_conv1x1_bf16(const unsigned short* in, int in_ctot, int in_off, int red, const unsigned short* wfrag,
                      unsigned short* out, int out_ctot, int out_off, int n_out, long nvox, const float* bias,
-                     const unsigned short* res, int res_ctot, int res_off, float alpha, float beta, int act,
-                     float slope, const wsr_lrelu_mask_t* mask, hipStream_t st);  // conv_1x1.hip
+                     const unsigned short* res, int res_ctot, int res_off, int res_c1, float alpha, float beta, int act,
+                     float slope, const wsr_lrelu_mask_t* mask, const unsigned short* res2, int res2_ctot, int res2_off,
+                     float beta2, hipStream_t st);  // conv_1x1.hip
 
 extern "C" int wsr_conv3d_fwd_tile(const wsr_conv_t* c, const void* x, const void* wfrag, void* y,
                                    const wsr_epilogue_t* ep, void* stream) {
@@ -214,6 +215,7 @@ extern "C" int wsr_conv3d_fwd_tile(const wsr_conv_t* c, const void* x, const voi
     a.res = (const unsigned short*)ep->res;
     a.res_ctot = ep->res_ctot;
     a.res_off = ep->res_off;
+    a.res_c1 = 0x7FFFFFFF;
     a.alpha = ep->alpha;
     a.beta = ep->beta;
     a.slope = ep->slope;
@@ -234,9 +236,12 @@ extern "C" int wsr_conv3d_fwd_tile(const wsr_conv_t* c, const void* x, const voi
       a.act <= 1 && a.act_c1 == 0x7FFFFFFF) {
     const int rc = wsr_conv1x1_bf16(a.in, a.in_ctot, a.in_off, c->Cin, a.wf, (unsigned short*)a.out, a.out_ctot,
                                     a.out_off, a.Cout, (long)c->B * c->Xo * c->Yo * c->Zo, a.bias, a.res, a.res_ctot,
-                                    a.res_off, a.alpha, a.beta, a.act, a.slope, nullptr, as_stream(stream));
+                                    a.res_off, a.res ? a.res_c1 : 0, a.alpha, a.beta, a.act, a.slope, nullptr,
+                                    ep ? (const unsigned short*)ep->res2 : nullptr, ep ? ep->res2_ctot : 0,
+                                    ep ? ep->res2_off : 0, ep ? ep->beta2 : 0.f, as_stream(stream));
     if (rc != WSR_EUNSUPPORTED) return rc;
   }
+  if (ep && ep->res2) return WSR_EUNSUPPORTED;  // only the streaming kernel takes a second residual
   return run_conv_tile(a, c->Cin, as_stream(stream));
 }
 
@@ -256,11 +261,13 @@ extern "C" int wsr_conv3d_dgrad_tile(const wsr_conv_t* c, const void* dy, const 
   a.alpha = alpha;
   a.act_c1 = 0x7FFFFFFF;
   a.out_planar = dx_planar ? 1 : 0;
-  if (accumulate) {
+  if (accumulate) {  // 1: every produced channel; n > 1: the first n (a multiple of 4) only
     if (dx_planar) return WSR_EUNSUPPORTED;
+    if (accumulate > 1 && (accumulate & 3)) return WSR_EINVAL;
     a.res = (const unsigned short*)dx;
     a.res_ctot = c->in_ctot;
     a.res_off = c->in_off;
+    a.res_c1 = accumulate > 1 ? accumulate : 0x7FFFFFFF;
     a.beta = 1.f;
   }
   a.B = c->B;
@@ -274,7 +281,8 @@ extern "C" int wsr_conv3d_dgrad_tile(const wsr_conv_t* c, const void* dy, const 
   if (c->KX * c->KY * c->KZ == 1 && ux == 1 && !a.out_planar && (c->px | c->py | c->pz) == 0) {
     const int rc = wsr_conv1x1_bf16(a.in, a.in_ctot, a.in_off, c->Cout, a.wf, (unsigned short*)a.out, a.out_ctot,
                                     a.out_off, a.Cout, (long)c->B * c->Xo * c->Yo * c->Zo, nullptr, a.res, a.res_ctot,
-                                    a.res_off, a.alpha, a.beta, 0, 0.f, mask, as_stream(stream));
+                                    a.res_off, a.res ? a.res_c1 : 0, a.alpha, a.beta, 0, 0.f, mask, nullptr, 0, 0, 0.f,
+                                    as_stream(stream));
     if (rc != WSR_EUNSUPPORTED) return rc;
   }
   if (mask) {

@@ -39,7 +39,7 @@ struct CtArgs {
   const float* bias;
   const float* chan_scale;
   const unsigned short* res;
-  int res_ctot, res_off;
+  int res_ctot, res_off, res_c1;  // residual on produced channels < res_c1 only
   float alpha, beta, slope;
   int act, out_planar;            // act: 0 none, 1 LeakyReLU, 2 LeakyReLU after the residual add
   int act_c1;                     // bias + activation apply to channels < act_c1 (others: raw sums)
@@ -391,7 +391,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_tile_kernel(const CtArgs a)
       rr[s][i] = make_uint2(0u, 0u);
       yy[s][i] = make_uint2(0x3F803F80u, 0x3F803F80u);  // +1: the derivative is 1 outside the mask window
       if (mrow[i] < 0) continue;
-      if (a.res) rr[s][i] = *reinterpret_cast<const uint2*>(a.res + mrow[i] * a.res_ctot + a.res_off + co0);
+      if (a.res && co0 < a.res_c1) rr[s][i] = *reinterpret_cast<const uint2*>(a.res + mrow[i] * a.res_ctot + a.res_off + co0);
       if (masked)
         yy[s][i] = *reinterpret_cast<const uint2*>(a.mask_y + mrow[i] * a.mask_ctot + a.mask_off + (co0 - a.mask_c0));
     }
@@ -453,7 +453,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_tile_kernel(const CtArgs a)
         if (a.out_planar) {
           reinterpret_cast<float*>(a.out)[((long)b * a.Cout + co0 + q) * vox_per_b + vi] = x;
         } else {
-          if (a.res) x += a.beta * ldf<BF16>(a.res + mrow[i] * a.res_ctot + a.res_off + co0 + q);
+          if (a.res && co0 + q < a.res_c1) x += a.beta * ldf<BF16>(a.res + mrow[i] * a.res_ctot + a.res_off + co0 + q);
           if constexpr (MASK) {
             if (co0 + q >= a.mask_c0 && co0 + q < a.mask_c1)
               x *= ldf<BF16>(a.mask_y + mrow[i] * a.mask_ctot + a.mask_off + (co0 + q - a.mask_c0)) > 0.f

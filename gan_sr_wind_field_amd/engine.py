@@ -35,6 +35,9 @@ STACK_DGRAD = __import__("os").environ.get("WSR_STACK_DGRAD", "1") != "0"
 #: split the growth convs of a dense block into one conv over the block input + narrow convs over the growth
 #: channels (WSR_STACK_FWD=0: one launch per conv over its whole input window)
 STACK_FWD = __import__("os").environ.get("WSR_STACK_FWD", "1") != "0"
+#: keep the running gradient of a dense block's output in channels [0, nf) of the dense gradient buffer
+#: (WSR_GD_INPLACE=0: separate tensor + one add per block)
+GD_INPLACE = __import__("os").environ.get("WSR_GD_INPLACE", "1") != "0"
 #: run the last conv of the generator in its z-folded form (WSR_ZFOLD=0: plain 5x5x5 conv with 3 outputs)
 ZFOLD = __import__("os").environ.get("WSR_ZFOLD", "1") != "0"
 POISON_BUFFERS = bool(int(__import__("os").environ.get("WSR_POISON_BUFFERS", "0")))
@@ -284,6 +287,8 @@ class ProgramBase:
         def run():
             if self.tile_ok(s) and ops.conv_fwd_tile(d, x, self.filters.get_frag(s.weight, False), y, bias=bias, **ep):
                 return
+            if "res2" in ep:
+                raise RuntimeError("a second residual needs the streaming 1x1x1 kernel")
             ops.conv_fwd(d, x, self._w(s), y, bias=bias, **ep)
 
         if self.launch_probe is not None:
@@ -307,6 +312,8 @@ class ProgramBase:
             if self.tile_ok(s) and ops.conv_dgrad_tile(d, g, self.filters.get_frag(s.weight, True), dx, alpha=alpha,
                                                        accumulate=accumulate, dx_planar=dx_planar, mask=m):
                 return
+            if int(accumulate) > 1:
+                raise RuntimeError("partial accumulation needs the tile kernels (set WSR_GD_INPLACE=0)")
             ops.conv_dgrad(d, g, self._wt(s), dx, alpha=alpha, accumulate=accumulate, dx_planar=dx_planar)
             if mask is not None:
                 ops.lrelu_bwd_(dx, dx_off + mask[2], mask[0], mask[1], mask[3] - mask[2], self.slope)
@@ -629,12 +636,20 @@ class GeneratorProgram(ProgramBase):
                         self.conv(c, buf, 0, buf, nf + i * gc, act=True, slope=sl)
                 seen += 1
                 nb = self._empty((B, X, Y, nz, nf if seen == total_rdbs else dense), x)
-                # x + rdb_scale * (LFF(dense) + b)
-                self.conv(lff, buf, 0, nb, 0, alpha=rdb_scale, res=buf, res_off=0, beta=1.0)
+                # x + rdb_scale * (LFF(dense) + b); the last block of an RRDB also takes the RRDB shortcut:
+                # rr_scale * (x + rdb_scale * (LFF + b)) + x_rr in the same launch (two residuals)
+                fold = (convs is rdbs[-1][0] and self.dt == torch.bfloat16 and self.use_tile
+                        and ops.conv1x1_covers(buf.shape[-1], nf, False) and lff.taps == 1)
+                if fold:
+                    self.conv(lff, buf, 0, nb, 0, alpha=rr_scale * rdb_scale, res=buf, res_off=0, beta=rr_scale,
+                              res2=rr_in, res2_off=0, beta2=1.0)
+                else:
+                    self.conv(lff, buf, 0, nb, 0, alpha=rdb_scale, res=buf, res_off=0, beta=1.0)
                 bufs.append(buf)
                 buf = nb
             # RRDB residual: out = rr_scale * chain + x_rr
-            ops.chan_axpby(buf, 0, rr_in, 0, nf, alpha=1.0, beta=rr_scale)
+            if not (rdbs and fold):
+                ops.chan_axpby(buf, 0, rr_in, 0, nf, alpha=1.0, beta=rr_scale)
         t_last = buf
         s = self._empty((B, X, Y, nz, nf), x)
         self.conv(self.lr_conv, t_last, 0, s, 0, res=first, res_off=0, beta=1.0)
@@ -770,10 +785,19 @@ class GeneratorProgram(ProgramBase):
         bi = len(bufs)
         dense = bufs[0].shape[-1] if bufs else nf
         gd = self._empty((B, X, Y, nz, dense), g_out) if bufs else None
+        inplace = (GD_INPLACE and gd is not None and self.dt == torch.bfloat16 and self.use_tile
+                   and ops.conv1x1_covers(nf, dense, True))
         for rdbs, rr_scale in zip(reversed(self.rrdbs), reversed(self.rrdb_scales)):
             g_skip = g  # d(out)/d(x_rr) through the RRDB shortcut
-            go = self._empty(g.shape, g_out)
-            ops.chan_axpby(go, 0, g, 0, nf, alpha=rr_scale)
+            if inplace:
+                # the gradient of the current block's output lives in gd[..., :nf]: the LFF input gradient is
+                # taken in place (1x1x1: voxel-local) with the block's identity shortcut as a residual on those
+                # channels, and window 0 of the dense input gradient accumulates onto it
+                go, go_c = gd, nf
+                ops.chan_axpby(gd, 0, g, 0, nf, alpha=rr_scale)
+            else:
+                go, go_c = self._empty(g.shape, g_out), None
+                ops.chan_axpby(go, 0, g, 0, nf, alpha=rr_scale)
             for convs, lff, rdb_scale in reversed(rdbs):
                 bi -= 1
                 buf = bufs[bi]
@@ -781,14 +805,14 @@ class GeneratorProgram(ProgramBase):
                 self.wgrad(lff, buf, 0, go, 0, flat, sp, scratch, scale=rdb_scale)
                 gb = sp.view(flat, lff.bias)
                 if not ops.chan_sum(go, 0, nf, gb, scale=rdb_scale):
-                    gb.copy_(go.float().sum(dim=(0, 1, 2, 3)) * rdb_scale)
+                    gb.copy_(go[..., :nf].float().sum(dim=(0, 1, 2, 3)) * rdb_scale)
                 # gd[off_i : off_i+gc] is the gradient w.r.t. the LeakyReLU output of growth conv i; it is
                 # complete once the LFF and the later convs have added into it, so the kernel that makes the
                 # last contribution applies the LeakyReLU derivative in its epilogue (window i = nconv-1: the
                 # LFF's input gradient; window i-1: the input gradient of conv i)
                 nc = len(convs)
                 last = nf + (nc - 1) * gc
-                self.dgrad(lff, go, 0, gd, 0, (X, Y, nz), alpha=rdb_scale,
+                self.dgrad(lff, go, 0, gd, 0, (X, Y, nz), alpha=rdb_scale, accumulate=go_c if inplace else False,
                            mask=(buf, last, last, last + gc) if nc else None)
                 if STACK_DGRAD and self.dense_stackable(convs):
                     self.dgrad_dense(convs, gd, buf, (X, Y, nz))
@@ -799,10 +823,14 @@ class GeneratorProgram(ProgramBase):
                         self.dgrad(convs[i], gd, off, gd, 0, (X, Y, nz), accumulate=True, mask=m)
                 # all growth-channel gradients of the block are final now: one stacked wgrad
                 self.wgrad_dense(convs, buf, gd, flat, sp, scratch)
-                ops.chan_axpby(go, 0, gd, 0, nf, alpha=1.0, beta=1.0)  # + grad through the dense input
+                if not inplace:
+                    ops.chan_axpby(go, 0, gd, 0, nf, alpha=1.0, beta=1.0)  # + grad through the dense input
                 ready(lff.weight, lff.bias, *[c.weight for c in convs])
-            ops.chan_axpby(go, 0, g_skip, 0, nf, alpha=1.0, beta=1.0)
-            g = go
+            if inplace:
+                ops.chan_axpby(g, 0, gd, 0, nf, alpha=1.0, beta=1.0)  # g (= g_skip) += chain gradient; g is ours
+            else:
+                ops.chan_axpby(go, 0, g_skip, 0, nf, alpha=1.0, beta=1.0)
+                g = go
         # ---- feature conv: total grad of f = trunk path + skip path
         ops.chan_axpby(g, 0, gs, 0, nf, alpha=1.0, beta=1.0)
         self.wgrad(self.feature, saved["x_nd"], 0, g, 0, flat, sp, scratch)

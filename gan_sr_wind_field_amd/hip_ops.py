@@ -110,7 +110,8 @@ def conv_fwd(desc: ConvDesc, x: Tensor, w: Tensor, y: Tensor, *, bias: Optional[
 def conv_fwd_tile(desc: ConvDesc, x: Tensor, wfrag: Tensor, y: Tensor, *, bias: Optional[Tensor] = None,
                   chan_scale: Optional[Tensor] = None, res: Optional[Tensor] = None, res_off: int = 0,
                   alpha: float = 1.0, beta: float = 0.0, act=False, slope: float = 0.2,
-                  out_planar: bool = False, act_c1: int = 0) -> bool:
+                  out_planar: bool = False, act_c1: int = 0, res2: Optional[Tensor] = None, res2_off: int = 0,
+                  beta2: float = 0.0) -> bool:
     """LDS halo-tile forward conv (bf16, stride 1).  Returns False when the shape is outside
     the tile kernels (the caller then uses :func:`conv_fwd`).  ``act`` = 2 / ``act_c1``: the two stages of a
     split dense-block conv (see ``wsr_epilogue_t``)."""
@@ -123,11 +124,21 @@ def conv_fwd_tile(desc: ConvDesc, x: Tensor, wfrag: Tensor, y: Tensor, *, bias: 
     ep.act, ep.slope = int(act), slope
     ep.out_planar = int(out_planar)
     ep.act_c1 = act_c1
+    if res2 is not None:
+        _need_cuda(res2)
+        ep.res2, ep.res2_ctot, ep.res2_off, ep.beta2 = _p(res2), res2.shape[-1], res2_off, beta2
     rc = _lib.lib().wsr_conv3d_fwd_tile(C.byref(desc), _p(x), _p(wfrag), _p(y), C.byref(ep), _stream())
     if rc == _lib.WSR_EUNSUPPORTED:
         return False
     check(rc, "conv3d_fwd_tile")
     return True
+
+
+def conv1x1_covers(red: int, n_out: int, masked: bool) -> bool:
+    """shapes the streaming 1x1x1 kernel is instantiated for (conv_1x1.hip, ``wsr_conv1x1_bf16``): reduction
+    channels x produced channels.  Only that kernel may run a 1x1x1 input gradient in place."""
+    shapes = {(128, 256), (128, 128)} if masked else {(256, 128), (128, 256), (128, 128)}
+    return (red, n_out) in shapes
 
 
 def conv_dgrad_tile(desc: ConvDesc, dy: Tensor, wfrag_t: Tensor, dx: Tensor, *, alpha: float = 1.0,

@@ -71,6 +71,11 @@ typedef struct wsr_epilogue {
   int32_t out_planar;       /* 1: y is fp32 planar (B, Cout, Xo, Yo, Zo)        */
   int32_t act_c1;           /* > 0 (tile kernels only): bias and activation apply to channels < act_c1 only, the rest
                                are stored as raw sums - the first stage of a split dense-block conv            */
+  const void* res2;         /* second residual, y += beta2*res2[..., res2_off + c] (streaming 1x1x1 kernel only,
+                               WSR_EUNSUPPORTED elsewhere): the last LFF of an RRDB adds the dense block's and the
+                               RRDB's shortcut at once (torch_blocks.py:290,330)                                */
+  int32_t res2_ctot, res2_off;
+  float beta2;
 } wsr_epilogue_t;
 
 int wsr_abi_version(void);
@@ -87,7 +92,8 @@ int wsr_conv3d_fwd(const wsr_conv_t* c, const void* x, const void* w, void* y,
  * [Cin][KX][KY][KZ][Cout] (wsr_pack_filter with transpose=1).  dx gets channel
  * window [in_off, in_off+Cin) of an `in_ctot` buffer at the conv's *stored*
  * input resolution unless upsample_xy, in which case dx is at 2Xi x 2Yi and
- * wsr_upsample2_bwd folds it.  dx = alpha*result (+ dx if accumulate).  dx_planar=1: dx
+ * wsr_upsample2_bwd folds it.  dx = alpha*result (+ dx if accumulate; the tile entry point also takes
+ * accumulate = n > 1: only the first n produced channels are added to).  dx_planar=1: dx
  * is an fp32 planar (B, Cin, X, Y, Z) tensor (gradient w.r.t. a network input).  */
 int wsr_conv3d_dgrad(const wsr_conv_t* c, const void* dy, const void* wt, void* dx, float alpha,
                      int accumulate, int dx_planar, void* stream);

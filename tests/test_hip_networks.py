@@ -403,3 +403,23 @@ def test_generator_bf16_split_dense_forward(hip, monkeypatch, nf, gc, n_rrdb):
         e_s = rel_l2(res["split"][1][k], res["fp32"][1][k])
         e_p = rel_l2(res["perconv"][1][k], res["fp32"][1][k])
         assert e_s < max(1.5 * e_p, 2e-2), (k, e_s, e_p)
+
+
+def test_generator_bf16_inplace_block_gradient(hip, monkeypatch):
+    """Running block-output gradient kept in channels [0, nf) of the dense gradient buffer (LFF input
+    gradient in place, partial accumulation) against the separate-tensor form."""
+    from gan_sr_wind_field_amd import engine
+
+    spec = onets.GSpec(upscale=4, in_channels=4, out_channels=3, nf=128, n_rrdb=2, hr_kern=5, gc=32, tf=8)
+    LR, HR, Z, x, y = ogan.synthetic_batch(1, 8, 6, 4, seed=51)
+    gy = torch.randn(1, 3, 32, 32, 6, generator=torch.Generator().manual_seed(8)).to(DEV)
+    grads = {}
+    for inplace in (True, False):
+        monkeypatch.setattr(engine, "GD_INPLACE", inplace)
+        G, _ = build_G(spec, torch.bfloat16, 29)
+        G.eval()
+        (G(LR.to(DEV), Z.to(DEV)) * gy).sum().backward()
+        grads[inplace] = {k: p.grad.clone() for k, p in G.named_parameters()}
+    for k in grads[True]:
+        assert torch.isfinite(grads[True][k]).all(), k
+        assert rel_l2(grads[True][k], grads[False][k]) < 2e-2, k

@@ -76,6 +76,8 @@ HR = (128, 128, 128)
 CASES = {
     "rdb": lambda: [conv_case(f"rdb conv{i} {128 + 32 * i}->32", 128 + 32 * i, 32, (3, 3, 3), LR, 256, 256, 128 + 32 * i)
                     for i in range(4)],
+    "grow": lambda: [conv_case(f"grow stage {32 * i}->32", 32 * i, 32, (3, 3, 3), LR, 256, 256, 128 + 32 * i) for i in (1, 2, 3)]
+    + [conv_case("pre 128->128", 128, 128, (3, 3, 3), LR, 256, 256, 128)],
     "rdbg": lambda: conv_case("rdb conv3 224->32", 224, 32, (3, 3, 3), LR, 256, 256, 224, what="fwd_generic"),
     "hr0": lambda: [conv_case("hr0 144->144 k5", 144, 144, (5, 5, 5), HR, what=w) for w in ("fwd", "dgrad")],
     "rdbw": tri_case,
