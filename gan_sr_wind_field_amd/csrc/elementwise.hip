@@ -406,6 +406,94 @@ __global__ void zunfold_kernel(const float* __restrict__ g, typename T::elem* __
   }
 }
 
+
+// ---- wind-field derivatives (see windsr_hip.h).  Row i of the derivative operator along one axis with
+// coordinates c[0..n): interior  d_i = a_i f_{i-1} + b_i f_i + c_i f_{i+1},
+//   a_i = -hr^2/den, b_i = (hr^2 - hl^2)/den, c_i = hl^2/den, hl = c_i - c_{i-1}, hr = c_{i+1} - c_i,
+//   den = hl*hr*(hl + hr);  ends: (f_1 - f_0)/(c_1 - c_0), (f_{n-1} - f_{n-2})/(c_{n-1} - c_{n-2}).
+struct Row3 { float a, b, c; };
+template <class Coord>
+__device__ __forceinline__ Row3 deriv_row(const Coord& co, int i, int n) {
+  Row3 r;
+  if (n < 2) { r.a = r.b = r.c = 0.f; return r; }
+  if (i == 0) { const float h = co(1) - co(0); r.a = 0.f; r.b = -1.f / h; r.c = 1.f / h; return r; }
+  if (i == n - 1) { const float h = co(n - 1) - co(n - 2); r.a = -1.f / h; r.b = 1.f / h; r.c = 0.f; return r; }
+  const float hl = co(i) - co(i - 1), hr = co(i + 1) - co(i);
+  const float den = hl * hr * (hl + hr);
+  r.a = -(hr * hr) / den; r.b = (hr * hr - hl * hl) / den; r.c = (hl * hl) / den;
+  return r;
+}
+struct Lin { const float* p; long s; __device__ float operator()(int i) const { return p[(long)i * s]; } };
+
+// forward: one thread per (b, comp, x, y, z) point, three derivatives
+__global__ void wind_gradient_kernel(const float* __restrict__ f, const float* __restrict__ xs, const float* __restrict__ ys,
+                                     const float* __restrict__ zc, float* __restrict__ out, int B, int X, int Y, int Z) {
+  const long plane = (long)Y * Z, vol = (long)X * plane, total = (long)B * 3 * vol;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int z = (int)(i % Z);
+    long r = i / Z;
+    const int y = (int)(r % Y); r /= Y;
+    const int x = (int)(r % X); r /= X;
+    const int c = (int)(r % 3);
+    const long b = r / 3;
+    const float* fp = f + i;
+    const float f0 = *fp;
+    const long ob = ((b * 9) * vol) + (long)x * plane + (long)y * Z + z;
+    {
+      const Row3 w = deriv_row(Lin{xs, 1}, x, X);
+      out[ob + (long)(0 + c) * vol] = (x > 0 ? w.a * fp[-plane] : 0.f) + w.b * f0 + (x < X - 1 ? w.c * fp[plane] : 0.f);
+    }
+    {
+      const Row3 w = deriv_row(Lin{ys, 1}, y, Y);
+      out[ob + (long)(3 + c) * vol] = (y > 0 ? w.a * fp[-Z] : 0.f) + w.b * f0 + (y < Y - 1 ? w.c * fp[Z] : 0.f);
+    }
+    {
+      const float* zcol = zc + (b * vol + (long)x * plane + (long)y * Z);
+      const Row3 w = deriv_row(Lin{zcol, 1}, z, Z);
+      out[ob + (long)(6 + c) * vol] = (z > 0 ? w.a * fp[-1] : 0.f) + w.b * f0 + (z < Z - 1 ? w.c * fp[1] : 0.f);
+    }
+  }
+}
+
+// adjoint: df_j = c_{j-1} g_{j-1} + b_j g_j + a_{j+1} g_{j+1} along each axis, summed over the three axes
+__global__ void wind_gradient_bwd_kernel(const float* __restrict__ g, const float* __restrict__ xs,
+                                         const float* __restrict__ ys, const float* __restrict__ zc, float* __restrict__ df,
+                                         int B, int X, int Y, int Z) {
+  const long plane = (long)Y * Z, vol = (long)X * plane, total = (long)B * 3 * vol;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int z = (int)(i % Z);
+    long r = i / Z;
+    const int y = (int)(r % Y); r /= Y;
+    const int x = (int)(r % X); r /= X;
+    const int c = (int)(r % 3);
+    const long b = r / 3;
+    const long gb = ((b * 9) * vol) + (long)x * plane + (long)y * Z + z;
+    float acc = 0.f;
+    {
+      const float* gp = g + gb + (long)(0 + c) * vol;
+      const Lin co{xs, 1};
+      acc += deriv_row(co, x, X).b * gp[0];
+      if (x > 0) acc += deriv_row(co, x - 1, X).c * gp[-plane];
+      if (x < X - 1) acc += deriv_row(co, x + 1, X).a * gp[plane];
+    }
+    {
+      const float* gp = g + gb + (long)(3 + c) * vol;
+      const Lin co{ys, 1};
+      acc += deriv_row(co, y, Y).b * gp[0];
+      if (y > 0) acc += deriv_row(co, y - 1, Y).c * gp[-Z];
+      if (y < Y - 1) acc += deriv_row(co, y + 1, Y).a * gp[Z];
+    }
+    {
+      const float* gp = g + gb + (long)(6 + c) * vol;
+      const Lin co{zc + (b * vol + (long)x * plane + (long)y * Z), 1};
+      acc += deriv_row(co, z, Z).b * gp[0];
+      if (z > 0) acc += deriv_row(co, z - 1, Z).c * gp[-1];
+      if (z < Z - 1) acc += deriv_row(co, z + 1, Z).a * gp[1];
+    }
+    df[i] = acc;
+  }
+}
+
 }  // namespace
 
 #define DISPATCH_T(dtype, CALL_BF16, CALL_F32) \
@@ -675,6 +763,26 @@ extern "C" int wsr_zunfold(const float* g, void* d, int32_t B, int32_t C, int32_
                                 (unsigned short*)d, B, C, KZ, pz, (long)planes, Z, d_ctot, d_off, c_fill),
              hipLaunchKernelGGL(zunfold_kernel<F32>, dim3(ew_grid(total)), dim3(EW_BLOCK), 0, as_stream(stream), g,
                                 (float*)d, B, C, KZ, pz, (long)planes, Z, d_ctot, d_off, c_fill));
+  WSR_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int wsr_wind_gradient(const float* f, const float* xs, const float* ys, const float* zc, float* out,
+                                 int32_t B, int32_t X, int32_t Y, int32_t Z, void* stream) {
+  if (!f || !xs || !ys || !zc || !out || B <= 0 || X <= 0 || Y <= 0 || Z <= 0) return WSR_EINVAL;
+  const long total = (long)B * 3 * X * Y * Z;
+  hipLaunchKernelGGL(wind_gradient_kernel, dim3(ew_grid(total)), dim3(EW_BLOCK), 0, as_stream(stream), f, xs, ys, zc,
+                     out, B, X, Y, Z);
+  WSR_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int wsr_wind_gradient_bwd(const float* g, const float* xs, const float* ys, const float* zc, float* df,
+                                     int32_t B, int32_t X, int32_t Y, int32_t Z, void* stream) {
+  if (!g || !xs || !ys || !zc || !df || B <= 0 || X <= 0 || Y <= 0 || Z <= 0) return WSR_EINVAL;
+  const long total = (long)B * 3 * X * Y * Z;
+  hipLaunchKernelGGL(wind_gradient_bwd_kernel, dim3(ew_grid(total)), dim3(EW_BLOCK), 0, as_stream(stream), g, xs, ys, zc,
+                     df, B, X, Y, Z);
   WSR_LAUNCH_CHECK();
   return 0;
 }

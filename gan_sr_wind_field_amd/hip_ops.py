@@ -338,6 +338,40 @@ def upsample2_bwd(dy: Tensor, dx: Tensor) -> Tensor:
     return dx
 
 
+class _WindGradient(torch.autograd.Function):
+    """(B, 3, X, Y, Z) -> (B, 9, X, Y, Z) derivatives of the wind field (``wsr_wind_gradient``) with the adjoint
+    as backward - one launch each instead of torch.gradient + slicing arithmetic and their autograd graph."""
+
+    @staticmethod
+    def forward(ctx, f: Tensor, xs: Tensor, ys: Tensor, zc: Tensor) -> Tensor:
+        B, _, X, Y, Z = f.shape
+        out = torch.empty((B, 9, X, Y, Z), dtype=torch.float32, device=f.device)
+        check(_lib.lib().wsr_wind_gradient(_p(f), _p(xs), _p(ys), _p(zc), _p(out), B, X, Y, Z, _stream()),
+              "wind_gradient")
+        ctx.save_for_backward(xs, ys, zc)
+        return out
+
+    @staticmethod
+    def backward(ctx, g: Tensor):
+        xs, ys, zc = ctx.saved_tensors
+        g = g.contiguous().float()
+        B, _, X, Y, Z = g.shape
+        df = torch.empty((B, 3, X, Y, Z), dtype=torch.float32, device=g.device)
+        check(_lib.lib().wsr_wind_gradient_bwd(_p(g), _p(xs), _p(ys), _p(zc), _p(df), B, X, Y, Z, _stream()),
+              "wind_gradient_bwd")
+        return df, None, None, None
+
+
+def wind_gradient(f: Tensor, xs: Tensor, ys: Tensor, zc: Tensor) -> Tensor:
+    """``calculate_gradient_of_wind_field`` of the reference (process_data.py:301-313) on the device"""
+    _need_cuda(f, xs, ys, zc)
+    B, C_, X, Y, Z = f.shape
+    if C_ != 3 or xs.numel() != X or ys.numel() != Y or zc.numel() != B * X * Y * Z:
+        raise ValueError("wind_gradient wants f (B,3,X,Y,Z), x (X), y (Y), Z (B,1,X,Y,Z)")
+    return _WindGradient.apply(f.contiguous().float(), xs.contiguous().float(), ys.contiguous().float(),
+                               zc.contiguous().float())
+
+
 def zfold(t: Tensor, y: Tensor, bias: Optional[Tensor], kz: int, pz: int) -> Tensor:
     """``y[b,c,x,y,z] = bias[c] + sum_k t[b, c*kz+k, x, y, z+k-pz]`` - planar fp32 (see ``wsr_zfold``)."""
     _need_cuda(t, y)

@@ -51,7 +51,12 @@ def calculate_div_z(HR_data: torch.Tensor, Z: torch.Tensor) -> torch.Tensor:
 
 def calculate_gradient_of_wind_field(HR_data: torch.Tensor, x: torch.Tensor, y: torch.Tensor,
                                      Z: torch.Tensor) -> torch.Tensor:
-    """(B, 3, X, Y, nz) -> (B, 9, X, Y, nz): d/dx, d/dy (coordinate spacing), d/dz (reference :301-313)."""
+    """(B, 3, X, Y, nz) -> (B, 9, X, Y, nz): d/dx, d/dy (coordinate spacing), d/dz (reference :301-313).
+    Device tensors take the fused HIP kernel (forward + adjoint, ``wsr_wind_gradient``); the torch
+    expression below is the same arithmetic and serves host-side tensors (tests with stand-in networks)."""
+    if HR_data.is_cuda and HR_data.shape[1] == 3 and Z.shape[1] == 1:
+        from . import hip_ops
+        return hip_ops.wind_gradient(HR_data, x, y, Z)
     grad_x, grad_y = torch.gradient(HR_data, dim=(2, 3), spacing=(x, y))
     return torch.cat((grad_x, grad_y, calculate_div_z(HR_data, Z)), dim=1)
 

@@ -208,6 +208,18 @@ int wsr_planar_to_ndhwc(const float* src, void* dst, int32_t B, int32_t C, int64
 int wsr_ndhwc_to_planar(const void* src, float* dst, int32_t B, int32_t C, int64_t vox_per_b,
                         int32_t s_ctot, int32_t s_off, int32_t dtype, void* stream);
 
+/* Wind-field derivatives of the physics losses (process_data.py:273-313 of the reference:
+ * calculate_gradient_of_wind_field = torch.gradient over x, y with coordinate spacing + calculate_div_z on
+ * the terrain-following levels): out[b, 3*a + c] = d f[b, c] / d axis_a, a = 0 (x), 1 (y), 2 (z), planar
+ * fp32 (B, ., X, Y, Z).  Interior points use the second-order three-point stencil for non-uniform
+ * spacing, the two ends one-sided first differences.  xs[X], ys[Y] are the horizontal coordinates, zc
+ * (B, 1, X, Y, Z) the height of every level.  _bwd applies the adjoint (transpose) of that linear map to
+ * g (B, 9, X, Y, Z): the gradient w.r.t. f.                                                        */
+int wsr_wind_gradient(const float* f, const float* xs, const float* ys, const float* zc, float* out, int32_t B,
+                      int32_t X, int32_t Y, int32_t Z, void* stream);
+int wsr_wind_gradient_bwd(const float* g, const float* xs, const float* ys, const float* zc, float* df, int32_t B,
+                          int32_t X, int32_t Y, int32_t Z, void* stream);
+
 /* z-folded form of a conv with very few output channels (the last conv of the generator, 144 -> 3,
  * 5x5x5, Generator_3D_Resnet_ESRGAN.py:120-127): the KZ taps along z become output channels of a
  * (KX,KY,1) conv with C*KZ outputs - 15 instead of 3 of the 16 columns of an MFMA tile do work, a fifth

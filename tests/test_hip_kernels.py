@@ -470,3 +470,31 @@ def test_zfold_and_its_adjoint(hip):
     db = torch.empty((B, X, Y, Z, 16), device="cuda:0", dtype=torch.bfloat16)
     o.zunfold(gy, db, KZ, pz, 0, 16)
     assert rel_l2(db.float(), d) < 4e-3
+
+
+def test_wind_gradient_forward_and_adjoint(hip):
+    """fused wind-field derivatives == torch.gradient (x, y, coordinate spacing) + the non-uniform z stencil of
+    the reference (process_data.py:273-313), and its backward == autograd of that expression"""
+    from gan_sr_wind_field_amd import hip_ops as o
+    from gan_sr_wind_field_amd import process_data as pd
+
+    B, X, Y, Z = 2, 7, 6, 9
+    g = torch.Generator().manual_seed(17)
+    f = torch.randn((B, 3, X, Y, Z), generator=g, dtype=torch.float64)
+    xs = torch.cumsum(torch.rand(X, generator=g, dtype=torch.float64) + 0.5, 0) * 100.0
+    ys = torch.cumsum(torch.rand(Y, generator=g, dtype=torch.float64) + 0.5, 0) * 100.0
+    zc = torch.cumsum(torch.rand((B, 1, X, Y, Z), generator=g, dtype=torch.float64) + 0.2, -1) * 30.0
+    fr = f.clone().requires_grad_(True)
+    want = pd.calculate_gradient_of_wind_field(fr, xs, ys, zc)  # host tensors: the torch expression
+    gy = torch.randn(want.shape, generator=g, dtype=torch.float64)
+    (want * gy).sum().backward()
+    fd = f.float().to("cuda:0").requires_grad_(True)
+    got = o.wind_gradient(fd, xs.float().to("cuda:0"), ys.float().to("cuda:0"), zc.float().to("cuda:0"))
+    assert got.shape == (B, 9, X, Y, Z)
+    assert rel_l2(got.detach(), want.detach().float()) < 2e-5
+    (got * gy.float().to("cuda:0")).sum().backward()
+    assert rel_l2(fd.grad, fr.grad.float()) < 2e-5
+    # degenerate extents: a single level has no z derivative
+    one = o.wind_gradient(fd.detach()[..., :1].contiguous(), xs.float().to("cuda:0"), ys.float().to("cuda:0"),
+                          zc.float().to("cuda:0")[..., :1].contiguous())
+    assert torch.equal(one[:, 6:], torch.zeros_like(one[:, 6:]))
