@@ -55,7 +55,7 @@ struct CtArgs {
   int NT_total;     // 16-wide output-channel tiles
   int ngroups;      // n-tile groups (grid = ntiles * ngroups)
   int P;            // activation plane stride (bytes)
-  int off_mtab, off_htab, off_ttab, off_xs, off_ws;
+  int off_mtab, off_htab, off_ttab, off_btab, off_xs, off_ws;  // btab: bias and scale of the workgroup's columns
   int vec_ok;
   const unsigned short* mask_y;  // LeakyReLU-backward mask source (saved forward output) or NULL
   int mask_ctot, mask_off, mask_c0, mask_c1;
@@ -237,6 +237,16 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_tile_kernel(const CtArgs a)
     mtab[m] = m < M ? (ox | (oy << 8) | (oz << 16)) : (1u << 24);
     htab[m] = m < M ? (unsigned short)((ox * Ly + oy) * Lz + oz) : (unsigned short)0;
   }
+  // per-channel epilogue constants of this workgroup's columns: bias (where it applies) and
+  // channel scale * alpha - fetched now, so that the epilogue finds them in LDS instead of waiting for
+  // global memory once per n-tile
+  float* btab = reinterpret_cast<float*>(smem + a.off_btab);
+  for (int k = t; k < NTW * 16; k += NT) {
+    const int co = nt0 * 16 + k;
+    const bool in = co < a.Cout;
+    btab[k] = (a.bias && in && co < a.act_c1) ? a.bias[co] : 0.f;
+    btab[NTW * 16 + k] = ((a.chan_scale && in) ? a.chan_scale[(long)b * a.Cout + co] : 1.f) * a.alpha;
+  }
   for (int k = t; k < a.nts * TPK; k += NT) {
     int off = 0;
     if (k < taps) {
@@ -372,15 +382,27 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_tile_kernel(const CtArgs a)
     const bool ok = !(mv >> 24) && gx < a.Xo && gy < a.Yo && gz < a.Zo;
     mrow[i] = ok ? (long)b * vox_per_b + ((long)gx * a.Yo + gy) * a.Zo + gz : -1;
   }
+  // row base pointers once (64-bit multiply-adds), n-tile offsets are immediates
+  unsigned short* orow[TM];
+  const unsigned short* rrow[TM];
+  const unsigned short* yrow[TM];
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    const long m = mrow[i] < 0 ? 0 : mrow[i];
+    orow[i] = reinterpret_cast<unsigned short*>(a.out) + m * a.out_ctot + a.out_off + cob;
+    rrow[i] = a.res ? a.res + m * a.res_ctot + a.res_off + cob : nullptr;
+    yrow[i] = MASK && a.mask_y ? a.mask_y + m * a.mask_ctot + a.mask_off + (cob - a.mask_c0) : nullptr;
+  }
   float bb[2][4], ss[2][4];
   uint2 rr[2][TM], yy[2][TM];
   auto fetch = [&](int j, int s) {
     const int co0 = cob + 16 * j;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const bool in = co0 + q < a.Cout;
-      bb[s][q] = (a.bias && in && co0 + q < a.act_c1) ? a.bias[co0 + q] : 0.f;
-      ss[s][q] = ((a.chan_scale && in) ? a.chan_scale[(long)b * a.Cout + co0 + q] : 1.f) * a.alpha;
+    {
+      const int col = (wn * TN + j) * 16 + fg * 4;  // column within the workgroup
+      const float4 b4 = *reinterpret_cast<const float4*>(btab + col);
+      const float4 s4 = *reinterpret_cast<const float4*>(btab + NTW * 16 + col);
+      bb[s][0] = b4.x; bb[s][1] = b4.y; bb[s][2] = b4.z; bb[s][3] = b4.w;
+      ss[s][0] = s4.x; ss[s][1] = s4.y; ss[s][2] = s4.z; ss[s][3] = s4.w;
     }
     if (!fast || co0 >= a.Cout) return;
     // LeakyReLU backward of the layer whose output gradient this is (channels [mask_c0, mask_c1)): the
@@ -391,9 +413,8 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_tile_kernel(const CtArgs a)
       rr[s][i] = make_uint2(0u, 0u);
       yy[s][i] = make_uint2(0x3F803F80u, 0x3F803F80u);  // +1: the derivative is 1 outside the mask window
       if (mrow[i] < 0) continue;
-      if (a.res && co0 < a.res_c1) rr[s][i] = *reinterpret_cast<const uint2*>(a.res + mrow[i] * a.res_ctot + a.res_off + co0);
-      if (masked)
-        yy[s][i] = *reinterpret_cast<const uint2*>(a.mask_y + mrow[i] * a.mask_ctot + a.mask_off + (co0 - a.mask_c0));
+      if (a.res && co0 < a.res_c1) rr[s][i] = *reinterpret_cast<const uint2*>(rrow[i] + 16 * j);
+      if (masked) yy[s][i] = *reinterpret_cast<const uint2*>(yrow[i] + 16 * j);
     }
   };
   fetch(0, 0);
@@ -417,8 +438,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_tile_kernel(const CtArgs a)
           x = x > 0.f ? x : x * a.slope;
           v[q] = x * ss[s][q];
         }
-        st4<BF16>(reinterpret_cast<unsigned short*>(a.out) + mrow[i] * a.out_ctot + a.out_off + co0,
-                  make_float4(v[0], v[1], v[2], v[3]));
+        st4<BF16>(orow[i] + 16 * j, make_float4(v[0], v[1], v[2], v[3]));
         continue;
       }
 #pragma unroll
@@ -441,7 +461,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_tile_kernel(const CtArgs a)
           o4.z *= (short)(yy[s][i].y & 0xFFFFu) > 0 ? 1.f : a.mask_slope;
           o4.w *= (int)yy[s][i].y > 0xFFFF ? 1.f : a.mask_slope;
         }
-        st4<BF16>(reinterpret_cast<unsigned short*>(a.out) + mrow[i] * a.out_ctot + a.out_off + co0, o4);
+        st4<BF16>(orow[i] + 16 * j, o4);
         continue;
       }
       // general path: planar fp32 output (network boundary), channel tails, unaligned windows
@@ -495,7 +515,8 @@ int launch_ct(CtArgs& a, hipStream_t st) {
   a.off_mtab = 0;
   a.off_htab = M * 4;
   a.off_ttab = round_up(a.off_htab + M * 2, 16);
-  a.off_xs = round_up(a.off_ttab + a.nts * TPK * 4, 1024);
+  a.off_btab = round_up(a.off_ttab + a.nts * TPK * 4, 16);
+  a.off_xs = round_up(a.off_btab + 2 * NTW * 16 * 4, 1024);
   // two activation buffers when that still leaves room for weight stages of >= 2 K-steps
   int ts_max = 0;
   const int xb_first = getenv("WSR_CT_XBUFS") ? atoi(getenv("WSR_CT_XBUFS")) : 2;  // tuning aid
