@@ -393,8 +393,10 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_tile_kernel(const CtArgs a)
     rrow[i] = a.res ? a.res + m * a.res_ctot + a.res_off + cob : nullptr;
     yrow[i] = MASK && a.mask_y ? a.mask_y + m * a.mask_ctot + a.mask_off + (cob - a.mask_c0) : nullptr;
   }
-  float bb[2][4], ss[2][4];
-  uint2 rr[2][TM], yy[2][TM];
+  constexpr int FD = TN >= 4 ? 2 : 1;  // operand sets requested ahead of the n-tile being stored
+  constexpr int FS = FD + 1;
+  float bb[FS][4], ss[FS][4];
+  uint2 rr[FS][TM], yy[FS][TM];
   auto fetch = [&](int j, int s) {
     const int co0 = cob + 16 * j;
     {
@@ -417,11 +419,13 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_tile_kernel(const CtArgs a)
       if (masked) yy[s][i] = *reinterpret_cast<const uint2*>(yrow[i] + 16 * j);
     }
   };
-  fetch(0, 0);
+#pragma unroll
+  for (int j = 0; j < FD; ++j)
+    if (j < TN) fetch(j, j % FS);
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
-    const int s = j & 1;
-    if (j + 1 < TN) fetch(j + 1, s ^ 1);
+    const int s = j % FS;
+    if (j + FD < TN) fetch(j + FD, (j + FD) % FS);
     const int co0 = cob + 16 * j;
     if (co0 >= a.Cout) continue;
 #pragma unroll
