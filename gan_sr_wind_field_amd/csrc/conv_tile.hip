@@ -34,11 +34,17 @@ int wsr_ct_run_narrow(CtArgs& a, int tpk, hipStream_t st);  // conv_tile_narrow.
 int wsr_ct_run_wide(CtArgs& a, int tpk, hipStream_t st);    // conv_tile_wide.hip
 int wsr_ct_run_masked(CtArgs& a, int tpk, hipStream_t st);  // conv_tile_masked.hip
 int wsr_ct_run_narrow_masked(CtArgs& a, int tpk, hipStream_t st);  // conv_tile_narrow_masked.hip
+int wsr_ct_run_small(CtArgs& a, int tpk, hipStream_t st);          // conv_tile_small.hip
 
 namespace {
 
 int dispatch_ct(CtArgs& a, int tpk, hipStream_t st) {
   const int N = a.Cout;
+  // small volumes (< 128 tiles of 512 voxels): 128-voxel tiles where an instantiation exists
+  if ((long)a.B * a.Xo * a.Yo * a.Zo < 128L * 512 && !getenv("WSR_CT_NOSMALL")) {
+    const int rc = wsr_ct_run_small(a, tpk, st);
+    if (rc != WSR_EUNSUPPORTED) return rc;
+  }
   if (a.mask_y) return N <= 64 ? wsr_ct_run_narrow_masked(a, tpk, st) : wsr_ct_run_masked(a, tpk, st);
   if (N <= 64) return wsr_ct_run_narrow(a, tpk, st);
   if (N == 144) return wsr_ct_run_n144(a, tpk, st);

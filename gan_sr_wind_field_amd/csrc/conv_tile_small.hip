@@ -1,0 +1,26 @@
+// Halo-tile conv instantiations for SMALL volumes (fewer than ~128 tiles of 512 voxels, e.g. the
+// reference's own 32 x 32 x 10 low-resolution patches): 128-voxel tiles, two waves per workgroup, so that
+// the trunk still spreads over the chip instead of running on 20 of its 256 CUs.  Same kernel, same
+// epilogues; only the tile-row count changes.
+#include "conv_tile_impl.h"
+
+template <int TPK>
+static int run(CtArgs& a, hipStream_t st) {
+  const int N = a.Cout;
+  if constexpr (TPK == 2) {
+    if (a.mask_y) {
+      if (N <= 32) { pick_tile(a, 128); return launch_ct<2, 1, 4, 2, TPK, true>(a, st); }
+      return WSR_EUNSUPPORTED;
+    }
+    if (N <= 32) { pick_tile(a, 128); return launch_ct<2, 1, 4, 2, TPK>(a, st); }
+    // 128 voxels x 128 channels as 2 x 4 waves of 64 x 32: four times the waves of a <2,1,4,8> tile, a quarter of
+    // the work each - at these sizes the chip is latency-, not throughput-bound
+    if (N > 64 && N <= 128) { pick_tile(a, 128); return launch_ct<2, 4, 4, 2, TPK>(a, st); }
+  }
+  return WSR_EUNSUPPORTED;
+}
+
+int wsr_ct_run_small(CtArgs& a, int tpk, hipStream_t st) {
+  if (tpk == 2) return run<2>(a, st);
+  return WSR_EUNSUPPORTED;
+}
