@@ -364,6 +364,68 @@ __global__ __launch_bounds__(1024) void chan_sum_final_kernel(const float* __res
   }
 }
 
+// BatchNorm reductions, vectorised and atomic-free: thread = (voxel lane, 4-channel group) as in chan_sum;
+// row blockIdx.x of `part` gets {sum a [C], sum b [C]} of the workgroup, chan_sum_final_kernel adds the rows.
+//   stats : a = d, b = d*d, d = x - shift[c]
+//   bwd   : g = dy * lrelu'(y) (written back when act), a = g, b = g * xhat
+template <class T, bool BWD>
+__global__ __launch_bounds__(256) void bn_reduce_v4_kernel(typename T::elem* dy, const typename T::elem* __restrict__ y,
+                                                          const typename T::elem* __restrict__ x,
+                                                          const float* __restrict__ mean_or_shift,
+                                                          const float* __restrict__ invstd, int C, long nvox, int act,
+                                                          float slope, float* __restrict__ part) {
+  __shared__ float4 sa[256], sb[256];
+  const int groups = C >> 2, lanes = 256 / groups;
+  const int g = threadIdx.x % groups, vl = threadIdx.x / groups;
+  float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
+  if (vl < lanes) {
+    float4 mu = make_float4(0.f, 0.f, 0.f, 0.f), is = make_float4(1.f, 1.f, 1.f, 1.f);
+    if (mean_or_shift) mu = *reinterpret_cast<const float4*>(mean_or_shift + 4 * g);
+    if (BWD) is = *reinterpret_cast<const float4*>(invstd + 4 * g);
+    const long step = (long)gridDim.x * lanes;
+    for (long v = (long)blockIdx.x * lanes + vl; v < nvox; v += step) {
+      const long o = v * C + 4 * g;
+      const float4 xv = ld4<T>(x + o);
+      if (BWD) {
+        float4 gv = ld4<T>(dy + o);
+        if (act) {
+          const float4 yv = ld4<T>(y + o);
+          gv.x *= yv.x > 0.f ? 1.f : slope; gv.y *= yv.y > 0.f ? 1.f : slope;
+          gv.z *= yv.z > 0.f ? 1.f : slope; gv.w *= yv.w > 0.f ? 1.f : slope;
+          st4<T>(dy + o, gv);
+        }
+        a.x += gv.x; a.y += gv.y; a.z += gv.z; a.w += gv.w;
+        b.x += gv.x * (xv.x - mu.x) * is.x; b.y += gv.y * (xv.y - mu.y) * is.y;
+        b.z += gv.z * (xv.z - mu.z) * is.z; b.w += gv.w * (xv.w - mu.w) * is.w;
+      } else {
+        const float dx = xv.x - mu.x, dy_ = xv.y - mu.y, dz = xv.z - mu.z, dw = xv.w - mu.w;
+        a.x += dx; a.y += dy_; a.z += dz; a.w += dw;
+        b.x += dx * dx; b.y += dy_ * dy_; b.z += dz * dz; b.w += dw * dw;
+      }
+    }
+  }
+  sa[threadIdx.x] = a;
+  sb[threadIdx.x] = b;
+  __syncthreads();
+  if (vl == 0) {
+    for (int l = 1; l < lanes; ++l) {
+      const float4 p = sa[l * groups + g], q = sb[l * groups + g];
+      a.x += p.x; a.y += p.y; a.z += p.z; a.w += p.w;
+      b.x += q.x; b.y += q.y; b.z += q.z; b.w += q.w;
+    }
+    float* row = part + (long)blockIdx.x * 2 * C;
+    *reinterpret_cast<float4*>(row + 4 * g) = a;
+    *reinterpret_cast<float4*>(row + C + 4 * g) = b;
+  }
+}
+
+static inline int bn_v4_grid(int C, long nvox) {
+  const int lanes = 256 / (C / 4);
+  long grid = (nvox + (long)lanes * 16 - 1) / ((long)lanes * 16);
+  if (grid > WSR_CHAN_SUM_ROWS) grid = WSR_CHAN_SUM_ROWS;
+  return grid < 1 ? 1 : (int)grid;
+}
+
 // z-fold / z-unfold (see windsr_hip.h): planar tensors are (B, channels, planes, Z) with z contiguous
 __global__ void zfold_kernel(const float* __restrict__ t, float* __restrict__ y, const float* __restrict__ bias, int B,
                              int C, int KZ, int pz, long planes, int Z) {
@@ -631,9 +693,26 @@ static inline int bn_grid(long total) {
   return (int)g;
 }
 
-extern "C" int wsr_bn_stats(const void* x, int32_t C, int64_t nvox, const float* shift, float* sums, int32_t dtype,
-                            void* stream) {
+extern "C" int wsr_bn_stats(const void* x, int32_t C, int64_t nvox, const float* shift, float* sums, float* partials,
+                            int32_t dtype, void* stream) {
   if (!x || !sums || C <= 0 || nvox <= 0) return WSR_EINVAL;
+  if (partials && C % 4 == 0 && C <= 512) {  // vectorised two-pass form: sums are overwritten
+    const int grid = bn_v4_grid(C, nvox);
+    auto kb = bn_reduce_v4_kernel<BF16, false>;
+    auto kf = bn_reduce_v4_kernel<F32, false>;
+    DISPATCH_T(dtype,
+               hipLaunchKernelGGL(kb, dim3(grid), dim3(256), 0, as_stream(stream), (unsigned short*)nullptr,
+                                  (const unsigned short*)nullptr, (const unsigned short*)x, shift, (const float*)nullptr,
+                                  C, (long)nvox, 0, 0.f, partials),
+               hipLaunchKernelGGL(kf, dim3(grid), dim3(256), 0, as_stream(stream), (float*)nullptr,
+                                  (const float*)nullptr, (const float*)x, shift, (const float*)nullptr, C, (long)nvox, 0,
+                                  0.f, partials));
+    WSR_LAUNCH_CHECK();
+    hipLaunchKernelGGL(chan_sum_final_kernel, dim3(1), dim3(1024), 0, as_stream(stream), partials, grid, 2 * C, 1.f,
+                       sums);
+    WSR_LAUNCH_CHECK();
+    return 0;
+  }
   if (C > 256 || 256 % C) return WSR_EUNSUPPORTED;
   const int grid = bn_grid(nvox * C);
   DISPATCH_T(dtype,
@@ -681,9 +760,25 @@ extern "C" int wsr_bn_apply_lrelu(const void* x, void* y, const float* mean, con
 }
 
 extern "C" int wsr_bn_bwd_reduce(void* dy, const void* y, const void* x, const float* mean, const float* invstd,
-                                 int32_t C, int64_t nvox, int32_t act, float slope, float* sums, int32_t dtype,
-                                 void* stream) {
+                                 int32_t C, int64_t nvox, int32_t act, float slope, float* sums, float* partials,
+                                 int32_t dtype, void* stream) {
   if (!dy || !y || !x || !mean || !invstd || !sums || C <= 0 || nvox <= 0) return WSR_EINVAL;
+  if (partials && C % 4 == 0 && C <= 512) {  // vectorised two-pass form: sums are overwritten
+    const int grid = bn_v4_grid(C, nvox);
+    auto kb = bn_reduce_v4_kernel<BF16, true>;
+    auto kf = bn_reduce_v4_kernel<F32, true>;
+    DISPATCH_T(dtype,
+               hipLaunchKernelGGL(kb, dim3(grid), dim3(256), 0, as_stream(stream), (unsigned short*)dy,
+                                  (const unsigned short*)y, (const unsigned short*)x, mean, invstd, C, (long)nvox, act,
+                                  slope, partials),
+               hipLaunchKernelGGL(kf, dim3(grid), dim3(256), 0, as_stream(stream), (float*)dy, (const float*)y,
+                                  (const float*)x, mean, invstd, C, (long)nvox, act, slope, partials));
+    WSR_LAUNCH_CHECK();
+    hipLaunchKernelGGL(chan_sum_final_kernel, dim3(1), dim3(1024), 0, as_stream(stream), partials, grid, 2 * C, 1.f,
+                       sums);
+    WSR_LAUNCH_CHECK();
+    return 0;
+  }
   if (C > 256 || 256 % C) return WSR_EUNSUPPORTED;
   const int grid = bn_grid(nvox * C);
   DISPATCH_T(dtype,

@@ -959,7 +959,7 @@ class DiscriminatorProgram(ProgramBase):
             if training:
                 # pass 1: sum x -> mean ; pass 2: sum (x - mean)^2 -> variance without cancellation.
                 # The per-channel steps in between are two tiny fused kernels (was ~14 torch ops per layer).
-                st = torch.zeros(4 * C_ + 1, dtype=torch.float32, device=x.device)
+                st = torch.empty(4 * C_ + 1, dtype=torch.float32, device=x.device)  # (bn_stats overwrites)
                 s1, s2 = st[:2 * C_], st[2 * C_:4 * C_]
                 work = torch.empty(2 * C_, dtype=torch.float32, device=x.device)
                 mean, invstd = work[:C_], work[C_:]
@@ -1019,7 +1019,7 @@ class DiscriminatorProgram(ProgramBase):
                 bn = l.bn
                 gy = self._empty(r["y"].shape, g)
                 if r["training"]:
-                    sums = torch.zeros(2 * C_, dtype=torch.float32, device=dev)
+                    sums = torch.empty(2 * C_, dtype=torch.float32, device=dev)  # (overwritten)
                     ops.bn_bwd_reduce(g, r["a"], r["y"], r["mean"], r["invstd"], l.act, sl, sums)
                     if need_dw:
                         sp.view(flat, bn.bias).copy_(sums[:C_])
@@ -1033,7 +1033,7 @@ class DiscriminatorProgram(ProgramBase):
                     if l.act:
                         ops.lrelu_bwd_(g, 0, r["a"], 0, g.shape[-1], sl)
                     if need_dw:  # eval-mode BN: d beta = sum g, d gamma = sum g * xhat
-                        sums = torch.zeros(2 * C_, dtype=torch.float32, device=dev)
+                        sums = torch.empty(2 * C_, dtype=torch.float32, device=dev)
                         ops.bn_bwd_reduce(g, r["a"], r["y"], r["mean"], r["invstd"], False, sl, sums)
                         sp.view(flat, bn.bias).copy_(sums[:C_])
                         sp.view(flat, bn.weight).copy_(sums[C_:])

@@ -421,11 +421,24 @@ def ndhwc_to_planar(src: Tensor, C_: int, s_off: int = 0) -> Tensor:
     return dst
 
 
+def _reduce_ws(dev, C_: int) -> Optional[Tensor]:
+    """scratch of the atomic-free reductions (None: the scalar kernels, which accumulate, take over)"""
+    if C_ % 4 or C_ > 512:
+        return None
+    ws = _chan_sum_ws.get(dev)
+    if ws is None or ws.numel() < CHAN_SUM_ROWS * 2 * C_:
+        ws = _chan_sum_ws[dev] = torch.empty(CHAN_SUM_ROWS * max(2 * C_, 256), dtype=torch.float32, device=dev)
+    return ws
+
+
 def bn_stats(x: Tensor, sums: Tensor, shift: Optional[Tensor] = None) -> None:
-    """sums[2C] += {sum (x - shift), sum (x - shift)^2} per channel"""
+    """sums[2C] = {sum (x - shift), sum (x - shift)^2} per channel"""
     C_ = x.shape[-1]
-    check(_lib.lib().wsr_bn_stats(_p(x), C_, x.numel() // C_, _p(shift), _p(sums), dtype_id(x.dtype), _stream()),
-          "bn_stats")
+    ws = _reduce_ws(x.device, C_)
+    if ws is None:
+        sums.zero_()
+    check(_lib.lib().wsr_bn_stats(_p(x), C_, x.numel() // C_, _p(shift), _p(sums), _p(ws), dtype_id(x.dtype),
+                                  _stream()), "bn_stats")
 
 
 def bn_mean(sums: Tensor, mean: Tensor, count: float, count_dev: Optional[Tensor] = None) -> None:
@@ -450,8 +463,11 @@ def bn_apply_lrelu(x: Tensor, y: Tensor, mean: Tensor, invstd: Tensor, gamma: Te
 def bn_bwd_reduce(dy: Tensor, y: Tensor, x: Tensor, mean: Tensor, invstd: Tensor, act: bool, slope: float,
                   sums: Tensor) -> None:
     C_ = x.shape[-1]
+    ws = _reduce_ws(x.device, C_)
+    if ws is None:
+        sums.zero_()
     check(_lib.lib().wsr_bn_bwd_reduce(_p(dy), _p(y), _p(x), _p(mean), _p(invstd), C_, x.numel() // C_, int(act),
-                                       slope, _p(sums), dtype_id(x.dtype), _stream()), "bn_bwd_reduce")
+                                       slope, _p(sums), _p(ws), dtype_id(x.dtype), _stream()), "bn_bwd_reduce")
 
 
 def bn_bwd_apply(g: Tensor, x: Tensor, dx: Tensor, mean: Tensor, invstd: Tensor, gamma: Tensor,

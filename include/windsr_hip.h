@@ -233,10 +233,11 @@ int wsr_zunfold(const float* g, void* d, int32_t B, int32_t C, int32_t KZ, int32
                 int32_t d_ctot, int32_t d_off, int32_t c_fill, int32_t dtype, void* stream);
 
 /* BatchNorm3d (torch_blocks.py:20-25) on NDHWC tensors, fp32 statistics.
- * stats: sums[2*C] += {sum d, sum d^2}, d = x - shift[c] (shift NULL = 0; caller
- * zeroes sums).  Two calls - shift 0, then shift = mean - give a cancellation-free
- * variance.                                                                     */
-int wsr_bn_stats(const void* x, int32_t C, int64_t nvox, const float* shift, float* sums,
+ * stats: sums[2*C] = {sum d, sum d^2}, d = x - shift[c] (shift NULL = 0).  Two calls - shift 0, then
+ * shift = mean - give a cancellation-free variance.  `partials` = caller-owned scratch of
+ * WSR_CHAN_SUM_ROWS * 2C floats: with it (and C a multiple of 4, <= 512) the reduction is vectorised,
+ * atomic-free and OVERWRITES sums; with NULL the scalar kernel ADDS to sums (caller zeroes them).     */
+int wsr_bn_stats(const void* x, int32_t C, int64_t nvox, const float* shift, float* sums, float* partials,
                  int32_t dtype, void* stream);
 /* The small per-channel steps between the two statistics passes, fused (they are launch-latency bound):
  * mean = sums[0:C] / count;  then from the shifted sums: biased variance, invstd = rsqrt(var + eps) and the
@@ -251,10 +252,10 @@ int wsr_bn_apply_lrelu(const void* x, void* y, const float* mean, const float* i
                        const float* gamma, const float* beta, int32_t C, int64_t nvox, int32_t act,
                        float slope, int32_t dtype, void* stream);
 /* backward, pass 1: g = dy * lrelu'(y) (written in place into dy);
- * sums[2*C] += {sum g, sum g*xhat}.                                            */
+ * sums[2*C] = {sum g, sum g*xhat} (`partials` as for wsr_bn_stats).              */
 int wsr_bn_bwd_reduce(void* dy, const void* y, const void* x, const float* mean, const float* invstd,
-                      int32_t C, int64_t nvox, int32_t act, float slope, float* sums, int32_t dtype,
-                      void* stream);
+                      int32_t C, int64_t nvox, int32_t act, float slope, float* sums, float* partials,
+                      int32_t dtype, void* stream);
 /* pass 2 (training): dx = gamma*invstd*(g - sum_g/n - xhat*sum_gxhat/n); eval:
  * dx = gamma*invstd*g (sums == NULL).                                          */
 int wsr_bn_bwd_apply(const void* g, const void* x, void* dx, const float* mean, const float* invstd,

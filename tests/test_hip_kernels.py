@@ -208,10 +208,10 @@ def test_batchnorm_kernels(hip, dt, C_):
     (yl * gy.permute(0, 4, 1, 2, 3).double()).sum().backward()
     n = x.numel() // C_
     xb = x.to(DEV).to(dt)
-    sums = torch.zeros(2 * C_, device=DEV)
+    sums = torch.full((2 * C_,), float("nan"), device=DEV)  # overwritten, not accumulated into
     o.bn_stats(xb, sums)
     mean = sums[:C_] / n
-    s2 = torch.zeros(2 * C_, device=DEV)
+    s2 = torch.full((2 * C_,), float("nan"), device=DEV)
     o.bn_stats(xb, s2, shift=mean)
     var = s2[C_:] / n - (s2[:C_] / n) ** 2
     assert rel_l2(mean.cpu(), xl.detach().mean(dim=(0, 2, 3, 4)).float()) < 1e-4
@@ -222,7 +222,7 @@ def test_batchnorm_kernels(hip, dt, C_):
     tol = 2e-5 if dt == torch.float32 else 6e-3
     assert rel_l2(yb.float().cpu(), yl.detach().permute(0, 2, 3, 4, 1).float()) < tol
     gb = gy.to(DEV).to(dt)
-    s2 = torch.zeros(2 * C_, device=DEV)
+    s2 = torch.full((2 * C_,), float("nan"), device=DEV)
     o.bn_bwd_reduce(gb, yb, xb, mean, invstd, True, 0.2, s2)
     assert rel_l2(s2[:C_].cpu(), bl.grad.float()) < (1e-4 if dt == torch.float32 else 1e-2)
     assert rel_l2(s2[C_:].cpu(), gl.grad.float()) < (1e-4 if dt == torch.float32 else 1e-2)
