@@ -35,11 +35,13 @@ int wsr_ct_run_wide(CtArgs& a, int tpk, hipStream_t st);    // conv_tile_wide.hi
 int wsr_ct_run_masked(CtArgs& a, int tpk, hipStream_t st);  // conv_tile_masked.hip
 int wsr_ct_run_narrow_masked(CtArgs& a, int tpk, hipStream_t st);  // conv_tile_narrow_masked.hip
 int wsr_ct_run_small(CtArgs& a, int tpk, hipStream_t st);          // conv_tile_small.hip
+int wsr_ct_run_strided(CtArgs& a, int tpk, hipStream_t st);        // conv_tile_strided.hip
 
 namespace {
 
 int dispatch_ct(CtArgs& a, int tpk, hipStream_t st) {
   const int N = a.Cout;
+  if ((a.sx | a.sy | a.sz) != 1) return wsr_ct_run_strided(a, tpk, st);
   // small volumes (< 128 tiles of 512 voxels): 128-voxel tiles where an instantiation exists
   if ((long)a.B * a.Xo * a.Yo * a.Zo < 128L * 512 && !getenv("WSR_CT_NOSMALL")) {
     const int rc = wsr_ct_run_small(a, tpk, st);
@@ -209,8 +211,10 @@ int wsr_conv1x1_bf16(const unsigned short* in, int in_ctot, int in_off, int red,
 extern "C" int wsr_conv3d_fwd_tile(const wsr_conv_t* c, const void* x, const void* wfrag, void* y,
                                    const wsr_epilogue_t* ep, void* stream) {
   if (!conv_geom_ok(c) || !x || !wfrag || !y) return WSR_EINVAL;
-  if (c->dtype != WSR_BF16 || (c->sx | c->sy | c->sz) != 1) return WSR_EUNSUPPORTED;
+  if (c->dtype != WSR_BF16 || c->sx > 2 || c->sy > 2 || c->sz > 2) return WSR_EUNSUPPORTED;
+  if ((c->sx | c->sy | c->sz) != 1 && (c->upsample_xy || getenv("WSR_CT_NOSTRIDE"))) return WSR_EUNSUPPORTED;
   CtArgs a{};
+  a.sx = c->sx; a.sy = c->sy; a.sz = c->sz;
   a.in = (const unsigned short*)x;
   a.wf = (const unsigned short*)wfrag;
   a.out = y;
@@ -239,7 +243,7 @@ extern "C" int wsr_conv3d_fwd_tile(const wsr_conv_t* c, const void* x, const voi
   a.KX = c->KX; a.KY = c->KY; a.KZ = c->KZ;
   a.px = c->px; a.py = c->py; a.pz = c->pz;
   if (c->KX * c->KY * c->KZ == 1 && !a.ups && !a.out_planar && !a.chan_scale && (c->px | c->py | c->pz) == 0 &&
-      a.act <= 1 && a.act_c1 == 0x7FFFFFFF) {
+      (c->sx | c->sy | c->sz) == 1 && a.act <= 1 && a.act_c1 == 0x7FFFFFFF) {
     const int rc = wsr_conv1x1_bf16(a.in, a.in_ctot, a.in_off, c->Cin, a.wf, (unsigned short*)a.out, a.out_ctot,
                                     a.out_off, a.Cout, (long)c->B * c->Xo * c->Yo * c->Zo, a.bias, a.res, a.res_ctot,
                                     a.res_off, a.res ? a.res_c1 : 0, a.alpha, a.beta, a.act, a.slope, nullptr,
@@ -265,6 +269,7 @@ extern "C" int wsr_conv3d_dgrad_tile(const wsr_conv_t* c, const void* dy, const 
   a.wf = (const unsigned short*)wfrag_t;
   a.out = dx;
   a.alpha = alpha;
+  a.sx = a.sy = a.sz = 1;
   a.act_c1 = 0x7FFFFFFF;
   a.out_planar = dx_planar ? 1 : 0;
   if (accumulate) {  // 1: every produced channel; n > 1: the first n (a multiple of 4) only

@@ -48,6 +48,7 @@ struct CtArgs {
   int cin_valid;                  // channels of the window that exist in memory (multiple of 8)
   int Cout, out_ctot, out_off;
   int KX, KY, KZ, px, py, pz;
+  int sx, sy, sz;   // output stride of the gather (forward convs of the discriminator's down-sampling layers; 1 elsewhere)
   int TX, TY, TZ;
   int tiles_x, tiles_y, tiles_z, ntiles;
   int nts;          // K-steps per chunk = ceil(taps / TPK)
@@ -114,7 +115,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_tile_kernel(const CtArgs a)
   CT_STAMP(0);
   CT_STAMP(6);
 
-  const int Lx = a.TX + a.KX - 1, Ly = a.TY + a.KY - 1, Lz = a.TZ + a.KZ - 1;
+  const int Lx = (a.TX - 1) * a.sx + a.KX, Ly = (a.TY - 1) * a.sy + a.KY, Lz = (a.TZ - 1) * a.sz + a.KZ;
   const int L = Lx * Ly * Lz;
   const int M = a.TX * a.TY * a.TZ;  // <= MR
   constexpr int MR = WM * TM * 16;    // MFMA rows of the workgroup
@@ -177,7 +178,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_tile_kernel(const CtArgs a)
 
   // The halo geometry is the same for every chunk, so each wave resolves the source of "its" DMA units
   // (u = wave + WAVES*k) once: element offset of the lane's voxel (or OOB), octet plane, LDS offset.
-  constexpr int XK = 10;  // max units per wave per chunk (checked on the host)
+  constexpr int XK = 13;  // max units per wave per chunk (checked on the host)
   unsigned xoff[XK];
   int xo8[VM ? 1 : XK], xdst[VM ? 1 : XK];  // voxel-major rows: octet = lane & 1, unit u lands at u KB
 #pragma unroll
@@ -197,7 +198,8 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_tile_kernel(const CtArgs a)
       }
       if (v < L) {
         const unsigned q = fdiv((unsigned)v, Lz, a.mg_Lz), hx = fdiv(q, Ly, a.mg_Ly);
-        const int gx = x0 - a.px + (int)hx, gy = y0 - a.py + (int)(q - hx * Ly), gz = z0 - a.pz + (int)(v - q * Lz);
+        const int gx = x0 * a.sx - a.px + (int)hx, gy = y0 * a.sy - a.py + (int)(q - hx * Ly),
+                  gz = z0 * a.sz - a.pz + (int)(v - q * Lz);
         if ((unsigned)gx < (unsigned)(a.Xi << U) && (unsigned)gy < (unsigned)(a.Yi << U) &&
             (unsigned)gz < (unsigned)a.Zi) {
           const long vox = (((long)b * a.Xi + (gx >> U)) * a.Yi + (gy >> U)) * a.Zi + gz;
@@ -235,7 +237,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_tile_kernel(const CtArgs a)
     const unsigned q = fdiv((unsigned)m, a.TZ, a.mg_TZ), ox = fdiv(q, a.TY, a.mg_TY);
     const unsigned oz = m - q * a.TZ, oy = q - ox * a.TY;
     mtab[m] = m < M ? (ox | (oy << 8) | (oz << 16)) : (1u << 24);
-    htab[m] = m < M ? (unsigned short)((ox * Ly + oy) * Lz + oz) : (unsigned short)0;
+    htab[m] = m < M ? (unsigned short)((ox * a.sx * Ly + oy * a.sy) * Lz + oz * a.sz) : (unsigned short)0;
   }
   // per-channel epilogue constants of this workgroup's columns: bias (where it applies) and
   // channel scale * alpha - fetched now, so that the epilogue finds them in LDS instead of waiting for
@@ -508,7 +510,8 @@ int launch_ct(CtArgs& a, hipStream_t st) {
   const int taps = a.KX * a.KY * a.KZ;
   constexpr int M = WM * TM * 16;  // table sizes follow the MFMA rows; the tile volume may be smaller
   if (a.TX * a.TY * a.TZ > M) return WSR_EUNSUPPORTED;
-  const int L = (a.TX + a.KX - 1) * (a.TY + a.KY - 1) * (a.TZ + a.KZ - 1);
+  if (a.sx < 1) a.sx = a.sy = a.sz = 1;
+  const int L = ((a.TX - 1) * a.sx + a.KX) * ((a.TY - 1) * a.sy + a.KY) * ((a.TZ - 1) * a.sz + a.KZ);
   if (L > 65535) return WSR_EUNSUPPORTED;
   a.nts = (taps + TPK - 1) / TPK;
   a.NT_total = (a.Cout + 15) / 16;
@@ -535,7 +538,7 @@ int launch_ct(CtArgs& a, hipStream_t st) {
     if (ts_max >= 3 || ts_max >= a.nts || a.xbufs == 1) break;
   }
   if (ts_max < 1) return WSR_EUNSUPPORTED;
-  if ((VM ? (L + 31) / 32 : ((L + 63) / 64) * PL) > 10 * WAVES) return WSR_EUNSUPPORTED;  // XK units per wave
+  if ((VM ? (L + 31) / 32 : ((L + 63) / 64) * PL) > 13 * WAVES) return WSR_EUNSUPPORTED;  // XK units per wave
   if ((long)a.B * a.Xi * a.Yi * a.Zi * a.in_ctot >= 0xFFFFFFFFL) return WSR_EUNSUPPORTED;  // 32-bit element offsets
   const int nph = (a.nts + ts_max - 1) / ts_max;
   a.TS = (a.nts + nph - 1) / nph;  // balanced stages
@@ -553,7 +556,7 @@ int launch_ct(CtArgs& a, hipStream_t st) {
     if ((long)a.ntiles * a.ngroups * dmax >= (1l << 32)) return WSR_EUNSUPPORTED;
   }
   a.mg_TZ = fdiv_magic(a.TZ); a.mg_TY = fdiv_magic(a.TY);
-  a.mg_Lz = fdiv_magic(a.TZ + a.KZ - 1); a.mg_Ly = fdiv_magic(a.TY + a.KY - 1);
+  a.mg_Lz = fdiv_magic((a.TZ - 1) * a.sz + a.KZ); a.mg_Ly = fdiv_magic((a.TY - 1) * a.sy + a.KY);
   a.mg_KZ = fdiv_magic(a.KZ); a.mg_KY = fdiv_magic(a.KY);
   a.mg_ng = fdiv_magic(a.ngroups); a.mg_tz = fdiv_magic(a.tiles_z);
   a.mg_ty = fdiv_magic(a.tiles_y); a.mg_tx = fdiv_magic(a.tiles_x);

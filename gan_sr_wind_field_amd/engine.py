@@ -243,7 +243,7 @@ class ProgramBase:
         sites = [s for s in self.conv_sites() if self.tile_ok(s)]
         fstack = list(self.stacked_fwd_specs())
         fcov = {id(p) for _, parts, _, _ in fstack for p, *_ in parts}
-        wanted = [(s.weight, False) for s in sites if id(s.weight) not in fcov]
+        wanted = [(s.weight, False) for s in self.conv_sites() if self.tile_fwd_ok(s) and id(s.weight) not in fcov]
         stacked = fstack
         if backward:
             dstack = list(self.stacked_dgrad_specs())
@@ -265,6 +265,11 @@ class ProgramBase:
         """LDS halo-tile kernels: bf16, stride 1 (everything in G; the k3 s1 convs of D)"""
         return self.use_tile and self.dt == torch.bfloat16 and s.stride == (1, 1, 1)
 
+    def tile_fwd_ok(self, s: ConvSite) -> bool:
+        """forward only: also the stride-2 down-sampling convs of D"""
+        return self.tile_ok(s) or (self.use_tile and self.dt == torch.bfloat16 and max(s.stride) <= 2
+                                   and not s.upsample)
+
     def _w(self, s: ConvSite) -> Tensor:
         return self.filters.get(s.weight, self.dt, False, self.cp(s.cin), s.cout)
 
@@ -285,7 +290,8 @@ class ProgramBase:
         bias = s.bias.detach() if s.bias is not None else None
 
         def run():
-            if self.tile_ok(s) and ops.conv_fwd_tile(d, x, self.filters.get_frag(s.weight, False), y, bias=bias, **ep):
+            if self.tile_fwd_ok(s) and ops.conv_fwd_tile(d, x, self.filters.get_frag(s.weight, False), y, bias=bias,
+                                                         **ep):
                 return
             if "res2" in ep:
                 raise RuntimeError("a second residual needs the streaming 1x1x1 kernel")

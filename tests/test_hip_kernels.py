@@ -498,3 +498,29 @@ def test_wind_gradient_forward_and_adjoint(hip):
     one = o.wind_gradient(fd.detach()[..., :1].contiguous(), xs.float().to("cuda:0"), ys.float().to("cuda:0"),
                           zc.float().to("cuda:0")[..., :1].contiguous())
     assert torch.equal(one[:, 6:], torch.zeros_like(one[:, 6:]))
+
+
+@pytest.mark.parametrize("name,cin,cout,k,s,p,xyz,B", [
+    ("d_down_s221", 64, 64, (4, 4, 3), (2, 2, 1), (1, 1, 1), (12, 10, 9), 1),     # blocks 1-3 of D
+    ("d_down_s222", 32, 32, (4, 4, 3), (2, 2, 2), (1, 1, 1), (16, 12, 22), 2),    # first / last block (halved z)
+    ("d_down_n256", 256, 256, (4, 4, 3), (2, 2, 1), (1, 1, 1), (8, 8, 6), 1),     # two 128-channel groups
+    ("d_down_k5", 32, 32, (4, 4, 5), (2, 2, 2), (1, 1, 2), (10, 12, 11), 1),      # feat_kern_size 5
+])
+def test_conv_tile_strided_forward_vs_cpu(hip, name, cin, cout, k, s, p, xyz, B):
+    """Stride-2 down-sampling convs of the discriminator (torch_blocks.py:138-142) through the halo-tile kernel:
+    forward with bias + LeakyReLU against an fp32 CPU conv of the same bf16-rounded operands."""
+    o = ops()
+    dt = torch.bfloat16
+    gen = torch.Generator().manual_seed(cin + 3 * cout + sum(s))
+    x = torch.randn((B, cin) + tuple(xyz), generator=gen).bfloat16().float()
+    w = (torch.randn((cout, cin) + tuple(k), generator=gen) / math.sqrt(cin * k[0] * k[1] * k[2])).bfloat16().float()
+    bias = torch.randn(cout, generator=gen)
+    geom = o.ConvGeom(cin, cout, k, s, p)
+    xb = to_ndhwc(x, cin, 0, dt)
+    d = o.make_desc(geom, dt, B, xyz, cin, 0, cout, 0)
+    oxyz = (d.Xo, d.Yo, d.Zo)
+    yb = torch.full((B,) + oxyz + (cout,), float("nan"), dtype=dt, device=DEV)
+    assert o.conv_fwd_tile(d, xb, o.pack_filter_frag(packed_master(w)), yb, bias=bias.to(DEV), act=True, slope=0.2)
+    ref = F.leaky_relu(F.conv3d(x, w, bias, s, p), 0.2)
+    assert tuple(ref.shape[2:]) == oxyz
+    assert rel_l2(from_ndhwc(yb, 0, cout), ref) < 4e-3, name
