@@ -178,7 +178,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_tile_kernel(const CtArgs a)
 
   // The halo geometry is the same for every chunk, so each wave resolves the source of "its" DMA units
   // (u = wave + WAVES*k) once: element offset of the lane's voxel (or OOB), octet plane, LDS offset.
-  constexpr int XK = 13;  // max units per wave per chunk (checked on the host)
+  constexpr int XK = TM <= 2 ? 13 : 10;  // max units per wave per chunk (checked on the host; strided tiles: 13)
   unsigned xoff[XK];
   int xo8[VM ? 1 : XK], xdst[VM ? 1 : XK];  // voxel-major rows: octet = lane & 1, unit u lands at u KB
 #pragma unroll
@@ -348,6 +348,9 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_tile_kernel(const CtArgs a)
       }
     };
     const int mid = (STAGGER && wave >= WAVES / 2) ? ts_end / 2 : 0;  // wave-uniform
+    // (explicit operand pipelines for the wide tiles - fragment rings, half-K-step prefetch with a fenced
+    // scheduler - were measured 8..30 % SLOWER than this plain loop: the compiler's own interleaving of the
+    // next K-step's LDS reads with the MFMAs is better than what the register budget leaves room to write)
     if (mid == 0) burst();
     run_ksteps(0, mid);
     if (mid > 0) burst();
@@ -538,7 +541,7 @@ int launch_ct(CtArgs& a, hipStream_t st) {
     if (ts_max >= 3 || ts_max >= a.nts || a.xbufs == 1) break;
   }
   if (ts_max < 1) return WSR_EUNSUPPORTED;
-  if ((VM ? (L + 31) / 32 : ((L + 63) / 64) * PL) > 13 * WAVES) return WSR_EUNSUPPORTED;  // XK units per wave
+  if ((VM ? (L + 31) / 32 : ((L + 63) / 64) * PL) > (TM <= 2 ? 13 : 10) * WAVES) return WSR_EUNSUPPORTED;  // XK units per wave
   if ((long)a.B * a.Xi * a.Yi * a.Zi * a.in_ctot >= 0xFFFFFFFFL) return WSR_EUNSUPPORTED;  // 32-bit element offsets
   const int nph = (a.nts + ts_max - 1) / ts_max;
   a.TS = (a.nts + nph - 1) / nph;  // balanced stages
