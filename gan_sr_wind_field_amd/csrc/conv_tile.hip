@@ -49,7 +49,10 @@ int dispatch_ct(CtArgs& a, int tpk, hipStream_t st) {
   }
   if (a.mask_y) return N <= 64 ? wsr_ct_run_narrow_masked(a, tpk, st) : wsr_ct_run_masked(a, tpk, st);
   if (N <= 64) return wsr_ct_run_narrow(a, tpk, st);
-  if (N == 144) return wsr_ct_run_n144(a, tpk, st);
+  // (short reductions - the z-folded last conv's input gradient, 16 channels x 25 taps - stay on the generic
+  // wide tiles: the 512-voxel N = 144 instantiation is kept for the 5x5x5 144 -> 144 conv it is tuned and
+  // profiled for)
+  if (N == 144 && (long)a.nchunks * a.KX * a.KY * a.KZ >= 256) return wsr_ct_run_n144(a, tpk, st);
   if (N > 64 && N <= 128 && !getenv("WSR_CT_NO_N128")) {  // (the env switch is a tuning aid)
     const int rc = wsr_ct_run_n128(a, tpk, st);
     if (rc != WSR_EUNSUPPORTED) return rc;
