@@ -36,7 +36,7 @@ struct C1Args {
   float mask_slope;
 };
 
-template <int TN, int TM, int KS, bool MASK, int WAVES>
+template <int TN, int TM, int KS, bool MASK, int WAVES, bool PF>
 __global__ __launch_bounds__(WAVES * 64) void conv1x1_kernel(const C1Args a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];  // KS * TN fragments of 1 KB
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -141,20 +141,34 @@ __global__ __launch_bounds__(WAVES * 64) void conv1x1_kernel(const C1Args a) {
       }
     }
   };
-  for (int strip = blockIdx.x * WAVES + wave; strip < a.nstrips; strip += stride) {
-    uint4 xa[KS][TM];
-    load_x(strip, xa);
-    do_strip(strip, xa);
+  if constexpr (PF) {  // the next strip's activation fragments are requested before this strip is computed
+    uint4 xa[KS][TM], xb[KS][TM];
+    int strip = blockIdx.x * WAVES + wave;
+    if (strip < a.nstrips) load_x(strip, xa);
+    for (; strip < a.nstrips; strip += 2 * stride) {
+      if (strip + stride < a.nstrips) load_x(strip + stride, xb);
+      do_strip(strip, xa);
+      if (strip + stride < a.nstrips) {
+        if (strip + 2 * stride < a.nstrips) load_x(strip + 2 * stride, xa);
+        do_strip(strip + stride, xb);
+      }
+    }
+  } else {
+    for (int strip = blockIdx.x * WAVES + wave; strip < a.nstrips; strip += stride) {
+      uint4 xa[KS][TM];
+      load_x(strip, xa);
+      do_strip(strip, xa);
+    }
   }
 }
 
-template <int TN, int TM, int KS, bool MASK>
+template <int TN, int TM, int KS, bool MASK, bool PF = false>
 int launch_c1(const C1Args& a0, hipStream_t st) {
   C1Args a = a0;
   a.nstrips = (int)((a.nvox + 16 * TM - 1) / (16 * TM));
   const size_t lds = (size_t)KS * TN * 1024;
   constexpr int WAVES = 4;  // (8 waves halve the register budget: the up-front loads of a strip then spill)
-  auto kern = conv1x1_kernel<TN, TM, KS, MASK, WAVES>;
+  auto kern = conv1x1_kernel<TN, TM, KS, MASK, WAVES, PF>;
   static bool attr_done = false;
   if (!attr_done) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -201,11 +215,14 @@ int wsr_conv1x1_bf16(const unsigned short* in, int in_ctot, int in_off, int red,
   if ((a.res || a.res2) && (a.act || a.alpha == 0.f)) return WSR_EUNSUPPORTED;  // residuals are folded into the accumulator start
   if (a.bias && ((size_t)a.bias & 15)) return WSR_EUNSUPPORTED;
   if (!mask) {
-    if (nt == 8 && ks == 8) return launch_c1<8, 2, 8, false>(a, st);    // 256 -> 128 (LFF forward)
+    if (nt == 8 && ks == 8) {  // 256 -> 128 (LFF forward): 16-voxel strips, next strip prefetched (-18 % vs <8,2,8>)
+      if (getenv("WSR_C1_NOPF")) return launch_c1<8, 2, 8, false>(a, st);
+      return launch_c1<8, 1, 8, false, true>(a, st);
+    }
     if (nt == 16 && ks == 4) return launch_c1<16, 1, 4, false>(a, st);  // 128 -> 256
     if (nt == 8 && ks == 4) return launch_c1<8, 2, 4, false>(a, st);    // 128 -> 128
   } else {
-    if (nt == 16 && ks == 4) return launch_c1<16, 1, 4, true>(a, st);   // 128 -> 256 (LFF input gradient)
+    if (nt == 16 && ks == 4) return launch_c1<16, 1, 4, true>(a, st);   // 128 -> 256 (LFF input gradient; prefetch spills)
     if (nt == 8 && ks == 4) return launch_c1<8, 2, 4, true>(a, st);
   }
   return WSR_EUNSUPPORTED;
