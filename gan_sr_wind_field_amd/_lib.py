@@ -48,7 +48,7 @@ class LreluMask(C.Structure):
     """``wsr_lrelu_mask_t``."""
 
     _fields_ = [("y", C.c_void_p), ("y_ctot", C.c_int32), ("y_off", C.c_int32), ("c0", C.c_int32), ("c1", C.c_int32),
-                ("slope", C.c_float)]
+                ("slope", C.c_float), ("chan_scale", C.c_void_p)]
 
 
 _lib: Optional[C.CDLL] = None

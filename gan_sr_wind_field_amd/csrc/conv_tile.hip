@@ -292,7 +292,8 @@ extern "C" int wsr_conv3d_dgrad_tile(const wsr_conv_t* c, const void* dy, const 
   a.Cout = c->Cin; a.out_ctot = c->in_ctot; a.out_off = c->in_off;
   a.KX = c->KX; a.KY = c->KY; a.KZ = c->KZ;
   a.px = c->KX - 1 - c->px; a.py = c->KY - 1 - c->py; a.pz = c->KZ - 1 - c->pz;
-  if (c->KX * c->KY * c->KZ == 1 && ux == 1 && !a.out_planar && (c->px | c->py | c->pz) == 0) {
+  if (mask && mask->chan_scale) a.chan_scale = mask->chan_scale;
+  if (c->KX * c->KY * c->KZ == 1 && ux == 1 && !a.out_planar && (c->px | c->py | c->pz) == 0 && !a.chan_scale) {
     const int rc = wsr_conv1x1_bf16(a.in, a.in_ctot, a.in_off, c->Cout, a.wf, (unsigned short*)a.out, a.out_ctot,
                                     a.out_off, a.Cout, (long)c->B * c->Xo * c->Yo * c->Zo, nullptr, a.res, a.res_ctot,
                                     a.res_off, a.res ? a.res_c1 : 0, a.alpha, a.beta, 0, 0.f, mask, nullptr, 0, 0, 0.f,

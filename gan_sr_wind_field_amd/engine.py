@@ -305,16 +305,17 @@ class ProgramBase:
     def dgrad(self, s: ConvSite, g: Tensor, g_off: int, dx: Tensor, dx_off: int, in_xyz, *, alpha: float = 1.0,
               accumulate: bool = False, dx_planar: bool = False, mask=None) -> None:
         """dx[window] (+)= alpha * conv^T(g[window]);  in_xyz = stored input extent of the conv.
-        ``mask`` = (y, y_off, c0, c1): afterwards multiply channels [c0, c1) of the window by the
-        LeakyReLU derivative taken from channels [y_off, ...) of ``y`` (folded into the tile kernel's
-        epilogue; a separate pass on the generic path)."""
+        ``mask`` = (y, y_off, c0, c1[, chan_scale]): afterwards multiply channels [c0, c1) of the window by the
+        LeakyReLU derivative taken from channels [y_off, ...) of ``y`` - and by the Dropout3d keep factors
+        ``chan_scale`` [B][c1-c0] when given (the mask then spans the whole window) - folded into the tile
+        kernel's epilogue; a separate pass on the generic path."""
         B = g.shape[0]
         cin = s.cin if dx_planar else self.cp(s.cin)
         d = self._desc(s, B, tuple(in_xyz), s.cin if dx_planar else dx.shape[-1], 0 if dx_planar else dx_off,
                        g.shape[-1], g_off, cin=cin, cout=self.cp(s.cout))
 
         def run():
-            m = None if mask is None else (mask[0], mask[1], mask[2], mask[3], self.slope)
+            m = None if mask is None else (mask[0], mask[1], mask[2], mask[3], self.slope) + tuple(mask[4:5])
             if self.tile_ok(s) and ops.conv_dgrad_tile(d, g, self.filters.get_frag(s.weight, True), dx, alpha=alpha,
                                                        accumulate=accumulate, dx_planar=dx_planar, mask=m):
                 return
@@ -322,7 +323,8 @@ class ProgramBase:
                 raise RuntimeError("partial accumulation needs the tile kernels (set WSR_GD_INPLACE=0)")
             ops.conv_dgrad(d, g, self._wt(s), dx, alpha=alpha, accumulate=accumulate, dx_planar=dx_planar)
             if mask is not None:
-                ops.lrelu_bwd_(dx, dx_off + mask[2], mask[0], mask[1], mask[3] - mask[2], self.slope)
+                ops.lrelu_bwd_(dx, dx_off + mask[2], mask[0], mask[1], mask[3] - mask[2], self.slope,
+                               chan_scale=mask[4] if len(mask) > 4 else None)
 
         if self.launch_probe is not None:
             self.launch_probe("dgrad:" + s.name, run)
@@ -725,6 +727,9 @@ class GeneratorProgram(ProgramBase):
         h, hcat = saved["h"], saved["hcat"]
         cat_c = h.shape[-1]
         gh = self._empty(h.shape, g_out)
+        # hr0's LeakyReLU + Dropout3d backward rides on the input gradient of hr1 (epilogue mask + keep factors)
+        drop = self._drop_padded(saved["drop"], cat_c)
+        hr0_mask = (h, 0, 0, cat_c) + ((drop,) if drop is not None else ())
         if self.zfold_active():  # adjoint of the folded forward: dy un-folded into cout*KZ channels
             kx, ky, kz = self.hr1.kernel
             cz = self.hr1.cout * kz
@@ -734,7 +739,7 @@ class GeneratorProgram(ProgramBase):
             if self._hr1z_grad is None or self._hr1z_grad.device != dev:
                 self._hr1z_grad = torch.empty_like(self.hr1z.weight, device=dev)
             self.wgrad(self.hr1z, h, 0, g3, 0, flat, sp, scratch, dst=self._hr1z_grad)
-            self.dgrad(self.hr1z, g3, 0, gh, 0, (sX, sY, nz))
+            self.dgrad(self.hr1z, g3, 0, gh, 0, (sX, sY, nz), mask=hr0_mask)
             self.flush_unpack()
             sp.view(flat, self.hr1.weight).copy_(
                 self._hr1z_grad.view(self.hr1.cout, kz, self.hr1.cin, kx, ky).permute(0, 2, 3, 4, 1))
@@ -743,12 +748,11 @@ class GeneratorProgram(ProgramBase):
             g3 = self._empty((B, sX, sY, nz, co_p), g_out)
             ops.planar_to_ndhwc(g_out, g3, 0, co_p)
             self.wgrad(self.hr1, h, 0, g3, 0, flat, sp, scratch)
-            self.dgrad(self.hr1, g3, 0, gh, 0, (sX, sY, nz))
+            self.dgrad(self.hr1, g3, 0, gh, 0, (sX, sY, nz), mask=hr0_mask)
         sp.view(flat, self.hr1.bias).copy_(g_out.sum(dim=(0, 2, 3, 4)))
         ready(self.hr1.weight, self.hr1.bias)
         del g3
-        # ---- hr0 (k5 + LReLU + Dropout3d mask)
-        ops.lrelu_bwd_(gh, 0, h, 0, cat_c, sl, chan_scale=self._drop_padded(saved["drop"], cat_c))
+        # ---- hr0 (k5 + LReLU + Dropout3d mask: already applied to gh above)
         self.wgrad(self.hr0, hcat, 0, gh, 0, flat, sp, scratch)
         ghcat = self._empty(hcat.shape, g_out)
         self.dgrad(self.hr0, gh, 0, ghcat, 0, (sX, sY, nz))

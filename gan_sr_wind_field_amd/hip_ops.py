@@ -148,10 +148,12 @@ def conv_dgrad_tile(desc: ConvDesc, dy: Tensor, wfrag_t: Tensor, dx: Tensor, *, 
     _need_cuda(dy, wfrag_t, dx)
     mp = None
     if mask is not None:
-        y, y_off, c0, c1, slope = mask
-        _need_cuda(y)
+        y, y_off, c0, c1, slope = mask[:5]
+        cs = mask[5] if len(mask) > 5 else None
+        _need_cuda(y, cs)
         m = _lib.LreluMask()
         m.y, m.y_ctot, m.y_off, m.c0, m.c1, m.slope = y.data_ptr(), y.shape[-1], y_off, c0, c1, slope
+        m.chan_scale = _p(cs)
         mp = C.byref(m)
     rc = _lib.lib().wsr_conv3d_dgrad_tile(C.byref(desc), _p(dy), _p(wfrag_t), _p(dx), alpha, int(accumulate),
                                           int(dx_planar), mp, _stream())

@@ -116,6 +116,8 @@ typedef struct wsr_lrelu_mask {
   const void* y;
   int32_t y_ctot, y_off, c0, c1;
   float slope;
+  const float* chan_scale;  /* optional [B][Cin]: every produced channel is also multiplied by it - the
+                               Dropout3d keep factors of that layer (Generator_3D...py:104), backward       */
 } wsr_lrelu_mask_t;
 int wsr_conv3d_dgrad_tile(const wsr_conv_t* c, const void* dy, const void* wfrag_t, void* dx, float alpha,
                           int accumulate, int dx_planar, const wsr_lrelu_mask_t* mask, void* stream);
