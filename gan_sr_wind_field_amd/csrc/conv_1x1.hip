@@ -36,24 +36,29 @@ struct C1Args {
   float mask_slope;
 };
 
-template <int TN, int TM, int KS, bool MASK, int WAVES, bool PF>
+// NH = 2: the produced channels are split in two halves of TN n-tiles handled by different waves of the
+// workgroup (both read the same activation strip): half the accumulators per wave, room for the prefetch.
+template <int TN, int TM, int KS, bool MASK, int WAVES, bool PF, int NH>
 __global__ __launch_bounds__(WAVES * 64) void conv1x1_kernel(const C1Args a) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];  // KS * TN fragments of 1 KB
+  constexpr int TNT = TN * NH, SW = WAVES / NH;  // n-tiles of the filter, waves per column half
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // KS * TNT fragments of 1 KB
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int fr = lane & 15, fg = lane >> 4;
   {  // stage the filter: linear copy of KS*TN KB
     const uint4* src = reinterpret_cast<const uint4*>(a.wf);
     uint4* dst = reinterpret_cast<uint4*>(smem);
-    for (int i = t; i < KS * TN * 64; i += WAVES * 64) dst[i] = src[i];
+    for (int i = t; i < KS * TNT * 64; i += WAVES * 64) dst[i] = src[i];
   }
   __syncthreads();
   const char* wl = smem + lane * 16;
+  const int jb = (wave / SW) * TN;  // first n-tile of this wave's column half
+  const int swave = wave % SW;
 
   // Per strip: every load (activation fragments, bias, residual, mask values) is requested before the first
   // store - a load placed after a store cannot be hoisted by the compiler (possible aliasing) and would
   // cost a memory round trip per tile.  (Prefetching the next strip's fragments into a second register set
   // was measured slower: 128 more VGPRs spill.)
-  const int stride = gridDim.x * WAVES;
+  const int stride = gridDim.x * SW;
   auto load_x = [&](int strip, uint4 (&xf)[KS][TM]) {
     const long v0 = (long)strip * (16 * TM);
 #pragma unroll
@@ -78,7 +83,7 @@ __global__ __launch_bounds__(WAVES * 64) void conv1x1_kernel(const C1Args a) {
       const bool vok = v < a.nvox;
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
-        const int co0 = 16 * j + 4 * fg;
+        const int co0 = 16 * (jb + j) + 4 * fg;
         const bool ok = vok && co0 < a.Cout;
         float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
         if (a.bias && co0 < a.Cout) b4 = *reinterpret_cast<const float4*>(a.bias + co0);
@@ -108,7 +113,7 @@ __global__ __launch_bounds__(WAVES * 64) void conv1x1_kernel(const C1Args a) {
     for (int ks = 0; ks < KS; ++ks) {
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
-        const uint4 w = *reinterpret_cast<const uint4*>(wl + (ks * TN + j) * 1024);
+        const uint4 w = *reinterpret_cast<const uint4*>(wl + (ks * TNT + jb + j) * 1024);
 #pragma unroll
         for (int i = 0; i < TM; ++i) mma_chunk<BF16>(acc[i][j], w, xf[ks][i]);
       }
@@ -121,7 +126,7 @@ __global__ __launch_bounds__(WAVES * 64) void conv1x1_kernel(const C1Args a) {
       unsigned short* o = a.out + v * a.out_ctot + a.out_off + 4 * fg;
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
-        const int co0 = 16 * j + 4 * fg;
+        const int co0 = 16 * (jb + j) + 4 * fg;
         if (co0 >= a.Cout) continue;  // Cout is a multiple of 4 here (checked on the host)
         float4 o4 = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
         if (a.act) {
@@ -137,13 +142,13 @@ __global__ __launch_bounds__(WAVES * 64) void conv1x1_kernel(const C1Args a) {
           o4.z *= (short)(yy[i][j].y & 0xFFFFu) > 0 ? 1.f : a.mask_slope;
           o4.w *= (int)yy[i][j].y > 0xFFFF ? 1.f : a.mask_slope;
         }
-        st4<BF16>(o + 16 * j, o4);
+        st4<BF16>(o + 16 * (jb + j), o4);
       }
     }
   };
   if constexpr (PF) {  // the next strip's activation fragments are requested before this strip is computed
     uint4 xa[KS][TM], xb[KS][TM];
-    int strip = blockIdx.x * WAVES + wave;
+    int strip = blockIdx.x * SW + swave;
     if (strip < a.nstrips) load_x(strip, xa);
     for (; strip < a.nstrips; strip += 2 * stride) {
       if (strip + stride < a.nstrips) load_x(strip + stride, xb);
@@ -154,7 +159,7 @@ __global__ __launch_bounds__(WAVES * 64) void conv1x1_kernel(const C1Args a) {
       }
     }
   } else {
-    for (int strip = blockIdx.x * WAVES + wave; strip < a.nstrips; strip += stride) {
+    for (int strip = blockIdx.x * SW + swave; strip < a.nstrips; strip += stride) {
       uint4 xa[KS][TM];
       load_x(strip, xa);
       do_strip(strip, xa);
@@ -162,13 +167,13 @@ __global__ __launch_bounds__(WAVES * 64) void conv1x1_kernel(const C1Args a) {
   }
 }
 
-template <int TN, int TM, int KS, bool MASK, bool PF = false>
+template <int TN, int TM, int KS, bool MASK, bool PF = false, int NH = 1>
 int launch_c1(const C1Args& a0, hipStream_t st) {
   C1Args a = a0;
   a.nstrips = (int)((a.nvox + 16 * TM - 1) / (16 * TM));
-  const size_t lds = (size_t)KS * TN * 1024;
+  const size_t lds = (size_t)KS * TN * NH * 1024;
   constexpr int WAVES = 4;  // (8 waves halve the register budget: the up-front loads of a strip then spill)
-  auto kern = conv1x1_kernel<TN, TM, KS, MASK, WAVES, PF>;
+  auto kern = conv1x1_kernel<TN, TM, KS, MASK, WAVES, PF, NH>;
   static bool attr_done = false;
   if (!attr_done) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -176,7 +181,7 @@ int launch_c1(const C1Args& a0, hipStream_t st) {
     if (e != hipSuccess) return (int)e;
     attr_done = true;
   }
-  int grid = (a.nstrips + WAVES - 1) / WAVES;
+  int grid = (a.nstrips + WAVES / NH - 1) / (WAVES / NH);
   const int cap = getenv("WSR_C1_GRID") ? atoi(getenv("WSR_C1_GRID")) : 256;  // one workgroup per CU measured best (tuning aid)
   if (grid > cap) grid = cap;  // the filter is staged once per workgroup
   hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(WAVES * 64), lds, st, a);
@@ -222,7 +227,9 @@ int wsr_conv1x1_bf16(const unsigned short* in, int in_ctot, int in_off, int red,
     if (nt == 16 && ks == 4) return launch_c1<16, 1, 4, false>(a, st);  // 128 -> 256
     if (nt == 8 && ks == 4) return launch_c1<8, 2, 4, false>(a, st);    // 128 -> 128
   } else {
-    if (nt == 16 && ks == 4) return launch_c1<16, 1, 4, true>(a, st);   // 128 -> 256 (LFF input gradient; prefetch spills)
+    // 128 -> 256 (LFF input gradient).  (Two column halves on different waves + prefetch, launch_c1<8,1,4,true,true,2>,
+    // was measured 11 % slower; prefetch alone spills.)
+    if (nt == 16 && ks == 4) return launch_c1<16, 1, 4, true>(a, st);
     if (nt == 8 && ks == 4) return launch_c1<8, 2, 4, true>(a, st);
   }
   return WSR_EUNSUPPORTED;
