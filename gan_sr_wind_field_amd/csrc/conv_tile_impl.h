@@ -202,8 +202,9 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_tile_kernel(const CtArgs a)
                   gz = z0 * a.sz - a.pz + (int)(v - q * Lz);
         if ((unsigned)gx < (unsigned)(a.Xi << U) && (unsigned)gy < (unsigned)(a.Yi << U) &&
             (unsigned)gz < (unsigned)a.Zi) {
-          const long vox = (((long)b * a.Xi + (gx >> U)) * a.Yi + (gy >> U)) * a.Zi + gz;
-          off = (unsigned)(vox * a.in_ctot + a.in_off + 8 * pl);
+          // 32-bit arithmetic: the host checked that the whole tensor is below 2^32 elements
+          const unsigned vox = (((unsigned)b * a.Xi + (gx >> U)) * a.Yi + (gy >> U)) * a.Zi + gz;
+          off = vox * (unsigned)a.in_ctot + (unsigned)(a.in_off + 8 * pl);
         }
       }
     }
