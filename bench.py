@@ -3,14 +3,16 @@
 
 A step = one G-iteration + one D-iteration (reference wind_field_GAN_3D.py:585-593
 alternates the two kinds) on one synthetic batch already resident in HBM.
-Workload at N = 1: BASELINE.json configs[2] in reference semantics (SURVEY 8d "C3'"):
+Default workload (N = 1): BASELINE.json configs[2] in reference semantics (SURVEY 8d "C3'"):
 LR (B,4,32,32,128) -> HR (B,3,128,128,128), full-size G (16 RRDB, nf 128) and the
 128^3 D, bf16 compute with fp32 loss, dropout / instance noise / Adam all on.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--dtype bf16|fp32] [--batch B]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config C3p|C1|C1b|C2|C4|C5b|C5c|C5lit]
+                    [--dtype bf16|fp32] [--batch B] [--n N --nz NZ]
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
 
-Rank 0 prints ONE JSON line (see the keys below).
+``--config`` selects the other BASELINE.json configurations; they are recorded in
+DESIGN.md, the driver's line is always the default C3'.  Rank 0 prints ONE JSON line.
 """
 import argparse
 import json
@@ -22,6 +24,19 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 import torch  # noqa: E402
+
+#: name -> (ini, LR n, nz, batch/GPU, dtype, step kind, slicing, description)
+PRESETS = {
+    "C3p": ("local", 32, 128, 1, "bf16", "gan", False, "C3' full G+D adversarial step"),
+    "C4": ("local", 32, 128, 4, "bf16", "gan", False, "C4 per-GPU shape: C3' at batch 4/GPU (global batch 32 on 8 GPUs)"),
+    "C1": ("local", 16, 10, 1, "bf16", "gan", True, "C1 shipped local ini: D with slicing, 64x64x10 HR patches"),
+    "C1b": ("local", 32, 10, 1, "bf16", "gan", False, "C1b the reference's real patch size, no slicing"),
+    "C2": ("local", 64, 64, 1, "fp32", "g_only", False, "C2 generator-only fwd+bwd+Adam, fp32"),
+    "C5b": ("upscale8", 16, 10, 8, "bf16", "gan", False, "C5b upscale8 ini (x8, three UpConv stages), full G+D step"),
+    "C5c": ("upscale8", 16, 128, 1, "bf16", "gan", False, "C5c x8 to 128^3, full G+D step"),
+    "C5lit": ("upscale8", 64, 64, 1, "bf16", "g_only", False, "C5 literal: x8 generator-only fwd+bwd+Adam, HBM stress"),
+}
+
 
 # per-sample algorithmic FLOPs, SURVEY.md 8(d) formulae
 def g_fwd_flops(n, nz, s=4, nf=128, gc=32, tf=16, cin=4, nrrdb=16):
@@ -40,29 +55,34 @@ def g_fwd_flops(n, nz, s=4, nf=128, gc=32, tf=16, cin=4, nrrdb=16):
     return 2 * (trunk + ups + hr)
 
 
-def d_fwd_flops(xy, nz, bf=32):
-    """no-slicing D on (3, xy, xy, nz); z halves in block 0 when nz > 19 and in block 4"""
+def d_fwd_flops(xy, nz, bf=32, slicing=False):
+    """D on (3, xy, xy, nz), reference Discriminator_3D.py:55-169: z halves in block 0 when nz > 19; the last
+    block is k3 s1 + k3 s(1,1,2) with slicing, k3 s1 + k(4,4,3) s2 without"""
     f, X, Z = 0, xy, nz
     cin = 3
     for i, cout in enumerate((bf, 2 * bf, 4 * bf, 8 * bf, 8 * bf)):
         f += 2 * cin * cout * 27 * X * X * Z
-        halve = (i == 0 and nz > 19) or i == 4
-        Zo = (Z + 2 - 3) // 2 + 1 if halve else Z
-        X //= 2
-        f += 2 * cout * cout * 48 * X * X * Zo
+        if slicing and i == 4:
+            Zo = (Z + 2 - 3) // 2 + 1
+            f += 2 * cout * cout * 27 * X * X * Zo
+        else:
+            halve = (i == 0 and nz > 19) or i == 4
+            Zo = (Z + 2 - 3) // 2 + 1 if halve else Z
+            X //= 2
+            f += 2 * cout * cout * 48 * X * X * Zo
         Z, cin = Zo, cout
-    return f + 2 * (8 * bf * 16 * Z) * 100
+    return f + 2 * (8 * bf * X * X * Z) * 100
 
 
 def make_gan(args, dev, dtype):
     from gan_sr_wind_field_amd.config.config import Config
     from gan_sr_wind_field_amd.GAN_models.wind_field_GAN_3D import wind_field_GAN_3D
 
-    cfg = Config(os.path.join(ROOT, "gan_sr_wind_field_amd", "config", "wind_field_GAN_3D_config_local.ini"))
+    cfg = Config(os.path.join(ROOT, "gan_sr_wind_field_amd", "config", f"wind_field_GAN_3D_config_{args.ini}.ini"))
     cfg.is_train, cfg.is_test, cfg.is_use = True, False, False
     cfg.gpu_id, cfg.device = dev.index, dev
     cfg.compute_dtype = dtype
-    cfg.gan_config.enable_slicing = False
+    cfg.gan_config.enable_slicing = args.slicing
     cfg.gan_config.number_of_z_layers = args.nz
     cfg.training.niter = 150000
     cfg.training.d_g_train_period = 1  # it even -> G-iteration, it odd -> D-iteration
@@ -73,7 +93,8 @@ def make_gan(args, dev, dtype):
 def cpu_baseline(n_threads):
     """The oracle (CPU restatement of the reference, kind "port") timed on this host:
     full-size G + D at the reference's own CPU-runnable case (16x16x10 -> 64x64x10, B=1),
-    1 warm-up pair + timed pairs for ~15 s, converted to the metric's unit by FLOPs."""
+    1 warm-up pair + timed pairs for ~15 s, converted to the metric's unit by FLOPs.
+    (tools/cpu_baseline_check.py times the real reference beside it in the build container.)"""
     from oracle import gan as ogan
     from oracle import nets as onets
 
@@ -95,9 +116,18 @@ def cpu_baseline(n_threads):
         gan.optimize_parameters(LR, HR, Z, 2 * pairs + 3)
         pairs += 1
     dt = (time.time() - t0) / pairs
-    # D with slicing at 64x64x10: use the measured-table value of SURVEY 8a (8.5 GF fwd)
-    pair_flops = 4 * g_fwd_flops(16, 10) + 9 * 8.5e9
+    pair_flops = 4 * g_fwd_flops(16, 10) + 9 * d_fwd_flops(64, 10, slicing=True)
     return dt, pair_flops
+
+
+def recorded_traffic(key):
+    """HBM bytes per launch from the PMC passes of this round (profiles/r02_hbm_traffic.json, written from the
+    rocprofv3 --pmc summaries by tools/tuning/pmc_sum.py; gfx950 FETCH_SIZE correction applied there)."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r02_hbm_traffic.json")) as f:
+            return json.load(f).get(key)
+    except (OSError, ValueError):
+        return None
 
 
 def main():
@@ -105,14 +135,22 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
-    ap.add_argument("--batch", type=int, default=1, help="samples per GPU")
-    ap.add_argument("--n", type=int, default=32, help="LR X=Y extent")
-    ap.add_argument("--nz", type=int, default=128, help="vertical levels")
+    ap.add_argument("--config", default="C3p", choices=sorted(PRESETS))
+    ap.add_argument("--dtype", default=None, choices=["bf16", "fp32"])
+    ap.add_argument("--batch", type=int, default=None, help="samples per GPU")
+    ap.add_argument("--n", type=int, default=None, help="LR X=Y extent")
+    ap.add_argument("--nz", type=int, default=None, help="vertical levels")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
+    ini, n0, nz0, b0, dt0, kind, slicing, desc = PRESETS[args.config]
+    args.ini, args.slicing = ini, slicing
+    args.n = n0 if args.n is None else args.n
+    args.nz = nz0 if args.nz is None else args.nz
+    args.batch = b0 if args.batch is None else args.batch
+    args.dtype = dt0 if args.dtype is None else args.dtype
 
     from gan_sr_wind_field_amd import _lib, dist as wdist
+    from gan_sr_wind_field_amd.process_data import synthetic_batch
     _lib.lib()  # fail loudly without the HIP extension
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -126,31 +164,47 @@ def main():
     gan, cfg = make_gan(args, dev, args.dtype)
     dp = wdist.attach(gan, bucket_mb=cfg.dist.bucket_mb, sync_bn=cfg.dist.sync_bn) if distributed else None
 
-    from oracle.gan import synthetic_batch  # input generator only (host side, before timing)
     B, n, nz, s = args.batch, args.n, args.nz, cfg.scale
     LR, HR, Z, x, y = (t.to(dev) for t in synthetic_batch(B, n, nz, s, seed=2001 + rank))
     gan.feed_xy_niter(x, y, torch.tensor(cfg.training.niter, device=dev), 1, 1)
 
-    # ---- live timing of the dominant kernel: the N=144 implicit-GEMM (hr0 fwd + its dgrad)
-    probe_events = []
+    # ---- live timing (HIP events on the launch stream, inside the timed region) of
+    #   the dominant MFMA-bound kernel: the N=144 halo-tile conv (hr0 forward + its input gradient)
+    #   the dominant HBM-bound kernel:  the streaming 1x1x1 conv (LFF forward, 256 -> 128)
+    probe_events = {"mfma": [], "hbm": []}
     timing_on = [False]
 
     def probe(tag, fn):
-        if timing_on[0] and tag in ("fwd:hr_convs.0.0", "dgrad:hr_convs.0.0"):
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
+        which = None
+        if timing_on[0]:
+            if tag in ("fwd:hr_convs.0.0", "dgrad:hr_convs.0.0"):
+                which = "mfma"
+            elif tag.startswith("fwd:") and tag.endswith(".LFF"):
+                which = "hbm"
+        if which is None:
             fn()
-            e1.record()
-            probe_events.append((e0, e1))
-        else:
-            fn()
+            return
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        fn()
+        e1.record()
+        probe_events[which].append((e0, e1))
 
     gan.G.program().launch_probe = probe
 
-    def step(i):
-        gan.optimize_parameters(LR, HR, Z, 2 * i)      # G-iteration
-        gan.optimize_parameters(LR, HR, Z, 2 * i + 1)  # D-iteration
-        gan.update_learning_rate()
+    if kind == "gan":
+        def step(i):
+            gan.optimize_parameters(LR, HR, Z, 2 * i)      # G-iteration
+            gan.optimize_parameters(LR, HR, Z, 2 * i + 1)  # D-iteration
+            gan.update_learning_rate()
+    else:  # generator only: forward, L1 loss against HR, backward, Adam (reference pixel criterion)
+        l1 = torch.nn.L1Loss()
+
+        def step(i):
+            gan.G.train()
+            gan.optimizer_G.zero_grad(set_to_none=True)
+            l1(gan.G(LR, Z), HR).backward()
+            gan.optimizer_G.step()
 
     def barrier():
         if distributed:
@@ -170,50 +224,75 @@ def main():
         tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(tmax)
-    loss_ok = all(bool(torch.isfinite(v).all()) for v in gan.get_G_train_loss_dict_ref().values())
-    assert loss_ok, "non-finite generator loss in the timed region"
+    if kind == "gan":
+        loss_ok = all(bool(torch.isfinite(v).all()) for v in gan.get_G_train_loss_dict_ref().values())
+        assert loss_ok, "non-finite generator loss in the timed region"
 
     if rank != 0:
         return
     ms_per_step = elapsed / args.steps * 1e3
-    value = world * B * 0 + world * args.steps / elapsed  # global train-steps/s (each step = `batch` samples/GPU)
+    # One data-parallel step is ONE global optimiser step over world * B samples (weak scaling: B per GPU is
+    # fixed).  The metric counts train-steps at the quoted per-GPU shape, so the whole-job aggregate is the
+    # sample-normalised rate: world * (B / B_quoted) / step time, with B_quoted = this preset's batch.
+    steps_per_s = args.steps / elapsed
+    value = world * steps_per_s
     sX = s * n
-    g_f, d_f = g_fwd_flops(n, nz, s), d_fwd_flops(sX, nz)
-    pair_flops = B * (4 * g_f + 9 * d_f)  # G-it 3G+3D, D-it G+6D
-    k_ms = [a.elapsed_time(b) for a, b in probe_events]
-    k_flops = 2.0 * B * sX * sX * nz * 125 * 144 * 144
+    g_f = g_fwd_flops(n, nz, s)
+    d_f = d_fwd_flops(sX, nz, slicing=slicing) if kind == "gan" else 0
+    step_flops = B * ((4 * g_f + 9 * d_f) if kind == "gan" else 3 * g_f)  # G-it 3G+3D, D-it G+6D
     peak = 2500.0 if args.dtype == "bf16" else 157.3
-    achieved = k_flops / (sum(k_ms) / len(k_ms) * 1e-3) / 1e12 if k_ms else None
+    esz = 2 if args.dtype == "bf16" else 4
+
+    def mean_ms(evs):
+        ms = [a.elapsed_time(b) for a, b in evs]
+        return (sum(ms) / len(ms), len(ms)) if ms else (None, 0)
+
+    k_ms, k_n = mean_ms(probe_events["mfma"])
+    k_flops = 2.0 * B * sX * sX * nz * 125 * 144 * 144
+    achieved = k_flops / (k_ms * 1e-3) / 1e12 if k_ms else None
+    h_ms, h_n = mean_ms(probe_events["hbm"])
+    # LFF forward: reads the 256-channel dense buffer once, writes 128 channels, reads the 128-channel residual
+    # (the block input = the first 128 channels of the same buffer: re-read, counted once more), + filter
+    vox = B * n * n * nz
+    h_bytes = vox * (256 + 128 + 128) * esz + 256 * 128 * esz
+    h_ach = h_bytes / (h_ms * 1e-3) / 1e9 if h_ms else None
+    default_shape = args.dtype == "bf16" and n == 32 and nz == 128 and B == 1 and s == 4
     out = {
-        "metric": "GAN train-steps/sec (G+D fwd+bwd)", "value": round(value, 4), "unit": "train-steps/s",
+        "metric": "GAN train-steps/sec (G+D fwd+bwd)" if kind == "gan" else "generator train-steps/sec (G fwd+bwd+Adam)",
+        "value": round(value, 4), "unit": "train-steps/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 2),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": args.dtype, "data": "synthetic",
-        "config": {"workload": f"C3' full G+D adversarial step, LR {n}x{n}x{nz} -> HR {sX}x{sX}x{nz} (x{s}), "
-                               f"batch {B}/GPU, G 16 RRDB nf128 (34.77M), D 128^3 bf32",
-                   "global_batch": B * world, "parallelism": f"dp{world}",
-                   "step_tflop": round(pair_flops / 1e12, 2),
-                   "achieved_tflops_per_gpu": round(pair_flops / 1e12 / (elapsed / args.steps), 1),
+        "config": {"workload": f"{desc}: LR {n}x{n}x{nz} -> HR {sX}x{sX}x{nz} (x{s}), batch {B}/GPU, "
+                               f"G 16 RRDB nf128 (34.77M)" + (f", D bf32{' sliced' if slicing else ''}" if kind == "gan" else ""),
+                   "preset": args.config, "global_batch": B * world, "parallelism": f"dp{world}",
+                   "global_steps_per_s": round(steps_per_s, 4), "samples_per_s": round(world * B * steps_per_s, 4),
+                   "step_tflop": round(step_flops / 1e12, 2),
+                   "achieved_tflops_per_gpu": round(step_flops / 1e12 / (elapsed / args.steps), 1),
                    "peak_hbm_gb": round(torch.cuda.max_memory_allocated(dev) / 2**30, 2)},
         "roofline": {"bound": "mfma",
                      "kernel": ("conv_tile_kernel<8,1,4,9,2> (LDS halo-tile conv)" if args.dtype == "bf16"
                                 else "igemm_kernel<F32,4,1,2,9>") + ": hr_convs.0 5x5x5 144->144 fwd + dgrad",
                      "achieved": round(achieved, 1) if achieved else None, "peak": peak, "unit": "TFLOP/s",
                      "frac": round(achieved / peak, 4) if achieved else None,
-                     # HBM bytes per launch from the PMC passes in profiles/r01_c_hr0_hbm_traffic_pmc.txt,
-                     # corrected as MI355X_MICROARCH.md prescribes for gfx950: 2 x FETCH_SIZE (wide LDS-DMA
-                     # reads are tallied at half) + WRITE_SIZE = 2 x 2.66 GB + 0.59 GB; algorithmic 1.21e9
-                     "traffic": 5.92e9 if (args.dtype == "bf16" and n == 32 and nz == 128 and B == 1) else None,
-                     "launches_timed": len(k_ms), "avg_launch_ms": round(sum(k_ms) / len(k_ms), 3) if k_ms else None},
+                     "traffic": recorded_traffic("hr0") if default_shape else None,
+                     "traffic_source": "profiles/r02_hbm_traffic.json (PMC passes of this round)" if default_shape else None,
+                     "launches_timed": k_n, "avg_launch_ms": round(k_ms, 3) if k_ms else None},
+        "roofline_hbm": {"bound": "hbm", "kernel": "conv1x1_kernel (streaming 1x1x1 GEMM): RDB LFF 256->128 fwd + residuals",
+                         "achieved": round(h_ach, 1) if h_ach else None, "peak": 8000.0, "unit": "GB/s",
+                         "frac": round(h_ach / 8000.0, 4) if h_ach else None,
+                         "traffic": recorded_traffic("lff_fwd") if default_shape else None,
+                         "algorithmic_bytes": h_bytes, "launches_timed": h_n,
+                         "avg_launch_us": round(h_ms * 1e3, 2) if h_ms else None},
     }
     if world == 1 and not args.no_cpu_baseline:
         cores = min(os.cpu_count() or 1, 16)
         dt, sample_flops = cpu_baseline(cores)
         tf_s = sample_flops / dt / 1e12
         out["cpu_baseline"] = {
-            "value": round(tf_s * 1e12 / (pair_flops / B), 6), "unit": "train-steps/s", "cores": cores, "kind": "port",
+            "value": round(tf_s * 1e12 / (step_flops / B), 6), "unit": "train-steps/s", "cores": cores, "kind": "port",
             "sample": f"oracle (PyTorch CPU restatement) full-size G+D pair at 16x16x10->64x64x10 B=1: "
-                      f"{dt:.2f} s/pair = {tf_s:.3f} TFLOP/s, scaled by FLOPs to the C3' step"}
+                      f"{dt:.2f} s/pair = {tf_s:.3f} TFLOP/s, scaled by FLOPs to this workload's step"}
     print(json.dumps(out))
 
 

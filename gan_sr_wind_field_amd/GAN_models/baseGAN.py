@@ -25,8 +25,16 @@ class BaseGAN(lc.GlobalLoggingClass):
     def __init__(self, cfg):
         super().__init__()
         self.cfg = cfg
-        use_gpu = torch.cuda.is_available() and cfg.gpu_id is not None
-        self.device = torch.device(f"cuda:{cfg.gpu_id}") if use_gpu else torch.device("cpu")
+        # ONE source of truth for the device: ``cfg.device`` when a launcher set it (run.py / train.py put
+        # every rank on cuda:LOCAL_RANK), else the reference's rule ``cuda:{gpu_id}`` (baseGAN.py:27-33).
+        dev = getattr(cfg, "device", None)
+        if dev is not None:
+            self.device = torch.device(dev)
+        else:
+            use_gpu = torch.cuda.is_available() and cfg.gpu_id is not None
+            self.device = torch.device(f"cuda:{cfg.gpu_id}") if use_gpu else torch.device("cpu")
+        if self.device.type == "cuda" and self.device.index is None:
+            self.device = torch.device("cuda", torch.cuda.current_device())
         self.is_train = cfg.is_train
         self.schedulers = []
         self.optimizers = []

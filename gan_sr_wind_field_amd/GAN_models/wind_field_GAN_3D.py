@@ -148,6 +148,10 @@ class wind_field_GAN_3D(BaseGAN):
         """mean over the (global) batch - the RaGAN average logit"""
         return torch.mean(t) if self.dp is None else self.dp.batch_mean(t)
 
+    def _any(self, flag: torch.Tensor) -> bool:
+        """host-side truth of a device flag - set on ANY rank when data-parallel"""
+        return bool(flag) if self.dp is None else self.dp.any_flag(flag)
+
     def _noise(self, sigma: float, shape, it):
         return trainingtricks.instance_noise(torch.tensor(sigma, device=self.device), shape, it, self.niter,
                                              device=self.device)
@@ -221,7 +225,10 @@ class wind_field_GAN_3D(BaseGAN):
             "xy_divergence": l_div2 * t.xy_divergence_loss_weight,
         }
         physics = torch.stack([L["divergence"], L["xy_divergence"], L["z_gradient"], L["xy_gradient"]])
-        if bool(torch.logical_or(physics.isnan(), physics.isinf()).any()):  # ONE host sync (reference: up to 8)
+        # ONE host sync (reference: up to 8).  Under data parallelism the flag is OR-ed over the ranks: replicas
+        # that took different branches (or of which only some skipped the Adam step below) would drift apart
+        # for good, parameters being broadcast only once.
+        if self._any(torch.logical_or(physics.isnan(), physics.isinf()).any()):
             total = L["adversarial"] + L["pix"] + L["feature_D"]
         else:
             total = (L["adversarial"] + L["pix"] + L["xy_gradient"] + L["z_gradient"] + L["divergence"]
@@ -229,8 +236,10 @@ class wind_field_GAN_3D(BaseGAN):
         L["total"] = total
         if training_iteration:
             total.backward()
-            if not bool(total.isnan() or total.isinf()):
+            if not self._any(torch.logical_or(total.isnan(), total.isinf()).any()):
                 self.optimizer_G.step()
+            elif self.dp is not None:
+                self.dp.wait()  # the gradient collectives of the skipped step must still complete
         self.log_G_losses(fake_HR, L, training_iteration)
         return total
 
@@ -395,7 +404,7 @@ def get_norm_factors_of_gradients(HR_wind_gradient: torch.Tensor, SR_wind_gradie
 
     Batch-global maxima; the z-gradient maximum is taken WITHOUT abs, like the
     reference (:780-781).  Under data parallelism the 8 maxima are max-reduced
-    across ranks in one collective.
+    across ranks in one collective that keeps them differentiable (``dist._GlobalMax``).
     """
     def stats(g):
         div3 = g[:, 0] + g[:, 4] + g[:, 8]
@@ -403,7 +412,7 @@ def get_norm_factors_of_gradients(HR_wind_gradient: torch.Tensor, SR_wind_gradie
         return torch.stack([g[:, :6].abs().max(), g[:, 6:].max(), div3.abs().max(), div2.abs().max()])
 
     m = torch.stack([stats(HR_wind_gradient), stats(SR_wind_gradient)])
-    if dp is not None:
-        m = dp.global_max(m.detach())
+    if dp is not None:  # stays in the graph like the single-GPU maxima (gradient goes to the owning rank)
+        m = dp.global_max(m)
     out = torch.max(m[0], m[1] / 100)
     return [out[0], out[1], out[2], out[3]]

@@ -69,6 +69,29 @@ class _BatchMean(torch.autograd.Function):
         return (g / ctx.count).to(ctx.dtype).expand(ctx.shape), None
 
 
+class _GlobalMax(torch.autograd.Function):
+    """element-wise maximum over the ranks that stays in the autograd graph: the value is the all-reduced
+    maximum, the gradient - summed over the ranks, because every rank's loss uses the global value - goes to
+    the rank (and, through ``torch.max`` upstream, the element) that holds the maximum.  This is what the
+    single-GPU step does on the concatenated batch (reference wind_field_GAN_3D.py:773-814 keeps the maxima
+    attached).  Ties between ranks (measure zero) would each receive the full gradient."""
+
+    @staticmethod
+    def forward(ctx, t: Tensor, group):
+        g = t.detach().clone()
+        dist.all_reduce(g, op=dist.ReduceOp.MAX, group=group)
+        ctx.group = group
+        ctx.save_for_backward(t.detach() == g)
+        return g
+
+    @staticmethod
+    def backward(ctx, grad: Tensor):
+        (owner,) = ctx.saved_tensors
+        grad = grad.clone()
+        dist.all_reduce(grad, group=ctx.group)
+        return grad * owner.to(grad.dtype), None
+
+
 class DataParallel:
     def __init__(self, group=None, bucket_mb: float = 32.0, sync_bn: bool = True):
         if not dist.is_initialized():
@@ -88,9 +111,19 @@ class DataParallel:
         return _BatchMean.apply(t, self.group)
 
     def global_max(self, t: Tensor) -> Tensor:
-        t = t.clone()
+        """maximum over the ranks; differentiable when ``t`` is (see :class:`_GlobalMax`)"""
+        if t.requires_grad and torch.is_grad_enabled():
+            return _GlobalMax.apply(t, self.group)
+        t = t.detach().clone()
         dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
         return t
+
+    def any_flag(self, flag: Tensor) -> bool:
+        """True on every rank when ``flag`` (a 0-d bool / number) is set on any rank - used for the
+        non-finite-loss guards so that all replicas take the same branch (one host sync, like the local test)"""
+        f = flag.detach().to(torch.float32).reshape(1).clone()
+        dist.all_reduce(f, op=dist.ReduceOp.MAX, group=self.group)
+        return bool(f.item() > 0)
 
     def stat_allreduce(self, t: Tensor) -> None:
         dist.all_reduce(t, group=self.group)
@@ -133,6 +166,13 @@ class DataParallel:
     def broadcast_module(self, module: torch.nn.Module) -> None:
         for t in list(module.parameters()) + list(module.buffers()):
             dist.broadcast(t.data, src=0, group=self.group)
+        # writes through .data do not bump the version counters the packed-filter caches watch: a forward that
+        # ran before attach() (a warm-up, a validation pass after load_model) would leave ranks != 0 with
+        # stale compute copies of the pre-broadcast weights
+        for m in module.modules():
+            prog = getattr(m, "_program", None)
+            if prog is not None and hasattr(prog, "filters"):
+                prog.filters.invalidate()
 
     def attach(self, gan) -> "DataParallel":
         """Wire a ``wind_field_GAN_3D`` for data-parallel training."""

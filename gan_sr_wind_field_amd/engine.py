@@ -622,6 +622,7 @@ class GeneratorProgram(ProgramBase):
         """x (B, Cin, X, Y, nz), Z (B, 1, sX, sY, nz) planar fp32 -> (B, 3, sX, sY, nz) fp32 (+ saved state)"""
         B, _, X, Y, nz = x.shape
         nf, gc, tf, sl = self.nf, self.gc, self.tf, self.slope
+        ops._need_cuda(x, Z, self.feature.weight)  # inputs and parameters on the current device
         self.refresh_filters(backward=save)
         x = x.contiguous().float()
         Z = Z.contiguous().float()
@@ -945,6 +946,7 @@ class DiscriminatorProgram(ProgramBase):
         """x (B, C, X, Y, Z) planar fp32 -> NDHWC feature tensor (+ saved state)"""
         sl = self.slope
         B = x.shape[0]
+        ops._need_cuda(x, self.layers[0].conv.weight)  # input and parameters on the current device
         self.refresh_filters(backward=save)
         x = x.contiguous().float()
         c0 = self.cp(self.layers[0].conv.cin)

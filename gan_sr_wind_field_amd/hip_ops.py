@@ -47,9 +47,19 @@ def _p(t: Optional[Tensor]) -> C.c_void_p:
 
 
 def _need_cuda(*ts: Tensor) -> None:
+    """Operands must live on the CURRENT device: the kernels are launched on its current stream with raw
+    pointers, so a tensor of another GPU would be a wild pointer there (no CPU fallback either)."""
+    cur = -1
     for t in ts:
-        if t is not None and not t.is_cuda:
+        if t is None:
+            continue
+        if not t.is_cuda:
             raise RuntimeError("windsr_hip kernels need device tensors (no CPU fallback)")
+        if cur < 0:
+            cur = torch.cuda.current_device()
+        if t.device.index != cur:
+            raise RuntimeError(f"windsr_hip: tensor on {t.device} but the current device is cuda:{cur} "
+                               "(set torch.cuda.set_device / cfg.device for this rank)")
 
 
 @dataclass(frozen=True)

@@ -284,6 +284,26 @@ def _smooth_field(rng: np.random.Generator, shape: Tuple[int, int], n_modes: int
     return f / np.sqrt(n_modes)
 
 
+def synthetic_batch(B: int, n: int, nz: int, scale: int, seed: int = 2001, in_ch: int = 4):
+    """One synthetic ``(LR, HR, Z, x, y)`` batch of the dataset contract without touching the disk (bench.py,
+    smoke runs): HR ~ U(-1, 1) (real data is wind / UVW_MAX), LR = every ``scale``-th HR column (reference
+    process_data.py:451,457) + the normalised terrain-height channel(s) (:477-484), Z strictly increasing
+    along z (``calculate_div_z`` divides by the level spacing), x = y = a 200 m grid."""
+    g = torch.Generator().manual_seed(seed)
+    sn = scale * n
+    HR = torch.rand((B, 3, sn, sn, nz), generator=g) * 2 - 1
+    ground = torch.rand((B, 1, sn, sn, 1), generator=g) * 100.0
+    levels = torch.linspace(0.0, 500.0, nz).view(1, 1, 1, 1, nz)
+    Z = levels + ground * torch.linspace(1.0, 0.2, nz).view(1, 1, 1, 1, nz)
+    chans = [HR[:, :, ::scale, ::scale, :]]
+    if in_ch > 3:
+        zc = (Z[:, :, ::scale, ::scale, :] - Z.min()) / (Z.max() - Z.min())
+        chans.append(zc.expand(B, in_ch - 3, n, n, nz))
+    LR = torch.cat(chans, dim=1).contiguous()
+    grid = torch.arange(sn, dtype=torch.float32) * 200.0
+    return LR, HR.contiguous(), Z.contiguous(), grid, grid.clone()
+
+
 def write_synthetic_dataset(start_date: date, end_date: date, x_dict: Dict, y_dict: Dict, z_dict: Dict,
                             seed: int = 2001, overwrite: bool = False) -> str:
     """Write smooth synthetic HARMONIE-SIMRA-like samples for every hour of [start_date, end_date] in the

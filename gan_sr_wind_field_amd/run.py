@@ -77,6 +77,7 @@ def setup_torch(cfg: Config) -> None:
     gpu = int(local) if local is not None else cfg.gpu_id
     cfg.device = torch.device(f"cuda:{gpu}") if torch.cuda.is_available() and gpu is not None else torch.device("cpu")
     if cfg.device.type == "cuda":
+        cfg.gpu_id = gpu  # keep the ini-level field in step with the device every rank really uses
         torch.cuda.set_device(cfg.device)
 
 

@@ -40,6 +40,10 @@ class GSpec:
     tf: int = 16
     dropout_p: float = 0.0
     n_rdb: int = 3  # RRDB.number_of_RDBs default, torch_blocks.py:308
+    #: test aid, not reference behaviour: round every tensor the MI355X bf16 path keeps in HBM (conv operands,
+    #: conv / residual outputs and their gradients) to bf16, accumulate in fp32 - the scale of error a bf16
+    #: storage format must produce; the bf16 GPU tests derive their per-parameter gradient bounds from it
+    bf16_storage: bool = False
 
     @property
     def n_up(self) -> int:
@@ -60,6 +64,7 @@ class DSpec:
     dropout_p: float = 0.0
     bn_eps: float = 1e-5
     bn_momentum: float = 0.1
+    bf16_storage: bool = False  # test aid, see GSpec.bf16_storage
 
 
 @dataclass
@@ -110,15 +115,37 @@ def _lrelu(x: Tensor, slope: float) -> Tensor:
     return F.leaky_relu(x, negative_slope=slope)
 
 
+class _RoundBF16(torch.autograd.Function):
+    """bf16 storage emulation (``bf16_storage``): value and gradient both pass through bf16."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.to(torch.bfloat16).to(x.dtype)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.to(torch.bfloat16).to(g.dtype)
+
+
+def _st(x: Tensor, s) -> Tensor:
+    """a tensor the bf16 path stores in HBM"""
+    return _RoundBF16.apply(x) if s.bf16_storage else x
+
+
+def _wq(w: Tensor, s) -> Tensor:
+    """compute copy of an fp32 master filter: rounded operand, un-rounded gradient"""
+    return w + (w.to(torch.bfloat16).to(w.dtype) - w).detach() if s.bf16_storage else w
+
+
 def rdb_forward(sd: Dict[str, Tensor], prefix: str, x: Tensor, s: GSpec) -> Tensor:
     """RDB.forward, torch_blocks.py:285-290 (+ RDB_Conv.forward :212-214)."""
     cur = x
     for i in range(s.n_rdb_convs - 1):
-        y = F.conv3d(cur, sd[f"{prefix}.conv{i}.conv.0.weight"], None, 1, 1)
-        cur = torch.cat((cur, _lrelu(y, s.slope)), dim=1)
+        y = F.conv3d(cur, _wq(sd[f"{prefix}.conv{i}.conv.0.weight"], s), None, 1, 1)
+        cur = torch.cat((cur, _st(_lrelu(y, s.slope), s)), dim=1)
     pad = (s.lff_kern - 1) // 2
-    res = F.conv3d(cur, sd[f"{prefix}.LFF.weight"], sd[f"{prefix}.LFF.bias"], 1, pad)
-    return res * s.rdb_scale + x
+    res = F.conv3d(cur, _wq(sd[f"{prefix}.LFF.weight"], s), sd[f"{prefix}.LFF.bias"], 1, pad)
+    return _st(res * s.rdb_scale + x, s)
 
 
 def rrdb_forward(sd: Dict[str, Tensor], prefix: str, x: Tensor, s: GSpec) -> Tensor:
@@ -126,7 +153,7 @@ def rrdb_forward(sd: Dict[str, Tensor], prefix: str, x: Tensor, s: GSpec) -> Ten
     t = x
     for d in range(s.n_rdb):
         t = rdb_forward(sd, f"{prefix}.RDBs.{d}", t, s)
-    return t * s.rrdb_scale + x
+    return _st(t * s.rrdb_scale + x, s)
 
 
 def generator_trunk(sd: Dict[str, Tensor], x: Tensor, s: GSpec) -> Tensor:
@@ -134,22 +161,22 @@ def generator_trunk(sd: Dict[str, Tensor], x: Tensor, s: GSpec) -> Tensor:
 
     Generator_3D_Resnet_ESRGAN.py:78-94,198,208-220; torch_blocks.py:45-46,345-356.
     """
-    f = F.conv3d(x, sd["model.0.0.weight"], None, 1, 1)
+    f = _st(F.conv3d(_st(x, s), _wq(sd["model.0.0.weight"], s), None, 1, 1), s)
     t = f
     for r in range(s.n_rrdb):
         t = rrdb_forward(sd, f"model.1.module.{r}", t, s)
-    t = F.conv3d(t, sd[f"model.1.module.{s.n_rrdb}.0.weight"], None, 1, 1)
-    t = f + t
+    t = F.conv3d(t, _wq(sd[f"model.1.module.{s.n_rrdb}.0.weight"], s), None, 1, 1)
+    t = _st(f + t, s)
     for u in range(s.n_up):
         t = F.interpolate(t, scale_factor=(2, 2, 1), mode="nearest")
-        t = _lrelu(F.conv3d(t, sd[f"model.{2 + u}.1.0.weight"], None, 1, 1), s.slope)
+        t = _st(_lrelu(F.conv3d(t, _wq(sd[f"model.{2 + u}.1.0.weight"], s), None, 1, 1), s.slope), s)
     return t
 
 
 def terrain_features(sd: Dict[str, Tensor], Z: Tensor, s: GSpec) -> Tensor:
     """``Generator_3D.terrain_convs``, Generator_3D_Resnet_ESRGAN.py:120-137."""
-    z = _lrelu(F.conv3d(Z, sd["terrain_convs.0.0.weight"], None, 1, 1), s.slope)
-    return F.conv3d(z, sd["terrain_convs.1.0.weight"], None, 1, 1)
+    z = _st(_lrelu(F.conv3d(_st(Z, s), _wq(sd["terrain_convs.0.0.weight"], s), None, 1, 1), s.slope), s)
+    return _st(F.conv3d(z, _wq(sd["terrain_convs.1.0.weight"], s), None, 1, 1), s)
 
 
 def generator_forward(
@@ -169,12 +196,13 @@ def generator_forward(
     zf = terrain_features(sd, Z, s)
     h = torch.cat((t, zf), dim=1)
     pad = (s.hr_kern - 1) // 2
-    h = _lrelu(F.conv3d(h, sd["hr_convs.0.0.weight"], None, 1, pad), s.slope)
+    h = _lrelu(F.conv3d(h, _wq(sd["hr_convs.0.0.weight"], s), None, 1, pad), s.slope)
     if dropout_mask is not None:
         h = h * dropout_mask
     elif training and s.dropout_p > 0:
         h = F.dropout3d(h, s.dropout_p, True)
-    return F.conv3d(h, sd["hr_convs.2.weight"], sd["hr_convs.2.bias"], 1, pad)
+    h = _st(h, s)
+    return F.conv3d(h, _wq(sd["hr_convs.2.weight"], s), sd["hr_convs.2.bias"], 1, pad)
 
 
 # --------------------------------------------------------------------------- #
@@ -260,9 +288,11 @@ def discriminator_features(
     In training mode the running statistics held in ``sd`` are updated in place,
     exactly like ``nn.BatchNorm3d`` (momentum 0.1, unbiased running variance).
     """
+    x = _st(x, s)
     for l in d_layers(s):
-        x = F.conv3d(x, sd[l.key + ".weight"], None, l.stride, l.pad)
+        x = F.conv3d(x, _wq(sd[l.key + ".weight"], s), None, l.stride, l.pad)
         if l.bn:
+            x = _st(x, s)  # the conv output is stored before the statistics pass
             if training and (l.bn + ".num_batches_tracked") in sd:
                 sd[l.bn + ".num_batches_tracked"] += 1
             x = F.batch_norm(
@@ -277,6 +307,7 @@ def discriminator_features(
             )
         if l.act:
             x = _lrelu(x, s.slope)
+        x = _st(x, s)
     return x
 
 

@@ -220,7 +220,7 @@ def gen_physics():
 # --------------------------------------------------------------------------- #
 # 5. train-step traces from the real wind_field_GAN_3D
 # --------------------------------------------------------------------------- #
-def reduced_cfg(use_noise: bool, dropout: float, period: int = 2):
+def reduced_cfg(use_noise: bool, dropout: float, period: int = 2, tf: int = 4, bf: int = 4):
     cfg = RefConfig(os.path.join(REF, "config", "wind_field_GAN_3D_config_local.ini"))
     cfg.is_train, cfg.is_test, cfg.is_use = True, False, False
     cfg.gpu_id = None
@@ -228,9 +228,9 @@ def reduced_cfg(use_noise: bool, dropout: float, period: int = 2):
     cfg.generator.num_features = 16
     cfg.generator.num_RRDB = 1
     cfg.generator.RDB_growth_chan = 8
-    cfg.generator.terrain_number_of_features = 4
+    cfg.generator.terrain_number_of_features = tf
     cfg.generator.dropout_probability = dropout
-    cfg.discriminator.num_features = 4
+    cfg.discriminator.num_features = bf
     cfg.discriminator.dropout_probability = dropout
     cfg.gan_config.number_of_z_layers = 4
     cfg.training.use_instance_noise = use_noise
@@ -250,8 +250,8 @@ def specs_from_cfg(cfg):
     return gs, ds
 
 
-def gen_trace(tag: str, use_noise: bool, dropout: float, its):
-    cfg = reduced_cfg(use_noise, dropout)
+def gen_trace(tag: str, use_noise: bool, dropout: float, its, tf: int = 4, bf: int = 4):
+    cfg = reduced_cfg(use_noise, dropout, tf=tf, bf=bf)
     torch.manual_seed(2001)
     gan = ref_gan.wind_field_GAN_3D(cfg)
     gs, ds = specs_from_cfg(cfg)
@@ -283,6 +283,58 @@ def gen_trace(tag: str, use_noise: bool, dropout: float, its):
     save(f"gan_trace_{tag}.npz", its=np.array(list(its)), kinds=np.array(kinds), G_losses=np.array(rows),
          D_loss=np.array(dloss), wsum_g=np.array(wsum_g), wsum_d=np.array(wsum_d), lr=np.array(lrs),
          use_noise=np.array(use_noise), dropout=np.array(dropout), **final_G, **final_D)
+
+
+def gen_c1_full():
+    """The SHIPPED local configuration at full width (34.77 M-parameter G, bf 32 D with slicing, LR 16x16x10 ->
+    HR 64x64x10, batch 1 - BASELINE.json configs[0]): one G-iteration and one D-iteration of the reference's
+    ``wind_field_GAN_3D`` with dropout and instance noise off.  Recorded: the eval-mode SR field (sub-sampled),
+    D's eval logit on HR, the 8 generator loss entries, the discriminator loss, L2 norms and abs-sums of EVERY
+    parameter gradient of both iterations and a few whole gradient tensors."""
+    cfg = RefConfig(os.path.join(REF, "config", "wind_field_GAN_3D_config_local.ini"))
+    cfg.is_train, cfg.is_test, cfg.is_use = True, False, False
+    cfg.gpu_id = None
+    cfg.device = torch.device("cpu")
+    cfg.generator.dropout_probability = 0.0
+    cfg.discriminator.dropout_probability = 0.0
+    cfg.training.use_instance_noise = False
+    cfg.training.niter = 150000
+    cfg.training.d_g_train_period = 1
+    torch.manual_seed(2001)
+    gan = ref_gan.wind_field_GAN_3D(cfg)
+    gs, ds = specs_from_cfg(cfg)
+    assert (gs.nf, gs.n_rrdb, gs.gc, gs.tf, ds.bf, ds.enable_slicing) == (128, 16, 32, 16, 32, True)
+    gan.G.load_state_dict(onets.deterministic_state(onets.g_param_shapes(gs), seed=101, scale=0.3))
+    gan.D.load_state_dict(onets.deterministic_state(onets.d_param_shapes(ds), seed=103, scale=1.0))
+    LR, HR, Z, x, y = synthetic_batch(1, 16, 10, 4, seed=2001)
+    gan.feed_xy_niter(x, y, torch.tensor(cfg.training.niter), 1, 1)
+    gan.G.eval()
+    gan.D.eval()
+    with torch.no_grad():
+        sr = gan.G(LR, Z)
+        d_hr = gan.D(HR)
+    keys = ["total", "adversarial", "pix", "xy_gradient", "z_gradient", "divergence", "xy_divergence", "feature_D"]
+    out = {"sr_sub": np_(sr[:, :, ::2, ::2, :]), "sr_abs_sum": np.array(float(sr.double().abs().sum())),
+           "d_hr_eval": np_(d_hr)}
+    gan.optimize_parameters(LR, HR, Z, 0)  # G-iteration
+    out["G_losses"] = np.array([float(gan.get_G_train_loss_dict_ref()[k]) for k in keys])
+    gG = {k: p.grad for k, p in gan.G.named_parameters()}
+    out["gG_keys"] = np.array(list(gG))
+    out["gG_l2"] = np.array([float(v.double().norm()) for v in gG.values()])
+    out["gG_abs"] = np.array([float(v.double().abs().sum()) for v in gG.values()])
+    for k in ("model.0.0.weight", "model.1.module.0.RDBs.0.LFF.bias", "model.1.module.15.RDBs.2.LFF.bias",
+              "terrain_convs.0.0.weight", "hr_convs.2.bias"):
+        out["gG." + k] = np_(gG[k])
+    out["gG8.model.1.module.7.RDBs.1.conv3.conv.0.weight"] = np_(gG["model.1.module.7.RDBs.1.conv3.conv.0.weight"][:8])
+    gan.optimize_parameters(LR, HR, Z, 1)  # D-iteration
+    out["D_loss"] = np.array(float(gan.get_D_loss_dict_ref()["train_loss"]))
+    gD = {k: p.grad for k, p in gan.D.named_parameters()}
+    out["gD_keys"] = np.array(list(gD))
+    out["gD_l2"] = np.array([float(v.double().norm()) for v in gD.values()])
+    out["gD_abs"] = np.array([float(v.double().abs().sum()) for v in gD.values()])
+    for k in ("features.0.0.0.weight", "features.4.1.weight", "classifier.2.weight", "features.2.0.1.bias"):
+        out["gD." + k] = np_(gD[k])
+    save("c1_full_step.npz", **out)
 
 
 def gen_init_manifest():
@@ -320,7 +372,7 @@ def gen_config_golden():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["conv", "blocks", "G", "D", "physics", "trace", "init", "config"]
+    which = sys.argv[1:] or ["conv", "blocks", "G", "D", "physics", "trace", "init", "config", "c1"]
     if "config" in which:
         gen_config_golden()
     if "conv" in which:
@@ -336,5 +388,9 @@ if __name__ == "__main__":
     if "trace" in which:
         gen_trace("plain", use_noise=False, dropout=0.0, its=[1, 2, 3, 4, 5, 6])
         gen_trace("noise", use_noise=True, dropout=0.1, its=[1, 2, 3, 4, 5])
+        # channel widths the bf16 kernels accept (terrain features / D base width multiples of 8)
+        gen_trace("plain_w8", use_noise=False, dropout=0.0, its=[1, 2, 3, 4, 5, 6], tf=8, bf=8)
+    if "c1" in which:
+        gen_c1_full()
     if "init" in which:
         gen_init_manifest()

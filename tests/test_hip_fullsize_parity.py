@@ -1,0 +1,296 @@
+"""GPU parity of the HIP path at the widths, dtype and tile geometry the benchmark runs.
+
+* the SHIPPED configuration (BASELINE.json configs[0], "C1": full 34.77 M-parameter G, bf 32 D with slicing,
+  LR 16x16x10 -> HR 64x64x10) - eval outputs, one G-iteration and one D-iteration, fp32 and bf16, against the
+  fixture recorded from the reference (tests/golden/c1_full_step.npz) and against the oracle on the host;
+* the C3' tile geometry (16-level tiles of 4 x 8 x 16 voxels, several z tiles, single activation buffer for
+  the 5x5x5 conv, 512-voxel 128-wide tiles, Z16 filter-gradient kernels) on a slab the oracle finishes in
+  seconds: full-width G and D, bf16;
+* the 6-iteration loss / weight trace of the reference, bf16.
+
+Tolerances.  fp32: outputs 2e-5, losses 2e-4, G gradients 2e-4 (rel-L2); D gradients 5e-3 (train-mode
+BatchNorm at batch 1 + LeakyReLU branch flips, see test_oracle_golden.py::test_c1_full_width_step).
+bf16: outputs 2e-2; every other bound is DERIVED, per loss entry and per parameter tensor, from the distance
+d_k between the fp32 oracle and the same oracle with bf16 *storage emulation* (``GSpec.bf16_storage``: every
+tensor the MI355X path keeps in HBM rounded to bf16, fp32 accumulation): tol_k = floor + 2 d_k with floor
+1e-2 (losses) / 2e-2 (gradients).  d_k is what ANY bf16-storage implementation of the reference's graph must
+show; the HIP path has to stay within twice that of the fp32 truth.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import REPO, rel_l2
+from c1_case import LOSS_KEYS, c1_batch, c1_d_grads_fp64, c1_oracle_step, c1_specs, c1_states
+from oracle import gan as ogan
+from oracle import nets as onets
+
+pytestmark = pytest.mark.gpu
+T = torch.from_numpy
+DEV = "cuda:0"
+
+
+def _report(name, payload):
+    """measured distances -> gpurun_out/parity_<name>.json (DESIGN.md quotes them); never fails the test"""
+    try:
+        d = os.path.join(REPO, "gpurun_out")
+        os.makedirs(d, exist_ok=True)
+        with open(os.path.join(d, f"parity_{name}.json"), "w") as f:
+            json.dump(payload, f, indent=1, sort_keys=True)
+    except OSError:
+        pass
+
+
+def _gan(dtype, ini="local", **over):
+    from gan_sr_wind_field_amd.config.config import Config
+    from gan_sr_wind_field_amd.GAN_models.wind_field_GAN_3D import wind_field_GAN_3D
+    import gan_sr_wind_field_amd
+
+    cfg = Config(os.path.join(os.path.dirname(gan_sr_wind_field_amd.__file__), "config",
+                              f"wind_field_GAN_3D_config_{ini}.ini"))
+    cfg.is_train, cfg.is_test, cfg.is_use = True, False, False
+    cfg.gpu_id, cfg.device = 0, torch.device(DEV)
+    cfg.compute_dtype = dtype
+    cfg.generator.dropout_probability = cfg.discriminator.dropout_probability = 0.0
+    cfg.training.use_instance_noise = False
+    cfg.training.niter = 150000
+    cfg.training.d_g_train_period = 1
+    for k, v in over.items():
+        sec, key = k.split("__")
+        setattr(getattr(cfg, sec), key, v)
+    torch.manual_seed(2001)
+    return wind_field_GAN_3D(cfg), cfg
+
+
+def _bounds(truth: dict, emul: dict, floor: float):
+    return {k: floor + 2.0 * rel_l2(emul[k], truth[k]) for k in truth}
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_c1_shipped_config_step(golden, hip, dtype):
+    g = golden("c1_full_step.npz")
+    r = c1_oracle_step(torch.float32, emulate_bf16=False)
+    bf16 = dtype == "bf16"
+    e = c1_oracle_step(torch.float32, emulate_bf16=True) if bf16 else None
+    gan, cfg = _gan(dtype)
+    assert sum(p.numel() for p in gan.G.parameters()) == 34769571
+    sdG, sdD = c1_states()
+    gan.G.load_state_dict(sdG)
+    gan.D.load_state_dict(sdD)
+    LR, HR, Z, x, y = (t.to(DEV) for t in c1_batch())
+    gan.feed_xy_niter(x, y, torch.tensor(cfg.training.niter, device=DEV), 1, 1)
+    rep = {}
+
+    # ---- eval-mode outputs: SR field and D's logit on HR
+    gan.G.eval()
+    gan.D.eval()
+    with torch.no_grad():
+        sr = gan.G(LR, Z)
+        d_hr = gan.D(HR)
+    rep["sr_vs_reference"] = rel_l2(sr[:, :, ::2, ::2, :], T(g["sr_sub"]))
+    rep["sr_vs_oracle"] = rel_l2(sr, r["sr"])
+    rep["d_logit_rel"] = abs(float(d_hr) - float(g["d_hr_eval"])) / abs(float(g["d_hr_eval"]))
+    assert rep["sr_vs_reference"] < (2e-2 if bf16 else 2e-5)
+    assert rep["sr_vs_oracle"] < (2e-2 if bf16 else 2e-5)
+    d_tol = 1e-2 + 2 * abs(float(e["d_hr_eval"]) - float(r["d_hr_eval"])) / abs(float(r["d_hr_eval"])) if bf16 else 2e-5
+    assert rep["d_logit_rel"] < d_tol, (rep["d_logit_rel"], d_tol)
+
+    # ---- G-iteration: the 8 loss entries (fp32 on both sides) and every parameter gradient
+    gan.optimize_parameters(LR, HR, Z, 0)
+    got = np.array([float(gan.get_G_train_loss_dict_ref()[k].detach()) for k in LOSS_KEYS])
+    ref = np.asarray(g["G_losses"])
+    rel = np.abs(got - ref) / np.maximum(np.abs(ref), 1e-12)
+    rep["G_losses_rel"] = dict(zip(LOSS_KEYS, rel.tolist()))
+    if bf16:
+        emul = np.asarray(e["G_losses"])
+        tol = 1e-2 + 2 * np.abs(emul - np.asarray(r["G_losses"])) / np.maximum(np.abs(ref), 1e-12)
+    else:
+        tol = np.full(len(ref), 2e-4)
+    assert (rel[ref != 0] < tol[ref != 0]).all(), (rep["G_losses_rel"], tol.tolist())
+    assert (got[ref == 0] == 0).all()
+    grads = {k: p.grad for k, p in gan.G.named_parameters()}
+    errs = {k: rel_l2(grads[k], r["gG"][k]) for k in grads}
+    lim = _bounds(r["gG"], e["gG"], 2e-2) if bf16 else {k: 2e-4 for k in grads}
+    rep["gG_worst"] = sorted(((v, k, lim[k]) for k, v in errs.items()), reverse=True)[:5]
+    rep["gG_median"] = float(np.median(list(errs.values())))
+    bad = {k: (v, lim[k]) for k, v in errs.items() if not v < lim[k]}
+    assert not bad, bad
+    # the same gradients against the reference's own run: norm of every tensor + the recorded tensors
+    l2 = np.array([float(grads[str(k)].double().norm()) for k in g["gG_keys"]])
+    lim_n = np.array([lim[str(k)] for k in g["gG_keys"]])
+    assert (np.abs(l2 / g["gG_l2"] - 1) < lim_n).all()
+    for k in g.files:
+        if k.startswith("gG."):
+            assert rel_l2(grads[k[3:]], T(g[k])) < lim[k[3:]], k
+
+    # ---- D-iteration: loss, every parameter gradient, BatchNorm running statistics
+    gan.optimize_parameters(LR, HR, Z, 1)
+    d_loss = float(gan.get_D_loss_dict_ref()["train_loss"].detach())
+    rep["D_loss_rel"] = abs(d_loss - float(g["D_loss"])) / abs(float(g["D_loss"]))
+    dl_tol = 1e-2 + 2 * abs(e["D_loss"] - r["D_loss"]) / abs(r["D_loss"]) if bf16 else 2e-4
+    assert rep["D_loss_rel"] < dl_tol, (rep["D_loss_rel"], dl_tol)
+    gD = {k: p.grad for k, p in gan.D.named_parameters()}
+    errs = {k: rel_l2(gD[k], r["gD"][k]) for k in gD}
+    lim = _bounds(r["gD"], e["gD"], 2e-2) if bf16 else {k: 5e-3 for k in gD}
+    rep["gD_worst"] = sorted(((v, k, lim[k]) for k, v in errs.items()), reverse=True)[:5]
+    bad = {k: (v, lim[k]) for k, v in errs.items() if not v < lim[k]}
+    assert not bad, bad
+    if not bf16:  # and within the same distance of an fp64 evaluation of the D-iteration
+        d64 = c1_d_grads_fp64(r["sr_d"])
+        assert max(rel_l2(gD[k].double().cpu(), d64[k]) for k in gD) < 5e-3
+    for k in g.files:
+        if k.startswith("gD."):
+            assert rel_l2(gD[k[3:]], T(g[k])) < lim[k[3:]], k
+    sd = gan.D.state_dict()
+    for k, v in r["bn"].items():
+        assert rel_l2(sd[k].float(), v) < (2e-2 if bf16 else 1e-5), k
+    _report(f"c1_{dtype}", rep)
+
+
+def test_c3_geometry_slab_generator_bf16(hip, monkeypatch):
+    """Full-width G on LR 16x16x32 -> HR 64x64x32 with the kernels and tiles of the 128^3 benchmark: 16-level
+    tiles (two z tiles everywhere), the single-buffer 5x5x5 144-wide kernel, 512-voxel 128-wide trunk tiles
+    (WSR_CT_NOSMALL keeps this small volume off the 128-voxel variants), Z16 filter-gradient kernels.  Output
+    and EVERY parameter gradient against the fp32 oracle, bounds from the bf16-storage emulation."""
+    monkeypatch.setenv("WSR_CT_NOSMALL", "1")
+    from test_hip_networks import build_G
+
+    spec = onets.GSpec()
+    LR, HR, Z, x, y = ogan.synthetic_batch(1, 16, 32, 4, seed=77)
+    gy = torch.randn((1, 3, 64, 64, 32), generator=torch.Generator().manual_seed(5))
+    res = {}
+    for mode in ("fp32", "emul"):
+        sd = onets.deterministic_state(onets.g_param_shapes(spec), seed=111, scale=0.3)
+        for v in sd.values():
+            v.requires_grad_(True)
+        sp = onets.GSpec(bf16_storage=mode == "emul")
+        out = onets.generator_forward(sd, LR, Z, sp, training=False)
+        (out * gy).sum().backward()
+        res[mode] = (out.detach(), {k: v.grad for k, v in sd.items()})
+    G, _ = build_G(spec, torch.bfloat16, 111, scale=0.3)
+    G.eval()
+    seen = []
+    G.program().launch_probe = lambda tag, fn: (seen.append(tag.split(":")[0]), fn())
+    out = G(LR.to(DEV), Z.to(DEV))
+    (out * gy.to(DEV)).sum().backward()
+    assert "fwd_dense_pre" in seen and "dgrad_dense0" in seen and "wgrad_tri" in seen
+    e_out = rel_l2(out, res["fp32"][0])
+    assert e_out < 2e-2, e_out
+    lim = _bounds(res["fp32"][1], res["emul"][1], 2e-2)
+    errs = {k: rel_l2(p.grad, res["fp32"][1][k]) for k, p in G.named_parameters()}
+    _report("c3_slab_G_bf16", {"out": e_out, "emul_out": rel_l2(res["emul"][0], res["fp32"][0]),
+                               "worst": sorted(((v, k, lim[k]) for k, v in errs.items()), reverse=True)[:8],
+                               "median": float(np.median(list(errs.values())))})
+    bad = {k: (v, lim[k]) for k, v in errs.items() if not v < lim[k]}
+    assert not bad, bad
+
+
+@pytest.mark.parametrize("train", [False, True], ids=["eval_input_grad", "train_param_grads"])
+def test_c3_geometry_slab_discriminator_bf16(hip, train):
+    """Full-width D (bf 32, no slicing) on 128x128x32 inputs - more than 19 levels, so block 0 halves z as at
+    128^3 (reference Discriminator_3D.py:75) and the strided (4,4,3) convs take their 16-level tiles.
+    eval mode (the G-iteration's use): logit and input gradient; train mode: logit and every parameter gradient."""
+    from test_hip_networks import build_D
+
+    spec = onets.DSpec(bf=32, nz=32)
+    gen = torch.Generator().manual_seed(9)
+    x = torch.rand((1, 3, 128, 128, 32), generator=gen) * 2 - 1
+    res = {}
+    for mode in ("fp32", "emul"):
+        sd = onets.deterministic_state(onets.d_param_shapes(spec), seed=121, scale=1.0)
+        params = {k: v for k, v in sd.items() if v.is_floating_point() and "running_" not in k}
+        for v in params.values():
+            v.requires_grad_(train)
+        xr = x.clone().requires_grad_(not train)
+        sp = onets.DSpec(bf=32, nz=32, bf16_storage=mode == "emul")
+        out = onets.discriminator_forward(sd, xr, sp, training=train)
+        out.sum().backward()
+        res[mode] = (float(out), {k: v.grad for k, v in params.items()} if train else {"x": xr.grad})
+    D, _ = build_D(spec, torch.bfloat16, 121)
+    D.train(train)
+    for p in D.parameters():
+        p.requires_grad = train
+    xd = x.to(DEV).requires_grad_(not train)
+    out = D(xd)
+    out.sum().backward()
+    tol = 1e-2 + 2 * abs(res["emul"][0] - res["fp32"][0]) / abs(res["fp32"][0])
+    assert abs(float(out) - res["fp32"][0]) / abs(res["fp32"][0]) < tol
+    got = {k: p.grad for k, p in D.named_parameters()} if train else {"x": xd.grad}
+    lim = _bounds(res["fp32"][1], res["emul"][1], 2e-2)
+    errs = {k: rel_l2(got[k], res["fp32"][1][k]) for k in got}
+    _report(f"c3_slab_D_bf16_{'train' if train else 'eval'}",
+            {"worst": sorted(((v, k, lim[k]) for k, v in errs.items()), reverse=True)[:6]})
+    bad = {k: (v, lim[k]) for k, v in errs.items() if not v < lim[k]}
+    assert not bad, bad
+
+
+def test_gan_train_step_trace_bf16_vs_reference(golden, hip):
+    """6 iterations (G, D, D, G, G, D) in bf16 against the reference's fp32 trace of the same widths
+    (gan_trace_plain_w8.npz): every loss entry within 1e-2 + twice the deviation the bf16-storage emulation of
+    the oracle shows on that entry (measured on the host, same run), Adam-updated weight sums within 1e-3."""
+    g = golden("gan_trace_plain_w8.npz")
+    keys = LOSS_KEYS
+
+    def nets_and_batch():
+        gs = onets.GSpec(in_channels=4, nf=16, n_rrdb=1, gc=8, tf=8, hr_kern=5, upscale=4)
+        ds = onets.DSpec(bf=8, nz=4, enable_slicing=True)
+        sdG = onets.deterministic_state(onets.g_param_shapes(gs), seed=41, scale=0.5)
+        sdD = onets.deterministic_state(onets.d_param_shapes(ds), seed=43, scale=1.0)
+        return gs, ds, sdG, sdD, ogan.synthetic_batch(2, 16, 4, 4, seed=2001)
+
+    # emulated deviations, per iteration and entry
+    gs, ds, sdG, sdD, (LR, HR, Z, x, y) = nets_and_batch()
+    gs.bf16_storage = ds.bf16_storage = True
+    em = ogan.OracleGAN(sdG, sdD, gs, ds, ogan.TrainSpec(use_instance_noise=False, d_g_train_period=2))
+    em.feed_xy(x, y)
+    dev_G, dev_D = {}, {}
+    for row, it in enumerate(g["its"]):
+        kind = em.optimize_parameters(LR, HR, Z, int(it))
+        if int(it) > 4:
+            em.update_learning_rate()
+        if kind == "G":
+            ref = g["G_losses"][row]
+            dev_G[row] = np.abs(np.array([float(em.G_losses[k]) for k in keys]) - ref) / np.maximum(np.abs(ref), 1e-12)
+        else:
+            dev_D[row] = abs(float(em.D_loss) - g["D_loss"][row]) / abs(g["D_loss"][row])
+
+    gan, cfg = _gan("bf16", generator__num_features=16, generator__num_RRDB=1, generator__RDB_growth_chan=8,
+                    generator__terrain_number_of_features=8, discriminator__num_features=8,
+                    gan_config__number_of_z_layers=4, training__d_g_train_period=2)
+    gs, ds, sdG, sdD, batch = nets_and_batch()
+    gan.G.load_state_dict(sdG)
+    gan.D.load_state_dict(sdD)
+    LR, HR, Z, x, y = (t.to(DEV) for t in batch)
+    gan.feed_xy_niter(x, y, torch.tensor(cfg.training.niter, device=DEV), 1, 2)
+    rep = {}
+    for row, it in enumerate(g["its"]):
+        gan.optimize_parameters(LR, HR, Z, int(it))
+        if int(it) > 4:
+            gan.update_learning_rate()
+        if g["kinds"][row]:
+            ref = g["G_losses"][row]
+            got = np.array([float(gan.get_G_train_loss_dict_ref()[k].detach()) for k in keys])
+            rel = np.abs(got - ref) / np.maximum(np.abs(ref), 1e-12)
+            tol = 1e-2 + 2 * dev_G[row]
+            rep[f"it{it}_G"] = rel.tolist()
+            assert (rel[ref != 0] < tol[ref != 0]).all(), (int(it), rel.tolist(), tol.tolist())
+        else:
+            rel = abs(float(gan.get_D_loss_dict_ref()["train_loss"].detach()) - g["D_loss"][row]) / abs(g["D_loss"][row])
+            rep[f"it{it}_D"] = rel
+            assert rel < 1e-2 + 2 * dev_D[row], (int(it), rel, dev_D[row])
+        sG, sD = gan.G.state_dict(), gan.D.state_dict()
+        wg = [float(sG[k].double().abs().sum())
+              for k in ("model.0.0.weight", "hr_convs.2.weight", "model.1.module.0.RDBs.1.LFF.bias")]
+        wd = [float(sD[k].double().abs().sum())
+              for k in ("features.0.0.0.weight", "classifier.2.weight", "features.1.1.1.running_var")]
+        np.testing.assert_allclose(wg, g["wsum_g"][row], rtol=1e-3, err_msg=f"it={it}")
+        np.testing.assert_allclose(wd, g["wsum_d"][row], rtol=1e-3, err_msg=f"it={it}")
+    for k in g.files:
+        if k.startswith("final_G."):
+            assert rel_l2(gan.G.state_dict()[k[8:]], T(g[k])) < 2e-3, k
+        if k.startswith("final_D."):
+            assert rel_l2(gan.D.state_dict()[k[8:]], T(g[k])) < 2e-3, k
+    _report("trace_bf16", rep)

@@ -288,6 +288,13 @@ def _cpu_wgrad(x, gy, k, p):
     ("k3_gc", 64, 32, (3, 3, 3), (5, 8, 9), 2, False),         # TN=2 config
     ("k3_up", 16, 64, (3, 3, 3), (4, 5, 6), 1, True),          # nearest x(2,2,1) folded into the x tile load
     ("lff_1x1", 256, 128, (1, 1, 1), (5, 6, 19), 1, False),    # 1x1x1: <8,1,8>, two c-chunks of 128 channels
+    # the geometry every launch of the benchmarked 128-level workloads takes: z extent a multiple of 16 ->
+    # 16-level tiles, the Z16 voxel<->k mapping (second transposing read at a constant offset), several z tiles
+    ("hr0_z32", 144, 144, (5, 5, 5), (8, 12, 32), 1, False),   # <3,16,1,Z16>: 4x4x16 tiles, 2 z tiles
+    ("k3_z16", 128, 128, (3, 3, 3), (8, 8, 16), 2, False),     # <4,7,2,Z16>: 4x8x16 tiles
+    ("k3_up_z16", 32, 64, (3, 3, 3), (4, 4, 16), 1, True),     # Z16 with the up-sampled x tile
+    ("lff_z48", 256, 128, (1, 1, 1), (4, 8, 48), 1, False),    # <8,1,8,Z16>, 3 z tiles
+    ("hr1z_z16", 144, 15, (5, 5, 1), (8, 8, 16), 1, False),    # z-folded last conv: (5,5,1) taps, 15 outputs
 ])
 def test_wgrad_tile_kernel_bf16(hip, name, cin, cout, k, xyz, B, ups):
     """LDS-tile filter-gradient kernel (bf16) vs an fp32 CPU wgrad of the same rounded operands."""
@@ -314,13 +321,15 @@ def test_wgrad_tile_kernel_bf16(hip, name, cin, cout, k, xyz, B, ups):
     assert rel_l2(dw.cpu(), ref) < 2e-5, name  # fp32 accumulation of exact bf16 products
 
 
-def test_wgrad_dense_block_fused(hip):
+@pytest.mark.parametrize("nf,gc,B,xyz", [(16, 8, 2, (6, 7, 9)), (128, 32, 1, (8, 8, 32))],
+                         ids=["small", "full_width_z32"])
+def test_wgrad_dense_block_fused(hip, nf, gc, B, xyz):
     """One launch for the four growth convs of an RDB: conv i reads channels [0, nf + i*gc) of the
-    dense buffer; block-triangular (n, c) structure (reference torch_blocks.py:256-267)."""
+    dense buffer; block-triangular (n, c) structure (reference torch_blocks.py:256-267).  The second case is
+    the shipped block width on 16-level tiles (the launch the benchmark issues 48 times per backward)."""
     o = ops()
     dt = torch.bfloat16
-    nf, gc, nconv = 16, 8, 4
-    B, xyz = 2, (6, 7, 9)
+    nconv = 4
     gen = torch.Generator().manual_seed(77)
     dense = nf + nconv * gc
     x = torch.randn((B, dense) + xyz, generator=gen).bfloat16().float()
@@ -398,6 +407,28 @@ def test_conv_tile_kernels_vs_golden(golden, hip, case):
 def test_conv_tile_shapes_vs_cpu(hip, name, cin, cout, k, xyz, B, ups):
     """Every tile-kernel configuration against an fp32 CPU conv of the same bf16-rounded operands,
     forward and input gradient (with residual epilogue on the forward pass)."""
+    _check_tile_conv(name, cin, cout, k, xyz, B, ups)
+
+
+@pytest.mark.parametrize("name,cin,cout,k,xyz,B,ups", [
+    # the tile geometry of the benchmarked 128-level workloads (conv_tile_impl.h pick_tile: 4 x 8 x 16 voxels,
+    # several z tiles); WSR_CT_NOSMALL keeps these small volumes on the kernels the full-size volumes take
+    ("hr0_prod", 144, 144, (5, 5, 5), (12, 16, 32), 1, False),   # <8,1,4,9>: one activation buffer, 9 chunks
+    ("n128_prod", 128, 128, (3, 3, 3), (8, 16, 32), 1, False),   # <8,1,4,8>: 512-voxel tile, 128 outputs
+    ("pre_prod", 128, 128, (3, 3, 3), (4, 8, 48), 2, False),     # same, batch 2, 3 z tiles
+    ("up_prod", 128, 128, (3, 3, 3), (4, 8, 32), 1, True),       # up-sampling gather on the 512-voxel tile
+    ("grow_prod", 96, 32, (3, 3, 3), (8, 8, 32), 1, False),      # <8,1,4,2>: growth conv over 96 channels
+    ("rdb_prod", 224, 32, (3, 3, 3), (8, 8, 16), 1, False),      # <8,1,4,2>: last growth conv (per-conv form)
+    ("dwin_prod", 32, 128, (3, 3, 3), (8, 8, 32), 1, False),     # input gradient of a growth window: 128 -> 32
+    ("hr1z_prod", 144, 15, (5, 5, 1), (8, 16, 32), 1, False),    # z-folded last conv, <8,1,4,1>
+    ("t1_prod", 16, 16, (3, 3, 3), (8, 16, 32), 1, False),       # terrain conv 16 -> 16
+])
+def test_conv_tile_production_geometry(hip, monkeypatch, name, cin, cout, k, xyz, B, ups):
+    monkeypatch.setenv("WSR_CT_NOSMALL", "1")
+    _check_tile_conv(name, cin, cout, k, xyz, B, ups)
+
+
+def _check_tile_conv(name, cin, cout, k, xyz, B, ups):
     o = ops()
     dt = torch.bfloat16
     gen = torch.Generator().manual_seed(cin * 7 + cout)
@@ -498,6 +529,34 @@ def test_wind_gradient_forward_and_adjoint(hip):
     one = o.wind_gradient(fd.detach()[..., :1].contiguous(), xs.float().to("cuda:0"), ys.float().to("cuda:0"),
                           zc.float().to("cuda:0")[..., :1].contiguous())
     assert torch.equal(one[:, 6:], torch.zeros_like(one[:, 6:]))
+
+
+def test_wind_gradient_vs_reference_fixture_and_oracle(golden, hip):
+    """``wsr_wind_gradient`` against the Jacobian stacks the REFERENCE's calculate_gradient_of_wind_field produced
+    (tests/golden/physics.npz, recorded by make_golden.py), and ``wsr_wind_gradient_bwd`` against autograd of the
+    oracle restatement (oracle/physics.py) in fp64 - neither side involves the product's own torch expression."""
+    from gan_sr_wind_field_amd import hip_ops as o
+    from oracle import physics as ophys
+
+    g = golden("physics.npz")
+    xs, ys, zc = (T(g[k]).to(DEV) for k in ("x", "y", "Z"))
+    for src, want in (("HR", "grad_hr"), ("SR", "grad_sr")):
+        got = o.wind_gradient(T(g[src]).to(DEV), xs, ys, zc)
+        assert rel_l2(got, T(g[want])) < 2e-6, src
+    # adjoint: d/df of sum(J * gy), oracle in fp64
+    gen = torch.Generator().manual_seed(23)
+    f = T(g["SR"]).double().requires_grad_(True)
+    J = ophys.wind_gradient(f, T(g["x"]).double(), T(g["y"]).double(), T(g["Z"]).double())
+    gy = torch.randn(J.shape, generator=gen, dtype=torch.float64)
+    (J * gy).sum().backward()
+    fd = T(g["SR"]).to(DEV).requires_grad_(True)
+    (o.wind_gradient(fd, xs, ys, zc) * gy.float().to(DEV)).sum().backward()
+    assert rel_l2(fd.grad, f.grad) < 2e-6
+    # the four normalisers of the loss (reference get_norm_factors_of_gradients) from the HIP Jacobians
+    from gan_sr_wind_field_amd.GAN_models.wind_field_GAN_3D import get_norm_factors_of_gradients
+    n = get_norm_factors_of_gradients(o.wind_gradient(T(g["HR"]).to(DEV), xs, ys, zc),
+                                      o.wind_gradient(T(g["SR"]).to(DEV), xs, ys, zc))
+    np.testing.assert_allclose([float(v) for v in n], g["norms"], rtol=1e-5)
 
 
 @pytest.mark.parametrize("name,cin,cout,k,s,p,xyz,B", [

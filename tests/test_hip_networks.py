@@ -2,8 +2,9 @@
 train step) against fixtures recorded from the reference and against the oracle.
 
 Tolerances (rel-L2): fp32 outputs 2e-5, fp32 gradients 2e-4 (reference noise floor
-fp32-vs-fp64 is 1.2e-6); bf16 outputs 2e-2, bf16 gradients 6e-2
-(operands rounded to 8 bits, fp32 accumulation, LeakyReLU masks from bf16 outputs).
+fp32-vs-fp64 is 1.2e-6); bf16 outputs 2e-2; bf16 gradients per tensor
+2e-2 + twice the distance of the oracle's bf16-storage emulation from fp32 on that
+tensor (``_emulated_bf16_bounds``; full-size cases: test_hip_fullsize_parity.py).
 """
 import numpy as np
 import pytest
@@ -60,6 +61,12 @@ def test_generator_fp32_vs_reference(golden, hip, scale, n, nz):
     assert torch.equal(out2, out.detach())
 
 
+def _emulated_bf16_bounds(truth: dict, emul: dict, floor: float = 2e-2):
+    """per-tensor bf16 tolerance: floor + twice the distance the oracle's bf16-storage emulation
+    (``GSpec.bf16_storage``) shows from the fp32 truth on that tensor"""
+    return {k: floor + 2.0 * rel_l2(emul[k], truth[k]) for k in truth}
+
+
 def test_generator_bf16_vs_reference(golden, hip):
     g = golden("g_small_s4.npz")
     spec = onets.GSpec(upscale=4, in_channels=4, out_channels=3, nf=16, n_rrdb=2, hr_kern=5, gc=8, tf=8)
@@ -70,8 +77,18 @@ def test_generator_bf16_vs_reference(golden, hip):
     assert out.dtype == torch.float32
     assert rel_l2(out, T(g["out"])) < 2e-2
     (out * T(g["gy"]).to(DEV)).sum().backward()
-    errs = {k: rel_l2(p.grad, T(g[f"grad.{k}"])) for k, p in G.named_parameters()}
-    assert max(errs.values()) < 0.15, sorted(errs.items(), key=lambda kv: -kv[1])[:3]
+    # bound per parameter tensor: what a bf16-storage evaluation of the reference's graph shows on it
+    sd = onets.deterministic_state(onets.g_param_shapes(spec), seed=15, scale=0.7)
+    for v in sd.values():
+        v.requires_grad_(True)
+    em = onets.GSpec(upscale=4, in_channels=4, out_channels=3, nf=16, n_rrdb=2, hr_kern=5, gc=8, tf=8,
+                     bf16_storage=True)
+    (onets.generator_forward(sd, LR, Z, em) * T(g["gy"])).sum().backward()
+    truth = {k: T(g[f"grad.{k}"]) for k in sd}
+    lim = _emulated_bf16_bounds(truth, {k: v.grad for k, v in sd.items()})
+    errs = {k: rel_l2(p.grad, truth[k]) for k, p in G.named_parameters()}
+    bad = {k: (v, lim[k]) for k, v in errs.items() if not v < lim[k]}
+    assert not bad, bad
 
 
 def test_generator_dropout_mask_and_train_mode(hip):
@@ -127,15 +144,10 @@ def test_discriminator_fp32_vs_reference(golden, hip, slicing, xy, nz):
     assert rel_l2(out, T(g["out_train"])) < 2e-5
     (out * torch.tensor([[1.0], [-0.5]], device=DEV)).sum().backward()
     # input gradient after 10 conv + 9 train-mode BatchNorm backward stages (each a
-    # g - mean(g) - xhat*mean(g*xhat) cancellation): 1e-3; the shallower cases sit at ~1e-4
-    # The z21 case is bimodal on the GPU: measured 1.1e-6 (most runs) or 2.4e-3 against an fp64
-    # evaluation, depending on the order of the float atomics in the BatchNorm sums - one
-    # near-zero pre-activation changes its LeakyReLU branch (the reference's own fp32 result is
-    # 5.4e-4 away from fp64 for the same reason).  `flip` is the allowance for that event (worst
-    # observed: 6.5e-3 on a 4-element BatchNorm weight gradient).
-    flip = 1e-2 if nz == 21 else 0.0
-    assert rel_l2(x.grad[:, :, ::4, ::4, :], T(g["dx_sub"])) < max(1e-3, flip)
-    assert abs(float(x.grad.double().abs().sum()) / float(g["dx_abs_sum"]) - 1) < max(1e-3, flip)
+    # g - mean(g) - xhat*mean(g*xhat) cancellation): 1e-3; the shallower cases sit at ~1e-4.
+    # (BatchNorm reductions are two-pass and atomic-free, so this gradient is deterministic.)
+    assert rel_l2(x.grad[:, :, ::4, ::4, :], T(g["dx_sub"])) < 1e-3
+    assert abs(float(x.grad.double().abs().sum()) / float(g["dx_abs_sum"]) - 1) < 1e-3
     # The recorded fp32 reference gradients are themselves up to 5.3e-4 away from an fp64
     # evaluation of the same graph (features.0.0.0.weight of the z21 case: 9 train-mode BN
     # backward stages over tiny populations), so each key's tolerance is 2e-4 plus 1.5x the
@@ -144,8 +156,8 @@ def test_discriminator_fp32_vs_reference(golden, hip, slicing, xy, nz):
     ref64 = _d_grads_fp64(spec, 31 + nz, int(g["x_seed"]), xy, nz)
     for k, p in D.named_parameters():
         floor = rel_l2(T(g[f"grad.{k}"]).double(), ref64[k])
-        assert rel_l2(p.grad, T(g[f"grad.{k}"])) < max(2e-4 + 1.5 * floor, flip), (k, floor)
-        assert rel_l2(p.grad.double().cpu(), ref64[k]) < max(2e-4 + floor, flip), (k, floor)
+        assert rel_l2(p.grad, T(g[f"grad.{k}"])) < 2e-4 + 1.5 * floor, (k, floor)
+        assert rel_l2(p.grad.double().cpu(), ref64[k]) < 2e-4 + floor, (k, floor)
     for k, v in D.state_dict().items():
         if "running_" in k or "num_batches" in k:
             assert rel_l2(v.float(), T(g[f"after.{k}"]).float()) < 1e-5, k
@@ -170,26 +182,33 @@ def test_discriminator_eval_mode_input_gradient(hip):
 
 def test_discriminator_bf16_vs_oracle(hip):
     spec = onets.DSpec(bf=8, nz=4, enable_slicing=True)
-    D, sd = build_D(spec, torch.bfloat16, 8)
+    D, _ = build_D(spec, torch.bfloat16, 8)
     gen = torch.Generator().manual_seed(3)
     x = (torch.rand((2, 3, 64, 64, 4), generator=gen) * 2 - 1)
     D.train()
     out = D(x.to(DEV))
-    params = [v for k, v in sd.items() if v.is_floating_point() and "running_" not in k]
-    for p in params:
-        p.requires_grad_(True)
-    ref = onets.discriminator_forward(sd, x, spec, training=True)
-    assert rel_l2(out, ref) < 3e-2
     wgt = torch.tensor([[1.0], [-0.5]])
     (out * wgt.to(DEV)).sum().backward()
-    (ref * wgt).sum().backward()
-    errs = {k: rel_l2(p.grad, sd[k].grad) for k, p in D.named_parameters()}
-    # batch-of-2 BatchNorm backward on bf16-stored activations is the noisiest spot of the
-    # bf16 path (projection terms cancel most of g); direction must still agree
-    assert max(errs.values()) < 0.3, sorted(errs.items(), key=lambda kv: -kv[1])[:3]
+    res = {}
+    for mode in ("fp32", "emul"):  # fp32 oracle, and the oracle with bf16 storage emulation (the yard-stick)
+        sd = onets.deterministic_state(onets.d_param_shapes(spec), seed=8, scale=1.0)
+        params = {k: v for k, v in sd.items() if v.is_floating_point() and "running_" not in k}
+        for p in params.values():
+            p.requires_grad_(True)
+        ref = onets.discriminator_forward(sd, x, onets.DSpec(bf=8, nz=4, enable_slicing=True,
+                                                              bf16_storage=mode == "emul"), training=True)
+        (ref * wgt).sum().backward()
+        res[mode] = (ref.detach(), {k: v.grad for k, v in params.items()})
+    assert rel_l2(out, res["fp32"][0]) < 1e-2 + 2 * rel_l2(res["emul"][0], res["fp32"][0])
+    # batch-of-2 BatchNorm backward on bf16-stored activations is the noisiest spot of the bf16 path (the
+    # projection terms cancel most of g): the emulation itself is 0.1-0.3 away from fp32 on the first layers
+    lim = _emulated_bf16_bounds(res["fp32"][1], res["emul"][1])
+    errs = {k: rel_l2(p.grad, res["fp32"][1][k]) for k, p in D.named_parameters()}
+    bad = {k: (v, lim[k]) for k, v in errs.items() if not v < lim[k]}
+    assert not bad, bad
     for k, p in D.named_parameters():
         if k != "classifier.2.bias":
-            cos = torch.nn.functional.cosine_similarity(p.grad.flatten().cpu(), sd[k].grad.flatten(), dim=0)
+            cos = torch.nn.functional.cosine_similarity(p.grad.flatten().cpu(), res["fp32"][1][k].flatten(), dim=0)
             assert float(cos) > 0.97, (k, float(cos))
 
 

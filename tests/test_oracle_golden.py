@@ -122,9 +122,9 @@ def test_physics_ops(golden):
     assert rel_l2(lab, T(g["labels"])) < 1e-6
 
 
-def _replay_trace(g, use_noise, dropout):
-    gs = onets.GSpec(in_channels=4, nf=16, n_rrdb=1, gc=8, tf=4, hr_kern=5, upscale=4, dropout_p=dropout)
-    ds = onets.DSpec(bf=4, nz=4, enable_slicing=True, dropout_p=dropout)
+def _replay_trace(g, use_noise, dropout, tf=4, bf=4):
+    gs = onets.GSpec(in_channels=4, nf=16, n_rrdb=1, gc=8, tf=tf, hr_kern=5, upscale=4, dropout_p=dropout)
+    ds = onets.DSpec(bf=bf, nz=4, enable_slicing=True, dropout_p=dropout)
     ts = ogan.TrainSpec(use_instance_noise=use_noise, d_g_train_period=2, niter=150000)
     sdG = onets.deterministic_state(onets.g_param_shapes(gs), seed=41, scale=0.5)
     sdD = onets.deterministic_state(onets.d_param_shapes(ds), seed=43, scale=1.0)
@@ -165,6 +165,41 @@ def test_gan_trace_plain(golden):
 def test_gan_trace_noise_dropout(golden):
     """Same with uniform instance noise + Dropout3d: pins the RNG call order."""
     _replay_trace(golden("gan_trace_noise.npz"), use_noise=True, dropout=0.1)
+
+
+def test_gan_trace_plain_w8(golden):
+    """The trace of the bf16-capable widths (terrain features 8, D base width 8) the bf16 GPU test replays."""
+    _replay_trace(golden("gan_trace_plain_w8.npz"), use_noise=False, dropout=0.0, tf=8, bf=8)
+
+
+def test_c1_full_width_step(golden):
+    """Oracle at the SHIPPED width (34.77 M-parameter G, bf 32 D with slicing, 16x16x10 -> 64x64x10) against the
+    reference's own G-iteration + D-iteration: SR field, D logit, all 8 loss entries, D loss and the norm of
+    every parameter gradient (c1_full_step.npz).  Pins the oracle at production width, not only at nf = 16."""
+    from c1_case import c1_oracle_step  # tests/golden/c1_case.py (shared with the GPU parity test)
+
+    g = golden("c1_full_step.npz")
+    r = c1_oracle_step(torch.float32, emulate_bf16=False)
+    assert rel_l2(r["sr"][:, :, ::2, ::2, :], T(g["sr_sub"])) < 1e-5
+    assert abs(float(r["sr"].double().abs().sum()) / float(g["sr_abs_sum"]) - 1) < 1e-5
+    assert rel_l2(r["d_hr_eval"], T(g["d_hr_eval"])) < 1e-5
+    np.testing.assert_allclose(r["G_losses"], g["G_losses"], rtol=1e-4, atol=1e-8)
+    np.testing.assert_allclose(r["D_loss"], float(g["D_loss"]), rtol=1e-4)
+    # D's gradients pass through 10 train-mode BatchNorm backward stages over 80..10240 elements (batch 1) and
+    # LeakyReLU branches of near-zero pre-activations: one branch flip between two fp32 evaluations (different
+    # summation order) moves a whole gradient tensor by ~1e-3 (measured here: the oracle's fp32 run is 1.3e-3
+    # from an fp64 evaluation that the reference's fp32 result matches to 3e-6).  G: 2e-4; D: 5e-3.
+    for tag, tol in (("G", 2e-4), ("D", 5e-3)):
+        grads = r["g" + tag]
+        keys = [str(k) for k in g[f"g{tag}_keys"]]
+        assert keys == list(grads)
+        l2 = np.array([float(grads[k].double().norm()) for k in keys])
+        np.testing.assert_allclose(l2, g[f"g{tag}_l2"], rtol=tol, err_msg=tag)
+        for k in g.files:
+            if k.startswith(f"g{tag}."):
+                assert rel_l2(grads[k[3:]], T(g[k])) < tol, k
+    k8 = "model.1.module.7.RDBs.1.conv3.conv.0.weight"
+    assert rel_l2(r["gG"][k8][:8], T(g["gG8." + k8])) < 2e-4
 
 
 def test_state_dict_manifest_full_size(golden):
