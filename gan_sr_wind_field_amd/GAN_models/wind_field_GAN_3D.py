@@ -148,9 +148,12 @@ class wind_field_GAN_3D(BaseGAN):
         """mean over the (global) batch - the RaGAN average logit"""
         return torch.mean(t) if self.dp is None else self.dp.batch_mean(t)
 
-    def _any(self, flag: torch.Tensor) -> bool:
-        """host-side truth of a device flag - set on ANY rank when data-parallel"""
-        return bool(flag) if self.dp is None else self.dp.any_flag(flag)
+    def _flags(self, flags) -> list:
+        """host-side truth of a list of 0-d device flags in one round trip - set when set on ANY rank"""
+        f = torch.stack([v.reshape(()).to(torch.float32) for v in flags])
+        if self.dp is not None:
+            f = self.dp.global_max(f)
+        return [v > 0 for v in f.tolist()]
 
     def _noise(self, sigma: float, shape, it):
         return trainingtricks.instance_noise(torch.tensor(sigma, device=self.device), shape, it, self.niter,
@@ -201,19 +204,7 @@ class wind_field_GAN_3D(BaseGAN):
         feat = torch.zeros(1, device=self.device)
         if self.feature_extractor is not None:
             feat = self.feature_D_criterion(self.feature_extractor(HR).detach(), self.feature_extractor(fake_HR))
-        pix = torch.zeros(1, device=self.device)
-        if self.pixel_criterion:
-            pix = self.pixel_criterion(HR, fake_HR)
-
-        g_hr = calculate_gradient_of_wind_field(HR[:, :3], self.x, self.y, Z)
-        g_sr = calculate_gradient_of_wind_field(fake_HR[:, :3], self.x, self.y, Z)
-        n_xy, n_z, n_div, n_div2 = get_norm_factors_of_gradients(g_hr, g_sr, self.dp)
-        l_xy = self.gradient_xy_criterion(g_sr[:, :6] / n_xy, g_hr[:, :6] / n_xy)
-        l_z = self.gradient_z_criterion(g_sr[:, 6:] / n_z, g_hr[:, 6:] / n_z)
-        l_div = self.divergence_criterion((g_hr[:, 0] + g_hr[:, 4] + g_hr[:, 8]) / n_div,
-                                          (g_sr[:, 0] + g_sr[:, 4] + g_sr[:, 8]) / n_div)
-        l_div2 = self.xy_divergence_criterion((g_hr[:, 0] + g_hr[:, 4]) / n_div2,
-                                              (g_sr[:, 0] + g_sr[:, 4]) / n_div2)
+        pix, l_xy, l_z, l_div, l_div2, sr_branch = self._content_losses(HR, fake_HR, Z)
 
         L = {
             "adversarial": adv * t.adversarial_loss_weight,
@@ -224,24 +215,80 @@ class wind_field_GAN_3D(BaseGAN):
             "divergence": l_div * t.divergence_loss_weight,
             "xy_divergence": l_div2 * t.xy_divergence_loss_weight,
         }
-        physics = torch.stack([L["divergence"], L["xy_divergence"], L["z_gradient"], L["xy_gradient"]])
-        # ONE host sync (reference: up to 8).  Under data parallelism the flag is OR-ed over the ranks: replicas
-        # that took different branches (or of which only some skipped the Adam step below) would drift apart
-        # for good, parameters being broadcast only once.
-        if self._any(torch.logical_or(physics.isnan(), physics.isinf()).any()):
-            total = L["adversarial"] + L["pix"] + L["feature_D"]
-        else:
-            total = (L["adversarial"] + L["pix"] + L["xy_gradient"] + L["z_gradient"] + L["divergence"]
-                     + L["xy_divergence"] + L["feature_D"])
+        # The reference tests the four physics terms for NaN / Inf (dropping them from the total) and the total
+        # itself (skipping the Adam step) in up to 9 host round trips (:434-460); here all flags - plus "a
+        # normaliser came from SR" of the fused path - travel in ONE.  Under data parallelism they are OR-ed over
+        # the ranks: replicas that took different branches would drift apart for good (parameters are
+        # broadcast only once).
+        def nonfinite(v):
+            return torch.logical_or(v.isnan(), v.isinf()).any()
+
+        def totals():
+            core = L["adversarial"] + L["pix"] + L["feature_D"]
+            full = (L["adversarial"] + L["pix"] + L["xy_gradient"] + L["z_gradient"] + L["divergence"]
+                    + L["xy_divergence"] + L["feature_D"])
+            physics = torch.stack([L["divergence"], L["xy_divergence"], L["z_gradient"], L["xy_gradient"]])
+            return core, full, [nonfinite(physics), nonfinite(core), nonfinite(full)]
+
+        core, full, flags = totals()
+        redo = sr_branch if sr_branch is not None else torch.zeros((), dtype=torch.bool, device=core.device)
+        bad, bad_core, bad_full, redo = self._flags(flags + [redo])
+        if redo and torch.is_grad_enabled():  # rare: SR a hundred times larger than HR (see _content_losses)
+            _, l_xy, l_z, l_div, l_div2, _ = self._content_losses(HR, fake_HR, Z, fused=False)
+            L.update({"xy_gradient": l_xy * t.gradient_xy_loss_weight, "z_gradient": l_z * t.gradient_z_loss_weight,
+                      "divergence": l_div * t.divergence_loss_weight,
+                      "xy_divergence": l_div2 * t.xy_divergence_loss_weight})
+            core, full, flags = totals()
+            bad, bad_core, bad_full = self._flags(flags)
+        total, total_bad = (core, bad_core) if bad else (full, bad_full)
         L["total"] = total
         if training_iteration:
             total.backward()
-            if not self._any(torch.logical_or(total.isnan(), total.isinf()).any()):
+            if not total_bad:
                 self.optimizer_G.step()
             elif self.dp is not None:
                 self.dp.wait()  # the gradient collectives of the skipped step must still complete
         self.log_G_losses(fake_HR, L, training_iteration)
         return total
+
+    def _content_losses(self, HR, fake_HR, Z, fused: bool = True):
+        """(pix, xy_gradient, z_gradient, divergence, xy_divergence) un-weighted (reference :377-432) and, on the
+        fused path, the device flag "a normaliser came from SR" (else None).
+
+        Device tensors with 3 wind components take ONE HIP pass (``wsr_physics_loss_stats``: 6 sums + 8 maxima,
+        Jacobians never materialised; every normaliser n is a scalar, so mse(a/n, b/n) = sum (a-b)^2 / (n^2 N))
+        and its two-launch backward.  The fused sums are differentiable w.r.t. SR only through the residuals,
+        exactly like the reference while n = HR_max; when n = SR_max / 100 (SR a hundred times larger than HR)
+        the reference also differentiates the maximum, and the caller re-evaluates the terms with the composed
+        ops below (``fused=False``), which keep that path."""
+        t = self.cfg.training
+        crit = t.pixel_criterion
+        if fused and HR.is_cuda and HR.shape[1] == 3 and fake_HR.shape[1] == 3 and Z.shape[1] == 1:
+            from .. import hip_ops
+            sums, mx = hip_ops.physics_loss_stats(HR, fake_HR, self.x, self.y, Z)
+            m = mx.view(2, 4)
+            if self.dp is not None:
+                m = self.dp.global_max(m)
+            n = torch.max(m[0], m[1] / 100)
+            nvox = float(HR.shape[0] * HR.shape[2] * HR.shape[3] * HR.shape[4])
+            terms = sums[:4] / (n * n * torch.tensor([6 * nvox, 3 * nvox, nvox, nvox], device=HR.device))
+            pix = torch.zeros(1, device=self.device)
+            if self.pixel_criterion:
+                pix = (sums[4] if crit == "l1" else sums[5]) / (3 * nvox)
+            return pix, terms[0], terms[1], terms[2], terms[3], (m[1] / 100 > m[0]).any()
+        pix = torch.zeros(1, device=self.device)
+        if self.pixel_criterion:
+            pix = self.pixel_criterion(HR, fake_HR)
+        g_hr = calculate_gradient_of_wind_field(HR[:, :3], self.x, self.y, Z)
+        g_sr = calculate_gradient_of_wind_field(fake_HR[:, :3], self.x, self.y, Z)
+        n_xy, n_z, n_div, n_div2 = get_norm_factors_of_gradients(g_hr, g_sr, self.dp)
+        l_xy = self.gradient_xy_criterion(g_sr[:, :6] / n_xy, g_hr[:, :6] / n_xy)
+        l_z = self.gradient_z_criterion(g_sr[:, 6:] / n_z, g_hr[:, 6:] / n_z)
+        l_div = self.divergence_criterion((g_hr[:, 0] + g_hr[:, 4] + g_hr[:, 8]) / n_div,
+                                          (g_sr[:, 0] + g_sr[:, 4] + g_sr[:, 8]) / n_div)
+        l_div2 = self.xy_divergence_criterion((g_hr[:, 0] + g_hr[:, 4]) / n_div2,
+                                              (g_sr[:, 0] + g_sr[:, 4]) / n_div2)
+        return pix, l_xy, l_z, l_div, l_div2, None
 
     def update_G(self, LR, HR, Z, it, training_iteration: bool):
         if training_iteration:

@@ -118,13 +118,6 @@ class DataParallel:
         dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
         return t
 
-    def any_flag(self, flag: Tensor) -> bool:
-        """True on every rank when ``flag`` (a 0-d bool / number) is set on any rank - used for the
-        non-finite-loss guards so that all replicas take the same branch (one host sync, like the local test)"""
-        f = flag.detach().to(torch.float32).reshape(1).clone()
-        dist.all_reduce(f, op=dist.ReduceOp.MAX, group=self.group)
-        return bool(f.item() > 0)
-
     def stat_allreduce(self, t: Tensor) -> None:
         dist.all_reduce(t, group=self.group)
 

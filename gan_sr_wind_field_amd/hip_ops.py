@@ -384,6 +384,51 @@ def wind_gradient(f: Tensor, xs: Tensor, ys: Tensor, zc: Tensor) -> Tensor:
                                zc.contiguous().float())
 
 
+_physics_ws: dict = {}  # per-device partial table of the statistics pass (stream-ordered re-use)
+
+
+class _PhysicsLossStats(torch.autograd.Function):
+    """``wsr_physics_loss_stats`` with ``wsr_physics_loss_bwd`` as backward: (sums[6], maxima[8]) of the content
+    losses in one pass over HR, SR, Z; only the sums carry gradient, and only towards SR."""
+
+    @staticmethod
+    def forward(ctx, hr: Tensor, sr: Tensor, xs: Tensor, ys: Tensor, zc: Tensor):
+        B, _, X, Y, Z = sr.shape
+        dev = sr.device
+        ws = _physics_ws.get(dev)
+        if ws is None:
+            ws = _physics_ws[dev] = torch.empty(int(_lib.lib().wsr_physics_loss_workspace_floats()),
+                                                dtype=torch.float32, device=dev)
+        stats = torch.empty(14, dtype=torch.float32, device=dev)
+        check(_lib.lib().wsr_physics_loss_stats(_p(hr), _p(sr), _p(xs), _p(ys), _p(zc), _p(stats), _p(ws), B, X, Y, Z,
+                                                _stream()), "physics_loss_stats")
+        ctx.save_for_backward(hr, sr, xs, ys, zc)
+        sums, maxima = stats[:6], stats[6:]
+        ctx.mark_non_differentiable(maxima)
+        return sums, maxima
+
+    @staticmethod
+    def backward(ctx, g_sums: Tensor, _g_max):
+        hr, sr, xs, ys, zc = ctx.saved_tensors
+        B, _, X, Y, Z = sr.shape
+        coef = g_sums.contiguous().float()
+        resid = torch.empty((B, 9, X, Y, Z), dtype=torch.float32, device=sr.device)
+        dsr = torch.empty_like(sr)
+        check(_lib.lib().wsr_physics_loss_bwd(_p(hr), _p(sr), _p(xs), _p(ys), _p(zc), _p(coef), _p(resid), _p(dsr), B, X,
+                                              Y, Z, _stream()), "physics_loss_bwd")
+        return None, dsr, None, None, None
+
+
+def physics_loss_stats(hr: Tensor, sr: Tensor, xs: Tensor, ys: Tensor, zc: Tensor):
+    """-> (sums[6], maxima[8]), see ``wsr_physics_loss_stats`` in windsr_hip.h.  hr, sr (B,3,X,Y,Z), zc (B,1,X,Y,Z)."""
+    _need_cuda(hr, sr, xs, ys, zc)
+    B, C_, X, Y, Z = sr.shape
+    if C_ != 3 or hr.shape != sr.shape or xs.numel() != X or ys.numel() != Y or zc.numel() != B * X * Y * Z:
+        raise ValueError("physics_loss_stats wants hr, sr (B,3,X,Y,Z), x (X), y (Y), Z (B,1,X,Y,Z)")
+    f = lambda t: t.contiguous().float()  # noqa: E731
+    return _PhysicsLossStats.apply(f(hr), f(sr), f(xs), f(ys), f(zc))
+
+
 def zfold(t: Tensor, y: Tensor, bias: Optional[Tensor], kz: int, pz: int) -> Tensor:
     """``y[b,c,x,y,z] = bias[c] + sum_k t[b, c*kz+k, x, y, z+k-pz]`` - planar fp32 (see ``wsr_zfold``)."""
     _need_cuda(t, y)

@@ -222,6 +222,23 @@ int wsr_wind_gradient(const float* f, const float* xs, const float* ys, const fl
 int wsr_wind_gradient_bwd(const float* g, const float* xs, const float* ys, const float* zc, float* df, int32_t B,
                           int32_t X, int32_t Y, int32_t Z, void* stream);
 
+/* Fused content losses of the generator (reference GAN_models/wind_field_GAN_3D.py:377-432: pixel L1 / L2,
+ * xy-gradient, z-gradient, divergence and xy-divergence MSE terms over the Jacobians of
+ * calculate_gradient_of_wind_field, normalised by get_norm_factors_of_gradients :773-814).  Every normaliser is
+ * a scalar, so one pass over hr, sr (B,3,X,Y,Z) and zc (B,1,X,Y,Z), planar fp32, yields everything:
+ *   stats[0..5]  = sum (J_sr - J_hr)^2 over channels 0..5 | over channels 6..8 | sum (div3_hr - div3_sr)^2 |
+ *                  sum (div2_hr - div2_sr)^2 | sum |hr - sr| | sum (hr - sr)^2
+ *   stats[6..13] = max |J[:6]|, max J[6:] (signed, as the reference), max |div3|, max |div2| of hr, then of sr
+ * (maxima propagate NaN like torch.max).  workspace: wsr_physics_loss_workspace_floats() floats; the reduction
+ * is two-pass and atomic-free (bit-reproducible).  _bwd: coef[6] (DEVICE array) = d loss / d stats[0..5];
+ * residual = scratch of B*9*X*Y*Z floats; dsr (B,3,X,Y,Z) = d loss / d sr (overwritten).                  */
+int64_t wsr_physics_loss_workspace_floats(void);
+int wsr_physics_loss_stats(const float* hr, const float* sr, const float* xs, const float* ys, const float* zc,
+                           float* stats, float* workspace, int32_t B, int32_t X, int32_t Y, int32_t Z, void* stream);
+int wsr_physics_loss_bwd(const float* hr, const float* sr, const float* xs, const float* ys, const float* zc,
+                         const float* coef, float* residual, float* dsr, int32_t B, int32_t X, int32_t Y, int32_t Z,
+                         void* stream);
+
 /* z-folded form of a conv with very few output channels (the last conv of the generator, 144 -> 3,
  * 5x5x5, Generator_3D_Resnet_ESRGAN.py:120-127): the KZ taps along z become output channels of a
  * (KX,KY,1) conv with C*KZ outputs - 15 instead of 3 of the 16 columns of an MFMA tile do work, a fifth

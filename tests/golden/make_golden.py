@@ -334,6 +334,13 @@ def gen_c1_full():
     out["gD_abs"] = np.array([float(v.double().abs().sum()) for v in gD.values()])
     for k in ("features.0.0.0.weight", "features.4.1.weight", "classifier.2.weight", "features.2.0.1.bias"):
         out["gD." + k] = np_(gD[k])
+    # conditioning yard-stick for the fp32 tolerances: distance of the reference's fp32 generator gradients from
+    # an fp64 evaluation of the same G-iteration (the oracle in double; 48 dense blocks deep, so the first layers
+    # accumulate a few 1e-4 of rounding)
+    from c1_case import c1_oracle_step
+    r64 = c1_oracle_step(torch.float64)
+    out["gG_floor"] = np.array([float((gG[k].double() - r64["gG"][k]).norm() / r64["gG"][k].norm()) for k in gG])
+    out["G_losses_fp64"] = np.array(r64["G_losses"])
     save("c1_full_step.npz", **out)
 
 

@@ -8,8 +8,9 @@
   seconds: full-width G and D, bf16;
 * the 6-iteration loss / weight trace of the reference, bf16.
 
-Tolerances.  fp32: outputs 2e-5, losses 2e-4, G gradients 2e-4 (rel-L2); D gradients 5e-3 (train-mode
-BatchNorm at batch 1 + LeakyReLU branch flips, see test_oracle_golden.py::test_c1_full_width_step).
+Tolerances.  fp32: outputs 2e-5, losses 2e-4, G gradients 2e-4 + 1.5 x the reference's own fp32-vs-fp64
+distance on that tensor (recorded in the fixture; rel-L2); D gradients 5e-3 (train-mode BatchNorm at batch 1 +
+LeakyReLU branch flips, see test_oracle_golden.py::test_c1_full_width_step).
 bf16: outputs 2e-2; every other bound is DERIVED, per loss entry and per parameter tensor, from the distance
 d_k between the fp32 oracle and the same oracle with bf16 *storage emulation* (``GSpec.bf16_storage``: every
 tensor the MI355X path keeps in HBM rounded to bf16, fp32 accumulation): tol_k = floor + 2 d_k with floor
@@ -113,7 +114,10 @@ def test_c1_shipped_config_step(golden, hip, dtype):
     assert (got[ref == 0] == 0).all()
     grads = {k: p.grad for k, p in gan.G.named_parameters()}
     errs = {k: rel_l2(grads[k], r["gG"][k]) for k in grads}
-    lim = _bounds(r["gG"], e["gG"], 2e-2) if bf16 else {k: 2e-4 for k in grads}
+    # fp32: 2e-4 + 1.5 x the distance of the REFERENCE's fp32 gradient from an fp64 evaluation, recorded per tensor
+    # in the fixture (48 dense blocks deep: median 2.4e-4, worst 9e-4 - rounding, not arithmetic)
+    floor = dict(zip((str(k) for k in g["gG_keys"]), g["gG_floor"]))
+    lim = _bounds(r["gG"], e["gG"], 2e-2) if bf16 else {k: 2e-4 + 1.5 * floor[k] for k in grads}
     rep["gG_worst"] = sorted(((v, k, lim[k]) for k, v in errs.items()), reverse=True)[:5]
     rep["gG_median"] = float(np.median(list(errs.values())))
     bad = {k: (v, lim[k]) for k, v in errs.items() if not v < lim[k]}

@@ -559,6 +559,54 @@ def test_wind_gradient_vs_reference_fixture_and_oracle(golden, hip):
     np.testing.assert_allclose([float(v) for v in n], g["norms"], rtol=1e-5)
 
 
+def test_fused_content_losses_vs_reference_fixture_and_oracle(golden, hip):
+    """``wsr_physics_loss_stats`` / ``_bwd``: the 6 sums and 8 maxima against the same quantities formed from the
+    Jacobian stacks the REFERENCE produced (physics.npz), the four normalised MSE terms + L1 against the oracle's
+    composed expressions (oracle/gan.py G_loss_terms arithmetic) and d loss / d SR against fp64 autograd of them."""
+    from gan_sr_wind_field_amd import hip_ops as o
+    from oracle import physics as ophys
+
+    g = golden("physics.npz")
+    HR, SR, Z, x, y = (T(g[k]) for k in ("HR", "SR", "Z", "x", "y"))
+    jh, js = T(g["grad_hr"]).double(), T(g["grad_sr"]).double()
+    srd = SR.to(DEV).requires_grad_(True)
+    sums, mx = o.physics_loss_stats(HR.to(DEV), srd, x.to(DEV), y.to(DEV), Z.to(DEV))
+    d3 = lambda j: j[:, 0] + j[:, 4] + j[:, 8]  # noqa: E731
+    d2 = lambda j: j[:, 0] + j[:, 4]  # noqa: E731
+    want = [((js[:, :6] - jh[:, :6]) ** 2).sum(), ((js[:, 6:] - jh[:, 6:]) ** 2).sum(), ((d3(jh) - d3(js)) ** 2).sum(),
+            ((d2(jh) - d2(js)) ** 2).sum(), (HR.double() - SR.double()).abs().sum(), ((HR.double() - SR.double()) ** 2).sum()]
+    np.testing.assert_allclose(sums.detach().cpu().numpy(), [float(v) for v in want], rtol=2e-5)
+    wmax = [f(j) for j in (jh, js) for f in (lambda j: j[:, :6].abs().max(), lambda j: j[:, 6:].max(),
+                                             lambda j: d3(j).abs().max(), lambda j: d2(j).abs().max())]
+    np.testing.assert_allclose(mx.cpu().numpy(), [float(v) for v in wmax], rtol=1e-5)
+    # determinism of the two-pass reduction
+    s2, m2 = o.physics_loss_stats(HR.to(DEV), srd, x.to(DEV), y.to(DEV), Z.to(DEV))
+    assert torch.equal(s2, sums) and torch.equal(m2, mx)
+    # loss terms and gradient: weights of the shipped ini
+    w = dict(pix=0.136, xy=3.064, z=0.2, div=0.366, div2=0.721)
+    n = torch.max(mx[:4], mx[4:] / 100)
+    nv = float(HR.shape[0] * HR[0, 0].numel())
+    loss = (w["xy"] * sums[0] / (n[0] ** 2 * 6 * nv) + w["z"] * sums[1] / (n[1] ** 2 * 3 * nv)
+            + w["div"] * sums[2] / (n[2] ** 2 * nv) + w["div2"] * sums[3] / (n[3] ** 2 * nv) + w["pix"] * sums[4] / (3 * nv))
+    loss.backward()
+    srr = SR.double().requires_grad_(True)
+    gh = ophys.wind_gradient(HR.double(), x.double(), y.double(), Z.double())
+    gs = ophys.wind_gradient(srr, x.double(), y.double(), Z.double())
+    nn_ = ophys.gradient_norm_factors(gh, gs)
+    F_ = torch.nn.functional
+    ref = (w["xy"] * F_.mse_loss(gs[:, :6] / nn_[0], gh[:, :6] / nn_[0]) + w["z"] * F_.mse_loss(gs[:, 6:] / nn_[1], gh[:, 6:] / nn_[1])
+           + w["div"] * F_.mse_loss(d3(gh) / nn_[2], d3(gs) / nn_[2]) + w["div2"] * F_.mse_loss(d2(gh) / nn_[3], d2(gs) / nn_[3])
+           + w["pix"] * F_.l1_loss(HR.double(), srr))
+    assert abs(float(loss) - float(ref)) < 1e-5 * abs(float(ref))
+    ref.backward()
+    assert rel_l2(srd.grad, srr.grad) < 1e-5
+    # the l2 pixel criterion's sum carries its gradient too
+    srd.grad = None
+    sums, _ = o.physics_loss_stats(HR.to(DEV), srd, x.to(DEV), y.to(DEV), Z.to(DEV))
+    (sums[5] / (3 * nv)).backward()
+    assert rel_l2(srd.grad, 2 * (SR - HR) / (3 * nv)) < 1e-6
+
+
 @pytest.mark.parametrize("name,cin,cout,k,s,p,xyz,B", [
     ("d_down_s221", 64, 64, (4, 4, 3), (2, 2, 1), (1, 1, 1), (12, 10, 9), 1),     # blocks 1-3 of D
     ("d_down_s222", 32, 32, (4, 4, 3), (2, 2, 2), (1, 1, 1), (16, 12, 22), 2),    # first / last block (halved z)
