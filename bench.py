@@ -218,6 +218,7 @@ def main():
     t0 = time.perf_counter()
     for i in range(args.warmup, args.warmup + args.steps):
         step(i)
+    issued = time.perf_counter() - t0  # host time to issue the steps (the loss guards sync once per G-iteration)
     barrier()
     elapsed = time.perf_counter() - t0
     if distributed:
@@ -269,7 +270,8 @@ def main():
                    "global_steps_per_s": round(steps_per_s, 4), "samples_per_s": round(world * B * steps_per_s, 4),
                    "step_tflop": round(step_flops / 1e12, 2),
                    "achieved_tflops_per_gpu": round(step_flops / 1e12 / (elapsed / args.steps), 1),
-                   "peak_hbm_gb": round(torch.cuda.max_memory_allocated(dev) / 2**30, 2)},
+                   "peak_hbm_gb": round(torch.cuda.max_memory_allocated(dev) / 2**30, 2),
+                   "host_issue_ms_per_step": round(issued / args.steps * 1e3, 2)},
         "roofline": {"bound": "mfma",
                      "kernel": ("conv_tile_kernel<8,1,4,9,2> (LDS halo-tile conv)" if args.dtype == "bf16"
                                 else "igemm_kernel<F32,4,1,2,9>") + ": hr_convs.0 5x5x5 144->144 fwd + dgrad",

@@ -156,8 +156,17 @@ class wind_field_GAN_3D(BaseGAN):
         return [v > 0 for v in f.tolist()]
 
     def _noise(self, sigma: float, shape, it):
-        return trainingtricks.instance_noise(torch.tensor(sigma, device=self.device), shape, it, self.niter,
-                                             device=self.device)
+        return trainingtricks.instance_noise(self._scalar(sigma), shape, it, self.niter, device=self.device)
+
+    def _scalar(self, v, dtype=None) -> torch.Tensor:
+        """0-d tensor on the model's device WITHOUT a blocking host-to-device copy: ``torch.tensor(v, device=cuda)``
+        copies from pageable memory and waits for the stream to drain - a dozen pipeline bubbles per iteration on
+        the reference's label / noise path; ``torch.full`` is a fill kernel."""
+        if self.device.type != "cuda":
+            return torch.tensor(v, device=self.device) if dtype is None else torch.tensor(v, device=self.device, dtype=dtype)
+        if dtype is None:
+            dtype = torch.int64 if isinstance(v, int) else torch.float32
+        return torch.full((), v, dtype=dtype, device=self.device)
 
     # ------------------------------------------------------------------ D passes
     def D_forward(self, HR: torch.Tensor, fake_HR: torch.Tensor, it: torch.Tensor, train_D: bool):
@@ -271,7 +280,10 @@ class wind_field_GAN_3D(BaseGAN):
                 m = self.dp.global_max(m)
             n = torch.max(m[0], m[1] / 100)
             nvox = float(HR.shape[0] * HR.shape[2] * HR.shape[3] * HR.shape[4])
-            terms = sums[:4] / (n * n * torch.tensor([6 * nvox, 3 * nvox, nvox, nvox], device=HR.device))
+            key = (HR.device, nvox)
+            if getattr(self, "_mse_den", (None,))[0] != key:  # elements per term: 6, 3, 1, 1 Jacobian channels
+                self._mse_den = (key, torch.tensor([6 * nvox, 3 * nvox, nvox, nvox], device=HR.device))
+            terms = sums[:4] / (n * n * self._mse_den[1])
             pix = torch.zeros(1, device=self.device)
             if self.pixel_criterion:
                 pix = (sums[4] if crit == "l1" else sums[5]) / (3 * nvox)
@@ -331,8 +343,9 @@ class wind_field_GAN_3D(BaseGAN):
         elif gan_type == "relativisticavg":
             loss_D = (self.criterion(y_pred - self._mean(fake_y_pred), self.HR_labels)
                       + self.criterion(fake_y_pred - self._mean(y_pred), self.fake_HR_labels)) / 2.0
-            if torch.all(self.HR_labels == 0.9):
-                loss_D -= 0.1985
+            # reference (:558-559): ``if torch.all(labels == 0.9): loss_D -= 0.1985`` - the same value without
+            # the host round trip of the ``if``
+            loss_D = loss_D - 0.1985 * torch.all(self.HR_labels == 0.9)
         else:
             raise NotImplementedError(f"Only relativistic and relativisticavg GAN are implemented, not {gan_type}")
         if training_epoch:
@@ -344,7 +357,7 @@ class wind_field_GAN_3D(BaseGAN):
     def compute_losses_and_optimize(self, LR, HR, Z, it, training_iteration: bool = False):
         self.batch_size = HR.size(0)
         it_int = int(it)
-        it = torch.tensor(it, device=self.device)
+        it = self._scalar(it)
         self.make_new_labels(it)
         t = self.cfg.training
         if self.use_D_feature_extractor_cost and it_int % t.feature_D_update_period == 0:
@@ -378,12 +391,12 @@ class wind_field_GAN_3D(BaseGAN):
         """Real / fake label vectors of this iteration (reference :627-678)."""
         t = self.cfg.training
         pred_real, pred_fake = (False, True) if t.flip_labels else (True, False)
-        real = torch.tensor(1.0, device=self.device)
-        fake = torch.tensor(0.0, device=self.device)
+        real = self._scalar(1.0)
+        fake = self._scalar(0.0)
         if t.use_one_sided_label_smoothing and t.flip_labels:
-            fake = torch.tensor(0.1, device=self.device) - 0.1 * it / self.niter
+            fake = self._scalar(0.1) - 0.1 * it / self.niter
         elif t.use_one_sided_label_smoothing:
-            real = torch.tensor(0.9, device=self.device) + 0.1 * it / self.niter
+            real = self._scalar(0.9) + 0.1 * it / self.niter
         extra = {} if t.use_noisy_labels else {"noise_stddev": 0.0}
         self.HR_labels = trainingtricks.noisy_labels(pred_real, self.batch_size, true_label_val=real,
                                                      false_label_val=fake, device=self.device, **extra).squeeze()

@@ -101,8 +101,13 @@ __device__ __forceinline__ void dma_wait() { asm volatile("s_waitcnt vmcnt(0)" :
 __device__ __forceinline__ unsigned fdiv(unsigned n, unsigned d, unsigned mg) { return d == 1 ? n : __umulhi(n, mg); }
 static inline unsigned fdiv_magic(int d) { return d <= 1 ? 0u : (unsigned)(((1ull << 32) + d - 1) / d); }
 
+// activation DMA units (1 KB) a wave may have to issue per chunk: registers of the resolved source offsets
+constexpr int ct_xk(int waves, int tm) { return waves <= 4 ? 16 : (tm <= 2 ? 13 : 10); }
+
+// (four-wave workgroups: one wave per SIMD by construction - let the register allocator have all 512)
 template <int WM, int WN, int TM, int TN, int TPK, bool PIPE, bool MASK>
-__global__ __launch_bounds__(WM * WN * 64) void conv_tile_kernel(const CtArgs a) {
+__global__ __launch_bounds__(WM * WN * 64) __attribute__((amdgpu_waves_per_eu(1, WM * WN <= 4 ? 1 : 8)))
+void conv_tile_kernel(const CtArgs a) {
   constexpr int WAVES = WM * WN, NT = WAVES * 64;
   constexpr int PL = 4 / TPK;      // octet planes per chunk
   constexpr int CK = 8 * PL;       // channels per chunk
@@ -162,7 +167,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_tile_kernel(const CtArgs a)
 
   // LDS-DMA (global_load_lds): each wave moves whole 1 KB units, lane l -> unit base + 16*l.
   // weights of stage (chunk, st) -> Ws[buf]
-  auto w_issue = [&](int chunk, int st, int buf) {
+  auto w_issue = [&](int chunk, int st, int buf) __attribute__((always_inline)) {
     const unsigned dst = ws_lds + buf * stage_units * 1024;
     for (int u = wave; u < stage_units; u += WAVES) {
       const int tsi = u / NTW, nl = u - tsi * NTW;
@@ -178,7 +183,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_tile_kernel(const CtArgs a)
 
   // The halo geometry is the same for every chunk, so each wave resolves the source of "its" DMA units
   // (u = wave + WAVES*k) once: element offset of the lane's voxel (or OOB), octet plane, LDS offset.
-  constexpr int XK = TM <= 2 ? 13 : 10;  // max units per wave per chunk (checked on the host; strided tiles: 13)
+  constexpr int XK = ct_xk(WAVES, TM);  // max units per wave per chunk (checked on the host; strided tiles: 13)
   unsigned xoff[XK];
   int xo8[VM ? 1 : XK], xdst[VM ? 1 : XK];  // voxel-major rows: octet = lane & 1, unit u lands at u KB
 #pragma unroll
@@ -216,7 +221,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_tile_kernel(const CtArgs a)
   }
   if constexpr (VM) { xo8[0] = 8 * (lane & 1); xdst[0] = 0; }
   // units [u0, u1) of the activation chunk (with halo) -> Xs[buf]; out-of-range voxels read the zero page
-  auto x_issue = [&](int chunk, int buf, int u0, int u1) {
+  auto x_issue = [&](int chunk, int buf, int u0, int u1) __attribute__((always_inline)) {
     const unsigned dst = xs_lds + buf * xs_bytes;
 #pragma unroll
     for (int k = 0; k < XK; ++k) {
@@ -287,7 +292,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_tile_kernel(const CtArgs a)
       dma_wait();
       __syncthreads();
     }
-    auto burst = [&]() {
+    auto burst = [&]() __attribute__((always_inline)) {
 #ifdef WSR_CT_STAMPS
       if (a.ablate & 2) goto skip_w;
 #endif
@@ -307,7 +312,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_tile_kernel(const CtArgs a)
     const char* xcur = Xs + (a.xbufs == 2 ? (chunk & 1) * xs_bytes : 0);
     const int ts_end = min(a.TS, a.nts - st * a.TS);
     const int* tt = ttab + st * a.TS * TPK + lane_tsub;
-    auto load_frags = [&](int tsi, uint4 (&wf)[TN], uint4 (&xf)[TM]) {
+    auto load_frags = [&](int tsi, uint4 (&wf)[TN], uint4 (&xf)[TM]) __attribute__((always_inline)) {
 #ifdef WSR_CT_STAMPS
       if (a.ablate & 4) return;
 #endif
@@ -317,7 +322,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_tile_kernel(const CtArgs a)
 #pragma unroll
       for (int i = 0; i < TM; ++i) xf[i] = *reinterpret_cast<const uint4*>(xcur + hb[i] + toff);
     };
-    auto mma_frags = [&](const uint4 (&wf)[TN], const uint4 (&xf)[TM]) {
+    auto mma_frags = [&](const uint4 (&wf)[TN], const uint4 (&xf)[TM]) __attribute__((always_inline)) {
 #ifdef WSR_CT_STAMPS
       if (a.ablate & 8) return;
 #endif
@@ -326,7 +331,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_tile_kernel(const CtArgs a)
 #pragma unroll
         for (int j = 0; j < TN; ++j) mma_chunk<BF16>(acc[i][j], wf[j], xf[i]);
     };
-    auto run_ksteps = [&](int lo, int hi) {
+    auto run_ksteps = [&](int lo, int hi) __attribute__((always_inline)) {
       if (lo >= hi) return;
       if constexpr (PIPE) {
         // register double-buffering: the fragments of K-step t+1 are in flight during the MFMAs of K-step t
@@ -403,7 +408,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_tile_kernel(const CtArgs a)
   constexpr int FS = FD + 1;
   float bb[FS][4], ss[FS][4];
   uint2 rr[FS][TM], yy[FS][TM];
-  auto fetch = [&](int j, int s) {
+  auto fetch = [&](int j, int s) __attribute__((always_inline)) {
     const int co0 = cob + 16 * j;
     {
       const int col = (wn * TN + j) * 16 + fg * 4;  // column within the workgroup
@@ -542,7 +547,7 @@ int launch_ct(CtArgs& a, hipStream_t st) {
     if (ts_max >= 3 || ts_max >= a.nts || a.xbufs == 1) break;
   }
   if (ts_max < 1) return WSR_EUNSUPPORTED;
-  if ((VM ? (L + 31) / 32 : ((L + 63) / 64) * PL) > (TM <= 2 ? 13 : 10) * WAVES) return WSR_EUNSUPPORTED;  // XK units per wave
+  if ((VM ? (L + 31) / 32 : ((L + 63) / 64) * PL) > ct_xk(WAVES, TM) * WAVES) return WSR_EUNSUPPORTED;  // XK units per wave
   if ((long)a.B * a.Xi * a.Yi * a.Zi * a.in_ctot >= 0xFFFFFFFFL) return WSR_EUNSUPPORTED;  // 32-bit element offsets
   const int nph = (a.nts + ts_max - 1) / ts_max;
   a.TS = (a.nts + nph - 1) / nph;  // balanced stages
@@ -564,7 +569,8 @@ int launch_ct(CtArgs& a, hipStream_t st) {
   a.mg_KZ = fdiv_magic(a.KZ); a.mg_KY = fdiv_magic(a.KY);
   a.mg_ng = fdiv_magic(a.ngroups); a.mg_tz = fdiv_magic(a.tiles_z);
   a.mg_ty = fdiv_magic(a.tiles_y); a.mg_tx = fdiv_magic(a.tiles_x);
-  constexpr bool PIPE = TN <= 7;  // register budget: (TM+TN)*8 fragment + TM*TN*4 accumulator VGPRs
+  // register budget: (TM+TN)*8 fragment + TM*TN*4 accumulator VGPRs; four-wave workgroups have 512 per wave
+  constexpr bool PIPE = TN <= 7 || WAVES <= 4;
   if (a.mask_y && !MASK) return WSR_EUNSUPPORTED;
   auto kern = conv_tile_kernel<WM, WN, TM, TN, TPK, PIPE, MASK>;
   static bool attr_done = false;

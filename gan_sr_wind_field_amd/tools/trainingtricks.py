@@ -11,8 +11,19 @@ def noisy_labels(label_type: bool, batch_size: int, noise_stddev=torch.tensor(0.
     The normal draw happens on the CPU generator even for stddev 0, like the
     reference (:37-39), so the host RNG stream advances identically.
     """
-    noise = torch.normal(mean=0.0, std=torch.full(torch.Size([int(batch_size)]), float(noise_stddev)))
+    std = float(noise_stddev)
+    noise = torch.normal(mean=0.0, std=torch.full(torch.Size([int(batch_size)]), std))
     base = true_label_val if label_type else false_label_val
+    dev = torch.device(device)
+    if dev.type == "cuda":
+        # no blocking host-to-device copies on the train-step path (a pageable copy waits for the stream to
+        # drain): N(0, 0) is exactly zero, a real draw travels through pinned memory, the clamp bounds are scalars
+        lo, hi = float(val_lower_lim), float(val_upper_lim)
+        if std == 0.0:
+            vals = base.to(dev).expand(int(batch_size)) + torch.zeros((), device=dev)
+        else:
+            vals = noise.pin_memory().to(dev, non_blocking=True) + base
+        return vals.clamp(min=lo, max=hi)
     vals = noise.to(device) + base
     return torch.minimum(torch.maximum(vals, val_lower_lim.to(vals.device)), val_upper_lim.to(vals.device))
 

@@ -121,6 +121,8 @@ def test_c1_shipped_config_step(golden, hip, dtype):
     rep["gG_worst"] = sorted(((v, k, lim[k]) for k, v in errs.items()), reverse=True)[:5]
     rep["gG_median"] = float(np.median(list(errs.values())))
     bad = {k: (v, lim[k]) for k, v in errs.items() if not v < lim[k]}
+    rep["gG_over"] = {k: [v[0], float(v[1]), float(floor[k])] for k, v in bad.items()}
+    _report(f"c1_{dtype}", rep)
     assert not bad, bad
     # the same gradients against the reference's own run: norm of every tensor + the recorded tensors
     l2 = np.array([float(grads[str(k)].double().norm()) for k in g["gG_keys"]])
