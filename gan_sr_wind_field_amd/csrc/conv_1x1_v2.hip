@@ -52,8 +52,7 @@ __device__ __forceinline__ void unpack8(const uint4& u, float (&f)[8]) {
 // 32p + 8fg .. +7, which is exactly its own K-step fragment p: no residual loads at all.
 template <int NT, int KS, bool MASK, bool RX>
 __global__ __launch_bounds__(512, 4) void conv1x1_v2_kernel(const C2Args a) {
-  constexpr int WAVES = 8, NP = NT / 2;
-  constexpr int WG = NT >= 16 ? 4 : 8;  // filter fragments requested together (register budget: 128)
+  constexpr int WAVES = 8;
   extern __shared__ __attribute__((aligned(16))) char smem[];  // KS*NT fragments of 1 KB, then NT*16 bias floats
   const int t = threadIdx.x, lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -93,77 +92,83 @@ __global__ __launch_bounds__(512, 4) void conv1x1_v2_kernel(const C2Args a) {
   const char* wl = smem + lane * 16;
   const float rs1 = a.res ? a.beta / a.alpha : 0.f, rs2 = a.res2 ? a.beta2 / a.alpha : 0.f;
 
+  // One strip = 16 voxels x NT n-tiles, contracted in passes of NH <= 8 n-tiles (32 accumulator registers; the
+  // strip's K-step fragments stay in registers over the passes), each pass: accumulator start, MFMAs, stores.
+  constexpr int NH = NT > 8 ? 8 : NT;
   auto do_strip = [&](int s, const uint4 (&xf)[KS]) __attribute__((always_inline)) {
     const long v = (long)s * 16 + fr;
     const bool vok = v < a.nvox;
     const long vc = vok ? v : 0;
-    // accumulators start from bias + (beta/alpha) res + (beta2/alpha) res2; lane (fr, fg) owns channels
-    // 32p + 8fg .. +7 of voxel v: acc[2p] the first four, acc[2p+1] the last four
-    f32x4_t acc[NT];
+    unsigned short* o = a.out + vc * a.out_ctot + a.out_off + 8 * fg;
 #pragma unroll
-    for (int p = 0; p < NP; ++p) {
-      const int co = 32 * p + 8 * fg;
-      const float4 b0 = *reinterpret_cast<const float4*>(btab + co), b1 = *reinterpret_cast<const float4*>(btab + co + 4);
-      float f[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
-      if (RX ? (p < KS && co < a.res_c1) : (a.res && co < a.res_c1)) {
-        float r[8];
-        if constexpr (RX) unpack8(xf[p < KS ? p : 0], r);
-        else unpack8(*reinterpret_cast<const uint4*>(a.res + vc * a.res_ctot + a.res_off + co), r);
+    for (int h0 = 0; h0 < NT; h0 += NH) {
+      // accumulators start from bias + (beta/alpha) res + (beta2/alpha) res2; lane (fr, fg) owns channels
+      // 32p + 8fg .. +7 of voxel v: acc[2p] the first four, acc[2p+1] the last four
+      f32x4_t acc[NH];
 #pragma unroll
-        for (int q = 0; q < 8; ++q) f[q] += rs1 * r[q];
+      for (int pp = 0; pp < NH / 2; ++pp) {
+        const int p = h0 / 2 + pp;
+        const int co = 32 * p + 8 * fg;
+        const float4 b0 = *reinterpret_cast<const float4*>(btab + co), b1 = *reinterpret_cast<const float4*>(btab + co + 4);
+        float f[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+        if (RX ? (p < KS && co < a.res_c1) : (a.res && co < a.res_c1)) {
+          float r[8];
+          if constexpr (RX) unpack8(xf[p < KS ? p : 0], r);
+          else unpack8(*reinterpret_cast<const uint4*>(a.res + vc * a.res_ctot + a.res_off + co), r);
+#pragma unroll
+          for (int q = 0; q < 8; ++q) f[q] += rs1 * r[q];
+        }
+        if (a.res2) {
+          float r[8];
+          unpack8(*reinterpret_cast<const uint4*>(a.res2 + vc * a.res2_ctot + a.res2_off + co), r);
+#pragma unroll
+          for (int q = 0; q < 8; ++q) f[q] += rs2 * r[q];
+        }
+        acc[2 * pp] = f32x4_t{f[0], f[1], f[2], f[3]};
+        acc[2 * pp + 1] = f32x4_t{f[4], f[5], f[6], f[7]};
       }
-      if (a.res2) {
-        float r[8];
-        unpack8(*reinterpret_cast<const uint4*>(a.res2 + vc * a.res2_ctot + a.res2_off + co), r);
+      // (fenced per K-step: left alone, the scheduler requests all filter fragments up front - 256 registers -
+      // and spills; NH fragments in flight are enough with 4 waves per SIMD)
 #pragma unroll
-        for (int q = 0; q < 8; ++q) f[q] += rs2 * r[q];
-      }
-      acc[2 * p] = f32x4_t{f[0], f[1], f[2], f[3]};
-      acc[2 * p + 1] = f32x4_t{f[4], f[5], f[6], f[7]};
-    }
-    // (fenced in groups of WG fragments: left alone, the scheduler requests all KS*NT filter fragments up front -
-    // 256 registers - and spills; 8 fragments in flight are enough with 4 waves per SIMD)
+      for (int ks = 0; ks < KS; ++ks) {
+        uint4 w[NH];
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
+        for (int j = 0; j < NH; ++j) w[j] = *reinterpret_cast<const uint4*>(wl + (ks * NT + h0 + j) * 1024);
 #pragma unroll
-      for (int j0 = 0; j0 < NT; j0 += WG) {
-        uint4 w[WG];
-#pragma unroll
-        for (int j = 0; j < WG; ++j) w[j] = *reinterpret_cast<const uint4*>(wl + (ks * NT + j0 + j) * 1024);
-#pragma unroll
-        for (int j = 0; j < WG; ++j) mma_chunk<BF16>(acc[j0 + j], w[j], xf[ks]);
+        for (int j = 0; j < NH; ++j) mma_chunk<BF16>(acc[j], w[j], xf[ks]);
         __builtin_amdgcn_sched_barrier(0);
       }
-    }
-    if (!vok) return;
-    unsigned short* o = a.out + v * a.out_ctot + a.out_off + 8 * fg;
+      if (vok) {
 #pragma unroll
-    for (int p = 0; p < NP; ++p) {
-      const int co = 32 * p + 8 * fg;
-      float f[8] = {acc[2 * p][0], acc[2 * p][1], acc[2 * p][2], acc[2 * p][3],
-                    acc[2 * p + 1][0], acc[2 * p + 1][1], acc[2 * p + 1][2], acc[2 * p + 1][3]};
-      if (a.act) {
+        for (int pp = 0; pp < NH / 2; ++pp) {
+          const int p = h0 / 2 + pp;
+          const int co = 32 * p + 8 * fg;
+          float f[8] = {acc[2 * pp][0], acc[2 * pp][1], acc[2 * pp][2], acc[2 * pp][3],
+                        acc[2 * pp + 1][0], acc[2 * pp + 1][1], acc[2 * pp + 1][2], acc[2 * pp + 1][3]};
+          if (a.act) {
 #pragma unroll
-        for (int q = 0; q < 8; ++q) f[q] = f[q] > 0.f ? f[q] : f[q] * a.slope;
-      }
+            for (int q = 0; q < 8; ++q) f[q] = f[q] > 0.f ? f[q] : f[q] * a.slope;
+          }
 #pragma unroll
-      for (int q = 0; q < 8; ++q) f[q] *= a.alpha;
-      if constexpr (MASK) {  // (mask window bounds are multiples of 8: whole lanes are inside or outside)
-        if (co >= a.mask_c0 && co < a.mask_c1) {
-          const uint4 y = *reinterpret_cast<const uint4*>(a.mask_y + v * a.mask_ctot + a.mask_off + (co - a.mask_c0));
-          // bf16 sign test on the raw bits: y > 0 <=> sign clear and not zero
-          f[0] *= (short)(y.x & 0xFFFFu) > 0 ? 1.f : a.mask_slope; f[1] *= (int)y.x > 0xFFFF ? 1.f : a.mask_slope;
-          f[2] *= (short)(y.y & 0xFFFFu) > 0 ? 1.f : a.mask_slope; f[3] *= (int)y.y > 0xFFFF ? 1.f : a.mask_slope;
-          f[4] *= (short)(y.z & 0xFFFFu) > 0 ? 1.f : a.mask_slope; f[5] *= (int)y.z > 0xFFFF ? 1.f : a.mask_slope;
-          f[6] *= (short)(y.w & 0xFFFFu) > 0 ? 1.f : a.mask_slope; f[7] *= (int)y.w > 0xFFFF ? 1.f : a.mask_slope;
+          for (int q = 0; q < 8; ++q) f[q] *= a.alpha;
+          if constexpr (MASK) {  // (mask window bounds are multiples of 8: whole lanes are inside or outside)
+            if (co >= a.mask_c0 && co < a.mask_c1) {
+              const uint4 y = *reinterpret_cast<const uint4*>(a.mask_y + v * a.mask_ctot + a.mask_off + (co - a.mask_c0));
+              // bf16 sign test on the raw bits: y > 0 <=> sign clear and not zero
+              f[0] *= (short)(y.x & 0xFFFFu) > 0 ? 1.f : a.mask_slope; f[1] *= (int)y.x > 0xFFFF ? 1.f : a.mask_slope;
+              f[2] *= (short)(y.y & 0xFFFFu) > 0 ? 1.f : a.mask_slope; f[3] *= (int)y.y > 0xFFFF ? 1.f : a.mask_slope;
+              f[4] *= (short)(y.z & 0xFFFFu) > 0 ? 1.f : a.mask_slope; f[5] *= (int)y.z > 0xFFFF ? 1.f : a.mask_slope;
+              f[6] *= (short)(y.w & 0xFFFFu) > 0 ? 1.f : a.mask_slope; f[7] *= (int)y.w > 0xFFFF ? 1.f : a.mask_slope;
+            }
+          }
+          uint4 u;
+          u.x = (unsigned)f2bf(f[0]) | ((unsigned)f2bf(f[1]) << 16);
+          u.y = (unsigned)f2bf(f[2]) | ((unsigned)f2bf(f[3]) << 16);
+          u.z = (unsigned)f2bf(f[4]) | ((unsigned)f2bf(f[5]) << 16);
+          u.w = (unsigned)f2bf(f[6]) | ((unsigned)f2bf(f[7]) << 16);
+          *reinterpret_cast<uint4*>(o + 32 * p) = u;
         }
       }
-      uint4 u;
-      u.x = (unsigned)f2bf(f[0]) | ((unsigned)f2bf(f[1]) << 16);
-      u.y = (unsigned)f2bf(f[2]) | ((unsigned)f2bf(f[3]) << 16);
-      u.z = (unsigned)f2bf(f[4]) | ((unsigned)f2bf(f[5]) << 16);
-      u.w = (unsigned)f2bf(f[6]) | ((unsigned)f2bf(f[7]) << 16);
-      *reinterpret_cast<uint4*>(o + 32 * p) = u;
     }
   };
 

@@ -470,6 +470,25 @@ __global__ void zunfold_kernel(const float* __restrict__ g, typename T::elem* __
 }
 
 
+// ---- per-channel sum of a planar fp32 tensor (B, C, V): the bias gradient of the last conv -----------------
+// row blockIdx.y of `part` gets the C partial sums of slice blockIdx.y; chan_sum_final_kernel adds the rows
+__global__ __launch_bounds__(256) void plane_sum_kernel(const float* __restrict__ src, int B, int C, long V,
+                                                       float* __restrict__ part) {
+  const int c = blockIdx.x;
+  const long per = (V + gridDim.y - 1) / gridDim.y, v0 = (long)blockIdx.y * per, v1 = v0 + per < V ? v0 + per : V;
+  float a = 0.f;
+  for (int b = 0; b < B; ++b) {
+    const float* p = src + ((long)b * C + c) * V;
+    for (long v = v0 + threadIdx.x; v < v1; v += 256) a += p[v];
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) a += __shfl_xor(a, off, 64);
+  __shared__ float sh[4];
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = a;
+  __syncthreads();
+  if (threadIdx.x == 0) part[(long)blockIdx.y * C + c] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+}
+
 // ---- wind-field derivatives (see windsr_hip.h); stencil rows: stencil.h
 // forward: one thread per (b, comp, x, y, z) point, three derivatives
 __global__ void wind_gradient_kernel(const float* __restrict__ f, const float* __restrict__ xs, const float* __restrict__ ys,
@@ -818,6 +837,19 @@ extern "C" int wsr_chan_sum(const void* x, int32_t x_ctot, int32_t x_off, int32_
   WSR_LAUNCH_CHECK();
   hipLaunchKernelGGL(chan_sum_final_kernel, dim3(1), dim3(1024), 0, as_stream(stream), partials, (int)grid, C, scale,
                      out);
+  WSR_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int wsr_plane_sum(const float* src, int32_t B, int32_t C, int64_t V, float* out, float* partials, void* stream) {
+  if (!src || !out || !partials || B <= 0 || C <= 0 || C > 1024 || V <= 0) return WSR_EINVAL;
+  long rows = (V + 16383) / 16384;  // >= 64 elements per thread
+  if (rows > WSR_CHAN_SUM_ROWS) rows = WSR_CHAN_SUM_ROWS;
+  if (rows < 1) rows = 1;
+  hipLaunchKernelGGL(plane_sum_kernel, dim3((unsigned)C, (unsigned)rows), dim3(256), 0, as_stream(stream), src, B, C,
+                     (long)V, partials);
+  WSR_LAUNCH_CHECK();
+  hipLaunchKernelGGL(chan_sum_final_kernel, dim3(1), dim3(1024), 0, as_stream(stream), partials, (int)rows, C, 1.f, out);
   WSR_LAUNCH_CHECK();
   return 0;
 }

@@ -750,7 +750,7 @@ class GeneratorProgram(ProgramBase):
             ops.planar_to_ndhwc(g_out, g3, 0, co_p)
             self.wgrad(self.hr1, h, 0, g3, 0, flat, sp, scratch)
             self.dgrad(self.hr1, g3, 0, gh, 0, (sX, sY, nz), mask=hr0_mask)
-        sp.view(flat, self.hr1.bias).copy_(g_out.sum(dim=(0, 2, 3, 4)))
+        ops.plane_sum(g_out, sp.view(flat, self.hr1.bias))
         ready(self.hr1.weight, self.hr1.bias)
         del g3
         # ---- hr0 (k5 + LReLU + Dropout3d mask: already applied to gh above)

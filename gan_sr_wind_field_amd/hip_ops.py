@@ -343,6 +343,21 @@ def chan_sum(x: Tensor, x_off: int, C_: int, out: Tensor, scale: float = 1.0) ->
     return True
 
 
+def plane_sum(src: Tensor, out: Tensor) -> Tensor:
+    """``out[c] = sum_{b, voxels} src[b, c]`` for a planar fp32 (B, C, ...) tensor (fp32, overwritten)"""
+    _need_cuda(src, out)
+    if src.dtype != torch.float32 or not src.is_contiguous() or out.dtype != torch.float32 or not out.is_contiguous():
+        raise ValueError("plane_sum wants contiguous fp32 tensors")
+    B, C_ = src.shape[:2]
+    if out.numel() != C_:
+        raise ValueError("plane_sum: one output element per channel")
+    ws = _chan_sum_ws.get(src.device)
+    if ws is None or ws.numel() < CHAN_SUM_ROWS * C_:
+        ws = _chan_sum_ws[src.device] = torch.empty(CHAN_SUM_ROWS * max(C_, 256), dtype=torch.float32, device=src.device)
+    check(_lib.lib().wsr_plane_sum(_p(src), B, C_, src[0, 0].numel(), _p(out), _p(ws), _stream()), "plane_sum")
+    return out
+
+
 def upsample2_bwd(dy: Tensor, dx: Tensor) -> Tensor:
     B, X, Y, Z, C_ = dx.shape
     check(_lib.lib().wsr_upsample2_bwd(_p(dy), _p(dx), B, X, Y, Z, C_, dtype_id(dx.dtype), _stream()),

@@ -222,6 +222,11 @@ int wsr_wind_gradient(const float* f, const float* xs, const float* ys, const fl
 int wsr_wind_gradient_bwd(const float* g, const float* xs, const float* ys, const float* zc, float* df, int32_t B,
                           int32_t X, int32_t Y, int32_t Z, void* stream);
 
+/* out[c] = sum over b, v of src[b][c][v] for a planar fp32 (B, C, V) tensor - the bias gradient of a conv whose
+ * output gradient arrives planar (hr_convs.2, Generator_3D_Resnet_ESRGAN.py:105-110; aten: sum.dim_IntList).
+ * Two passes through `partials` (WSR_CHAN_SUM_ROWS * C floats), no atomics.                                  */
+int wsr_plane_sum(const float* src, int32_t B, int32_t C, int64_t V, float* out, float* partials, void* stream);
+
 /* Fused content losses of the generator (reference GAN_models/wind_field_GAN_3D.py:377-432: pixel L1 / L2,
  * xy-gradient, z-gradient, divergence and xy-divergence MSE terms over the Jacobians of
  * calculate_gradient_of_wind_field, normalised by get_norm_factors_of_gradients :773-814).  Every normaliser is

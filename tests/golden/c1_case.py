@@ -52,6 +52,7 @@ def c1_oracle_step(dtype=torch.float32, emulate_bf16: bool = False):
            "gG": {k: v.grad.detach().clone() for k, v in sdG.items()}}
     with torch.no_grad():  # the SR field the D-iteration will see (G after its Adam step, eval mode)
         out["sr_d"] = onets.generator_forward(sdG, LR, Z, gs, training=False)
+    out["sdG_after"] = {k: v.detach().clone() for k, v in sdG.items()}
     assert ref.optimize_parameters(LR, HR, Z, 1) == "D"
     out["D_loss"] = float(ref.D_loss)
     out["gD"] = {k: v.grad.detach().clone() for k, v in sdD.items() if v.is_floating_point() and v.grad is not None}
