@@ -28,6 +28,8 @@ struct WgradArgs {
   int M;        // B*Xo*Yo*Zo
   int mchunk;   // voxels per workgroup (multiple of KB)
   int ntiles, ctiles;
+  long part_stride;  // > 0: wave w of voxel range mc STORES its sums at dw + (4*mc + w)*part_stride (no atomics)
+  int mchunks;       // voxel ranges (host side)
 };
 
 template <class T> struct WgCfg;
@@ -189,6 +191,8 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
   }
 
   // acc[i][j][reg]: n = n0 + i*16 + 4*fg + reg ; c = c0 + j*16 + fr
+  float* const dwp = a.dw + (long)(4 * mc + wave) * a.part_stride;
+  const bool store = a.part_stride > 0;
 #pragma unroll
   for (int i = 0; i < TN; ++i)
 #pragma unroll
@@ -198,13 +202,18 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int n = n0 + i * 16 + 4 * fg + r;
-        if (n < a.Cout) atomicAdd(a.dw + ((long)n * taps + tap) * a.Cin + c, acc[i][j][r]);
+        if (n < a.Cout) {
+          float* q = dwp + ((long)n * taps + tap) * a.Cin + c;
+          if (store) *q = acc[i][j][r];
+          else atomicAdd(q, acc[i][j][r]);
+        }
       }
     }
 }
 
+// plan != nullptr: report the number of partial copies (4 per voxel range: one per wave) and do not launch
 template <class T, int TN, int TC>
-int launch_wgrad(WgradArgs& a, hipStream_t st) {
+int launch_wgrad(WgradArgs& a, hipStream_t st, int* plan, int n_parts) {
   constexpr int KB = WgCfg<T>::KB;
   constexpr int ESZ = sizeof(typename T::elem);
   constexpr int BN = TN * 16, BC = TC * 16;
@@ -219,6 +228,8 @@ int launch_wgrad(WgradArgs& a, hipStream_t st) {
   if (mchunk < 4 * KB) mchunk = 4 * KB;
   a.mchunk = (int)mchunk;
   const long mchunks = (a.M + mchunk - 1) / mchunk;
+  if (plan) { *plan = (int)(4 * mchunks); return 0; }
+  if (a.part_stride > 0 && n_parts != 4 * mchunks) return WSR_EINVAL;
   const size_t lds = (size_t)KB * ((BN + BC) * ESZ + 32);
   dim3 grid((unsigned)(tiles * mchunks)), block(256);
   hipLaunchKernelGGL((wgrad_kernel<T, TN, TC>), grid, block, lds, st, a);
@@ -227,30 +238,26 @@ int launch_wgrad(WgradArgs& a, hipStream_t st) {
 }
 
 template <class T>
-int dispatch_wgrad(WgradArgs& a, hipStream_t st) {
-  if (a.Cout % 48 == 0 && a.Cin % 48 == 0 && a.Cin % 64 != 0) return launch_wgrad<T, 3, 3>(a, st);  // 144 x 144
-  if (a.Cout <= 16) return a.Cin <= 16 ? launch_wgrad<T, 1, 1>(a, st) : launch_wgrad<T, 1, 4>(a, st);
-  if (a.Cin <= 16) return launch_wgrad<T, 2, 1>(a, st);
-  if (a.Cin <= 32) return launch_wgrad<T, 2, 2>(a, st);
-  return launch_wgrad<T, 2, 4>(a, st);
+int dispatch_wgrad(WgradArgs& a, hipStream_t st, int* plan, int n_parts) {
+  if (a.Cout % 48 == 0 && a.Cin % 48 == 0 && a.Cin % 64 != 0) return launch_wgrad<T, 3, 3>(a, st, plan, n_parts);  // 144 x 144
+  if (a.Cout <= 16)
+    return a.Cin <= 16 ? launch_wgrad<T, 1, 1>(a, st, plan, n_parts) : launch_wgrad<T, 1, 4>(a, st, plan, n_parts);
+  if (a.Cin <= 16) return launch_wgrad<T, 2, 1>(a, st, plan, n_parts);
+  if (a.Cin <= 32) return launch_wgrad<T, 2, 2>(a, st, plan, n_parts);
+  return launch_wgrad<T, 2, 4>(a, st, plan, n_parts);
 }
 
 }  // namespace
 
 int wsr_wgrad_tile_bf16(const wsr_conv_t* c, const void* x, const void* dy, float* dw, int tri_base, int tri_step,
-                        void* stream);  // conv_wgrad_tile.hip
+                        long part_stride, int n_parts, int* plan, void* stream);  // conv_wgrad_tile.hip
 
-extern "C" int wsr_conv3d_wgrad_tri(const wsr_conv_t* c, const void* x, const void* dy, float* dw, int32_t tri_base,
-                                    int32_t tri_step, void* stream) {
-  if (!conv_geom_ok(c) || !x || !dy || !dw || tri_base <= 0 || tri_step <= 0) return WSR_EINVAL;
-  return wsr_wgrad_tile_bf16(c, x, dy, dw, tri_base, tri_step, stream);
-}
-
-extern "C" int wsr_conv3d_wgrad(const wsr_conv_t* c, const void* x, const void* dy, float* dw, void* stream) {
-  if (!conv_geom_ok(c) || !x || !dy || !dw) return WSR_EINVAL;
-  {  // stride-1 bf16 convs with more than one tap: LDS-tile kernel (x / dy read once per tile, not per tap)
-    const int rc = wsr_wgrad_tile_bf16(c, x, dy, dw, 0, 0, stream);
-    if (rc != WSR_EUNSUPPORTED) return rc;
+// shared body: accumulate (part_stride = 0), deterministic parts (part_stride > 0) or plan only (plan != nullptr)
+static int wgrad_any(const wsr_conv_t* c, const void* x, const void* dy, float* dw, int tri_base, int tri_step,
+                     long part_stride, int n_parts, int* plan, void* stream) {
+  {  // stride-1 bf16 convs: LDS-tile kernel (x / dy read once per tile, not per tap)
+    const int rc = wsr_wgrad_tile_bf16(c, x, dy, dw, tri_base, tri_step, part_stride, n_parts, plan, stream);
+    if (rc != WSR_EUNSUPPORTED || tri_step > 0) return rc;
   }
   const int epp = c->dtype == WSR_BF16 ? 8 : 4;
   if (c->Cin % epp || c->in_ctot % epp || c->in_off % epp) return WSR_EUNSUPPORTED;
@@ -269,5 +276,34 @@ extern "C" int wsr_conv3d_wgrad(const wsr_conv_t* c, const void* x, const void* 
   a.px = c->px; a.py = c->py; a.pz = c->pz;
   a.ups = c->upsample_xy ? 1 : 0;
   a.M = c->B * c->Xo * c->Yo * c->Zo;
-  return c->dtype == WSR_BF16 ? dispatch_wgrad<BF16>(a, as_stream(stream)) : dispatch_wgrad<F32>(a, as_stream(stream));
+  a.part_stride = part_stride;
+  return c->dtype == WSR_BF16 ? dispatch_wgrad<BF16>(a, as_stream(stream), plan, n_parts)
+                              : dispatch_wgrad<F32>(a, as_stream(stream), plan, n_parts);
+}
+
+extern "C" int wsr_conv3d_wgrad_tri(const wsr_conv_t* c, const void* x, const void* dy, float* dw, int32_t tri_base,
+                                    int32_t tri_step, void* stream) {
+  if (!conv_geom_ok(c) || !x || !dy || !dw || tri_base <= 0 || tri_step <= 0) return WSR_EINVAL;
+  return wgrad_any(c, x, dy, dw, tri_base, tri_step, 0, 0, nullptr, stream);
+}
+
+extern "C" int wsr_conv3d_wgrad(const wsr_conv_t* c, const void* x, const void* dy, float* dw, void* stream) {
+  if (!conv_geom_ok(c) || !x || !dy || !dw) return WSR_EINVAL;
+  return wgrad_any(c, x, dy, dw, 0, 0, 0, 0, nullptr, stream);
+}
+
+extern "C" int wsr_conv3d_wgrad_nparts(const wsr_conv_t* c, int32_t tri_base, int32_t tri_step, int32_t* n_parts) {
+  if (!conv_geom_ok(c) || !n_parts || tri_base < 0 || tri_step < 0) return WSR_EINVAL;
+  int plan = 0;
+  const int rc = wgrad_any(c, nullptr, nullptr, nullptr, tri_base, tri_step, 0, 0, &plan, nullptr);
+  *n_parts = plan;
+  return rc;
+}
+
+extern "C" int wsr_conv3d_wgrad_parts(const wsr_conv_t* c, const void* x, const void* dy, float* parts,
+                                      int64_t part_stride, int32_t n_parts, int32_t tri_base, int32_t tri_step,
+                                      void* stream) {
+  if (!conv_geom_ok(c) || !x || !dy || !parts || tri_base < 0 || tri_step < 0 || n_parts <= 0) return WSR_EINVAL;
+  if (part_stride < (int64_t)c->Cout * c->KX * c->KY * c->KZ * c->Cin) return WSR_EINVAL;
+  return wgrad_any(c, x, dy, parts, tri_base, tri_step, (long)part_stride, n_parts, nullptr, stream);
 }

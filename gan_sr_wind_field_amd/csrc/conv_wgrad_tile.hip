@@ -57,6 +57,10 @@ struct WgtArgs {
   int tri_base, tri_step;
   int n_active;                 // > 0: only these (n-chunk, c-chunk) pairs have work (block-triangular launches)
   unsigned char act_nc[64], act_cc[64];
+  long part_stride;             // > 0: spatial split s STORES its sums at dw + s*part_stride (no atomics, see
+                                // wsr_conv3d_wgrad_parts); 0: every split adds into dw with float atomics
+  int S_forced;                 // > 0: the number of spatial splits the caller was told (wsr_conv3d_wgrad_nparts)
+  int plan_only;                // host side: compute the launch geometry (S) and return without launching
   unsigned long long* stamps;  // -DWSR_CT_STAMPS builds: [workgroup][8] clock samples (else unused)
   int ablate;                  // -DWSR_CT_STAMPS builds, timing only: skip 1 = tile DMA, 4 = LDS reads, 8 = MFMAs
 };
@@ -432,7 +436,10 @@ __global__ __launch_bounds__(512) void wgrad_tile_kernel(const WgtArgs a) {
   }
   WG_STAMP(2);
 
-  // ---- add this workgroup's partial sums: acc[j][i][r] -> n = n0+16i+4G+r, c = c0+16ct+(lane&15)
+  // ---- this workgroup's partial sums: acc[j][i][r] -> n = n0+16i+4G+r, c = c0+16ct+(lane&15); stored to the
+  // split's own copy (deterministic two-pass form) or added to the shared one
+  float* const dwp = a.dw + (long)s0 * a.part_stride;
+  const bool store = a.part_stride > 0;
 #pragma unroll
   for (int j = 0; j < SPW; ++j) {
     const int sj = wave + WAVES * j;
@@ -446,7 +453,11 @@ __global__ __launch_bounds__(512) void wgrad_tile_kernel(const WgtArgs a) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int n = n0 + 16 * i + 4 * G + r;
-        if (n < a.Cout) atomicAdd(a.dw + ((long)n * taps + tap) * a.Cin + c, acc[j][i][r]);
+        if (n < a.Cout) {
+          float* q = dwp + ((long)n * taps + tap) * a.Cin + c;
+          if (store) *q = acc[j][i][r];
+          else atomicAdd(q, acc[j][i][r]);
+        }
       }
     }
   }
@@ -531,7 +542,7 @@ int launch_tile(WgtArgs& a, hipStream_t st) {
           ++a.n_active;
         }
       }
-    if (a.n_active == 0) return 0;
+    if (a.n_active == 0) { a.S = 0; return 0; }
     combos = a.n_active;
   }
   // Spatial split S: ONE round of workgroups (one is resident per CU: 148 KB of LDS).  Measured on the
@@ -546,6 +557,8 @@ int launch_tile(WgtArgs& a, hipStream_t st) {
     const int v = atoi(ov);
     if (v >= 1 && v <= a.ntiles) a.S = v;
   }
+  if (a.plan_only) return 0;
+  if (a.part_stride > 0 && a.S_forced != a.S) return WSR_EINVAL;  // the caller sized `parts` for another split
   const bool z16 = a.TZ % 16 == 0;
   auto kern = z16 ? wgrad_tile_kernel<TN, SPW, CT, true> : wgrad_tile_kernel<TN, SPW, CT, false>;
   static bool attr_done[2] = {false, false};  // raise the dynamic-LDS cap once per instantiation
@@ -566,10 +579,16 @@ int launch_tile(WgtArgs& a, hipStream_t st) {
 
 }  // namespace
 
+namespace {
+int run_tile(WgtArgs& a, int taps, int Cout, int Cin, hipStream_t st);
+}
+
 // Returns WSR_EUNSUPPORTED when the shape is outside what the tile kernel covers;
 // wsr_conv3d_wgrad then falls back to the per-tap split-K kernel.
+// part_stride > 0: deterministic form with n_parts (as returned by a plan call) split copies; plan != nullptr: only
+// report the number of spatial splits (*plan) the launch would use.
 int wsr_wgrad_tile_bf16(const wsr_conv_t* c, const void* x, const void* dy, float* dw, int tri_base, int tri_step,
-                        void* stream) {
+                        long part_stride, int n_parts, int* plan, void* stream) {
   if (c->dtype != WSR_BF16 || (c->sx | c->sy | c->sz) != 1) return WSR_EUNSUPPORTED;
   const int taps = c->KX * c->KY * c->KZ;
   if (taps > 128) return WSR_EUNSUPPORTED;
@@ -589,7 +608,17 @@ int wsr_wgrad_tile_bf16(const wsr_conv_t* c, const void* x, const void* dy, floa
   a.px = c->px; a.py = c->py; a.pz = c->pz;
   a.ups = c->upsample_xy ? 1 : 0;
   a.tri_base = tri_base; a.tri_step = tri_step;
+  a.part_stride = part_stride; a.S_forced = n_parts; a.plan_only = plan ? 1 : 0;
   hipStream_t st = as_stream(stream);
+  const int rc = run_tile(a, taps, c->Cout, c->Cin, st);
+  if (plan && rc == 0) *plan = a.S;
+  return rc;
+}
+
+namespace {
+int run_tile(WgtArgs& a, int taps, int Cout, int Cin, hipStream_t st) {
+  struct { int Cout, Cin; } cc{Cout, Cin};
+  auto* c = &cc;
   if (taps == 1) {  // 1x1x1 (LFF): a plain GEMM over the voxels; 8 slots = 8 c-tiles (128 input channels per chunk)
     if (c->Cout < 64 || c->Cin < 64) return WSR_EUNSUPPORTED;  // tiny GEMMs stay on the per-tap kernel
     return launch_tile<8, 1, 8>(a, st);
@@ -604,3 +633,4 @@ int wsr_wgrad_tile_bf16(const wsr_conv_t* c, const void* x, const void* dy, floa
   if (c->Cout <= 32) return launch_tile<2, 7, 2>(a, st);
   return launch_tile<4, 7, 2>(a, st);
 }
+}  // namespace

@@ -66,6 +66,38 @@ __global__ void unpack_wgrad_multi_kernel(const wsr_unpack_job_t* __restrict__ j
   }
 }
 
+// Deterministic filter gradients: the sum over the n_parts split copies (fixed order) and the move to the master
+// layout in one pass.  One workgroup per (job, output channel n, 64 input channels): the packed rows
+// [tap][c0 .. c0+63] of every part are read coalesced, summed, transposed through LDS and written as the
+// contiguous run dst[n][c0 .. c0+63][taps].
+__global__ __launch_bounds__(256) void unpack_reduce_multi_kernel(const wsr_unpack_job_t* __restrict__ jobs) {
+  __shared__ float sh[64][129];  // [c][tap], taps <= 128
+  const wsr_unpack_job_t j = jobs[blockIdx.y];
+  const int cchunks = (j.Cin + 63) / 64;
+  const int cl = threadIdx.x & 63, tl = threadIdx.x >> 6;
+  const int nparts = j.n_parts > 0 ? j.n_parts : 1;
+  for (int item = blockIdx.x; item < j.Cout * cchunks; item += gridDim.x) {
+    const int n = item / cchunks, c0 = (item - n * cchunks) * 64;
+    const int cw = min(64, j.Cin - c0);
+    __syncthreads();
+    if (cl < cw) {
+      for (int tap = tl; tap < j.taps; tap += 4) {
+        const float* p = j.src + ((long)n * j.taps + tap) * j.kpad + c0 + cl;
+        float a = 0.f;
+        for (int s = 0; s < nparts; ++s) a += p[(long)s * j.part_stride];
+        sh[cl][tap] = a;
+      }
+    }
+    __syncthreads();
+    float* d = j.dst + ((long)n * j.Cin + c0) * j.taps;
+    for (int idx = threadIdx.x; idx < cw * j.taps; idx += 256) {
+      const int c = idx / j.taps, tap = idx - c * j.taps;
+      const float v = j.scale * sh[c][tap];
+      d[idx] = j.accumulate ? d[idx] + v : v;
+    }
+  }
+}
+
 // ---- channel-window elementwise ---------------------------------------------------
 template <class T>
 __global__ void lrelu_bwd_kernel(typename T::elem* g, int g_ctot, int g_off, const typename T::elem* y, int y_ctot,
@@ -609,6 +641,13 @@ extern "C" int wsr_unpack_wgrad(const float* src, float* dst, int32_t Cout, int3
 extern "C" int wsr_unpack_wgrad_multi(const wsr_unpack_job_t* jobs_dev, int32_t n_jobs, void* stream) {
   if (!jobs_dev || n_jobs <= 0 || n_jobs > 65535) return WSR_EINVAL;
   hipLaunchKernelGGL(unpack_wgrad_multi_kernel, dim3(32, (unsigned)n_jobs), dim3(256), 0, as_stream(stream), jobs_dev);
+  WSR_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int wsr_unpack_wgrad_reduce_multi(const wsr_unpack_job_t* jobs_dev, int32_t n_jobs, void* stream) {
+  if (!jobs_dev || n_jobs <= 0 || n_jobs > 65535) return WSR_EINVAL;
+  hipLaunchKernelGGL(unpack_reduce_multi_kernel, dim3(64, (unsigned)n_jobs), dim3(256), 0, as_stream(stream), jobs_dev);
   WSR_LAUNCH_CHECK();
   return 0;
 }

@@ -41,6 +41,10 @@ GD_INPLACE = __import__("os").environ.get("WSR_GD_INPLACE", "1") != "0"
 #: run the last conv of the generator in its z-folded form (WSR_ZFOLD=0: plain 5x5x5 conv with 3 outputs)
 ZFOLD = __import__("os").environ.get("WSR_ZFOLD", "1") != "0"
 POISON_BUFFERS = bool(int(__import__("os").environ.get("WSR_POISON_BUFFERS", "0")))
+#: filter gradients without float atomics: every spatial split of a wgrad launch stores its partial sums to its own
+#: copy and the unpack pass adds the copies in index order - two backward passes give bit-identical gradients
+#: (WSR_DETERMINISTIC=0: one shared copy, float atomics)
+DETERMINISTIC = __import__("os").environ.get("WSR_DETERMINISTIC", "1") != "0"
 
 
 def compute_dtype_of(flag) -> torch.dtype:
@@ -230,6 +234,7 @@ class ProgramBase:
         self._scratch_elems_total = 0
         self._stack_specs = None
         self._stack_fwd_specs = None
+        self._nparts: Dict[tuple, int] = {}
 
     def cp(self, c: int) -> int:
         """channel count padded to whole 16-byte pieces"""
@@ -337,13 +342,20 @@ class ProgramBase:
         B = x.shape[0]
         cin_p = self.cp(s.cin)
         d = self._desc(s, B, tuple(x.shape[1:4]), x.shape[-1], x_off, g.shape[-1], g_off, cin=cin_p)
-        dwp = self._arena_take(s.cout * s.taps * cin_p, x.device)
-        if self.launch_probe is not None:
-            self.launch_probe("wgrad:" + s.name, lambda: ops.conv_wgrad(d, x, g, dwp))
+        out = space.view(flat, s.weight) if dst is None else dst
+        if DETERMINISTIC:
+            n = self._wgrad_nparts(("w", s.name, B) + tuple(x.shape[1:4]), d)
+            parts = torch.empty((n, s.cout, s.taps, cin_p), dtype=torch.float32, device=x.device)
+            run = lambda: ops.conv_wgrad_parts(d, x, g, parts, n)  # noqa: E731
+            self._pending_unpack.append((parts[0], out, scale, n, parts[0].numel()))
         else:
-            ops.conv_wgrad(d, x, g, dwp)
-        self._pending_unpack.append((dwp.view(s.cout, s.taps, cin_p),
-                                     space.view(flat, s.weight) if dst is None else dst, scale))
+            dwp = self._arena_take(s.cout * s.taps * cin_p, x.device)
+            run = lambda: ops.conv_wgrad(d, x, g, dwp)  # noqa: E731
+            self._pending_unpack.append((dwp.view(s.cout, s.taps, cin_p), out, scale))
+        if self.launch_probe is not None:
+            self.launch_probe("wgrad:" + s.name, run)
+        else:
+            run()
 
     def wgrad_dense(self, convs: Sequence[ConvSite], buf: Tensor, gd: Tensor, flat: Tensor, space: GradSpace,
                     scratch: Tensor) -> None:
@@ -363,13 +375,22 @@ class ProgramBase:
         g = ConvGeom(cin_w, cout, convs[0].kernel, (1, 1, 1), convs[0].pad)
         d = ops.make_desc(g, self.dt, B, tuple(buf.shape[1:4]), buf.shape[-1], 0, gd.shape[-1], nf)
         taps = convs[0].taps
-        dw3 = self._arena_take(cout * taps * cin_w, buf.device).view(cout, taps, cin_w)
-        if self.launch_probe is not None:
-            self.launch_probe("wgrad_tri:" + convs[0].name, lambda: ops.conv_wgrad_tri(d, buf, gd, dw3, nf, gc))
+        if DETERMINISTIC:
+            n = self._wgrad_nparts(("tri", convs[0].name, B) + tuple(buf.shape[1:4]), d, nf, gc)
+            parts = torch.empty((n, cout, taps, cin_w), dtype=torch.float32, device=buf.device)
+            run = lambda: ops.conv_wgrad_parts(d, buf, gd, parts, n, nf, gc)  # noqa: E731
+            for i, c in enumerate(convs):
+                self._pending_unpack.append((parts[0, i * gc:(i + 1) * gc], space.view(flat, c.weight), 1.0, n,
+                                             parts[0].numel()))
         else:
-            ops.conv_wgrad_tri(d, buf, gd, dw3, nf, gc)
-        for i, c in enumerate(convs):
-            self._pending_unpack.append((dw3[i * gc:(i + 1) * gc], space.view(flat, c.weight), 1.0))
+            dw3 = self._arena_take(cout * taps * cin_w, buf.device).view(cout, taps, cin_w)
+            run = lambda: ops.conv_wgrad_tri(d, buf, gd, dw3, nf, gc)  # noqa: E731
+            for i, c in enumerate(convs):
+                self._pending_unpack.append((dw3[i * gc:(i + 1) * gc], space.view(flat, c.weight), 1.0))
+        if self.launch_probe is not None:
+            self.launch_probe("wgrad_tri:" + convs[0].name, run)
+        else:
+            run()
 
     # ---- stacked input gradient of a dense block ---------------------------------------------------
     # Conv i of a block reads channels [0, nf + i*gc) of the dense buffer, so per-conv input gradients
@@ -482,10 +503,19 @@ class ProgramBase:
     # backward pass is zeroed with a single fill, every conv takes a slice, and the slices are moved to
     # the master layout in batches (one launch per `flush_unpack`) instead of a fill + an unpack per conv.
     def begin_backward(self, dev) -> None:
+        self._pending_unpack = []
+        if DETERMINISTIC:  # split copies are written with plain stores: nothing to zero, no arena
+            self._arena = None
+            return
         n = int(self._scratch_elems_total * 1.3) + 4096
         self._arena = torch.zeros(n, dtype=torch.float32, device=dev)
         self._arena_off = 0
-        self._pending_unpack = []
+
+    def _wgrad_nparts(self, key, desc, tri_base: int = 0, tri_step: int = 0) -> int:
+        n = self._nparts.get(key)
+        if n is None:
+            n = self._nparts[key] = ops.conv_wgrad_nparts(desc, tri_base, tri_step)
+        return n
 
     def _arena_take(self, n: int, dev) -> Tensor:
         off = self._arena_off
@@ -501,14 +531,17 @@ class ProgramBase:
         self._pending_unpack = []
         # the arena and the flat gradient buffer usually come back at the same addresses every step
         # (caching allocator), so the device job table is re-used when all pointers match
-        key = tuple(j[0].data_ptr() for j in jobs) + tuple(j[1].data_ptr() for j in jobs) + tuple(j[2] for j in jobs)
+        key = tuple(j[0].data_ptr() for j in jobs) + tuple(j[1].data_ptr() for j in jobs) + tuple(j[2:] for j in jobs)
         table = self._unpack_tables.get(key)
         if table is None:
             if len(self._unpack_tables) > 64:
                 self._unpack_tables.clear()
             table = ops.unpack_job_table(jobs)
             self._unpack_tables[key] = table
-        ops.unpack_wgrad_multi(table)
+        if len(jobs[0]) > 3:
+            ops.unpack_wgrad_reduce_multi(table)  # ordered sum over the split copies + move to the master layout
+        else:
+            ops.unpack_wgrad_multi(table)
 
     def end_backward(self) -> None:
         self.flush_unpack()

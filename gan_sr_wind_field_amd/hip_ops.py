@@ -260,6 +260,25 @@ def conv_wgrad_tri(desc: ConvDesc, x: Tensor, dy: Tensor, dw: Tensor, tri_base: 
     return dw
 
 
+def conv_wgrad_nparts(desc: ConvDesc, tri_base: int = 0, tri_step: int = 0) -> int:
+    """split copies the deterministic filter-gradient launch of this geometry writes (host-side query)"""
+    n = C.c_int32(0)
+    check(_lib.lib().wsr_conv3d_wgrad_nparts(C.byref(desc), tri_base, tri_step, C.byref(n)), "conv3d_wgrad_nparts")
+    return int(n.value)
+
+
+def conv_wgrad_parts(desc: ConvDesc, x: Tensor, dy: Tensor, parts: Tensor, n_parts: int, tri_base: int = 0,
+                     tri_step: int = 0) -> Tensor:
+    """Deterministic filter gradient: ``parts`` (n_parts, Cout, taps, Cin) fp32 receives one partial sum per split
+    (plain stores, nothing to zero); :func:`unpack_wgrad_reduce_multi` adds them in order."""
+    _need_cuda(x, dy, parts)
+    if parts.dtype != torch.float32 or not parts.is_contiguous() or parts.shape[0] != n_parts:
+        raise ValueError("conv_wgrad_parts wants a contiguous fp32 (n_parts, Cout, taps, Cin) buffer")
+    check(_lib.lib().wsr_conv3d_wgrad_parts(C.byref(desc), _p(x), _p(dy), _p(parts), parts[0].numel(), n_parts, tri_base,
+                                            tri_step, _stream()), "conv3d_wgrad_parts")
+    return parts
+
+
 def pack_filter(w: Tensor, dt: torch.dtype, *, transpose: bool = False, kpad: Optional[int] = None,
                 out: Optional[Tensor] = None) -> Tensor:
     """fp32 master ``(Cout, Cin, KX, KY, KZ)`` -> compute copy ``[rows][taps][kpad]`` of ``dt``."""
@@ -289,21 +308,30 @@ def unpack_wgrad(src: Tensor, dst: Tensor, scale: float = 1.0, accumulate: bool 
 
 def unpack_job_table(jobs) -> Tensor:
     """Device table of ``wsr_unpack_job_t`` records for ``jobs`` = [(packed src [Cout][taps][kpad] fp32,
-    master-layout dst fp32, scale)]."""
+    master-layout dst fp32, scale[, n_parts, part_stride])] - the last two for the deterministic split copies."""
     import numpy as np
 
-    rec = np.zeros((len(jobs), 5), dtype=np.int64)  # 2 pointers + 4 int32 + float + int32
-    for r, (src, dst, scale) in zip(rec, jobs):
+    rec = np.zeros((len(jobs), 7), dtype=np.int64)  # 2 pointers + 4 int32 + float + int32 + 2 int32 + int64
+    for r, job in zip(rec, jobs):
+        src, dst, scale = job[:3]
+        n_parts, part_stride = job[3:5] if len(job) > 3 else (0, 0)
         cout, taps, kpad = src.shape
         r[0], r[1] = src.data_ptr(), dst.data_ptr()
         r[2] = cout | (taps << 32)
         r[3] = dst.shape[1] | (kpad << 32)
         r[4] = int(np.float32(scale).view(np.int32)) & 0xFFFFFFFF  # accumulate = 0
+        r[5] = n_parts
+        r[6] = part_stride
     return torch.from_numpy(rec).to(jobs[0][0].device)
 
 
 def unpack_wgrad_multi(table: Tensor) -> None:
     check(_lib.lib().wsr_unpack_wgrad_multi(_p(table), table.shape[0], _stream()), "unpack_wgrad_multi")
+
+
+def unpack_wgrad_reduce_multi(table: Tensor) -> None:
+    """jobs with split copies (``(src, dst, scale, n_parts, part_stride)`` records): ordered sum + unpack"""
+    check(_lib.lib().wsr_unpack_wgrad_reduce_multi(_p(table), table.shape[0], _stream()), "unpack_wgrad_reduce_multi")
 
 
 def lrelu_bwd_(g: Tensor, g_off: int, y: Tensor, y_off: int, C_: int, slope: float,

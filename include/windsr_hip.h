@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define WSR_ABI_VERSION 1
+#define WSR_ABI_VERSION 2
 
 enum wsr_dtype { WSR_F32 = 0, WSR_BF16 = 1 };
 
@@ -147,6 +147,16 @@ int wsr_pack_filter_frag_multi(const wsr_pack_job_t* jobs_dev, int32_t n_jobs, v
  * order) is ACCUMULATED into (caller zeroes it when a fresh gradient is wanted;
  * wsr_unpack_wgrad moves it to the master layout).                             */
 int wsr_conv3d_wgrad(const wsr_conv_t* c, const void* x, const void* dy, float* dw, void* stream);
+/* Deterministic (atomic-free, bit-reproducible) form of the same gradient.  The kernels split the reduction
+ * over the voxels between workgroups / waves; wsr_conv3d_wgrad adds the partial sums into one buffer with float
+ * atomics (order varies from launch to launch), here split s STORES its sums to parts + s*part_stride (each a
+ * packed [Cout][taps][Cin] image; nothing has to be zeroed) and wsr_unpack_wgrad_reduce_multi adds the copies
+ * in index order while moving them to the master layout.  n_parts must be the value wsr_conv3d_wgrad_nparts
+ * reports for the same geometry (host-side query, no launch); tri_base / tri_step > 0: the stacked dense-block
+ * form of wsr_conv3d_wgrad_tri.                                                                             */
+int wsr_conv3d_wgrad_nparts(const wsr_conv_t* c, int32_t tri_base, int32_t tri_step, int32_t* n_parts);
+int wsr_conv3d_wgrad_parts(const wsr_conv_t* c, const void* x, const void* dy, float* parts, int64_t part_stride,
+                           int32_t n_parts, int32_t tri_base, int32_t tri_step, void* stream);
 /* Filter gradients of ALL growth convs of a residual dense block in one launch
  * (torch_blocks.py:256-267: conv i reads channels [0, tri_base + i*tri_step) of the
  * dense buffer and writes tri_step channels).  c describes the stacked conv: Cin =
@@ -178,8 +188,13 @@ typedef struct wsr_unpack_job {
   int32_t Cout, taps, Cin, kpad;
   float scale;
   int32_t accumulate;
+  int32_t n_parts;     /* wsr_unpack_wgrad_reduce_multi: split copies to sum (src + s*part_stride), else unused */
+  int32_t reserved;
+  int64_t part_stride; /* elements between two copies */
 } wsr_unpack_job_t;
 int wsr_unpack_wgrad_multi(const wsr_unpack_job_t* jobs_dev, int32_t n_jobs, void* stream);
+/* The same with the ordered sum over the split copies of wsr_conv3d_wgrad_parts folded in (taps <= 128). */
+int wsr_unpack_wgrad_reduce_multi(const wsr_unpack_job_t* jobs_dev, int32_t n_jobs, void* stream);
 
 /* ---- elementwise / normalisation ---------------------------------------------
  * leaky_relu_backward from the saved OUTPUT sign, in place on a channel window

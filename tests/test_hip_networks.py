@@ -481,10 +481,16 @@ def test_full_size_c3_generator_properties(hip, monkeypatch):
     monkeypatch.setattr(engine, "STACK_FWD", True)
     monkeypatch.setattr(engine, "ZFOLD", True)
     G.train()
+    torch.manual_seed(321)
     G(LR, Z).square().mean().backward()
     g1 = {k: p.grad.clone() for k, p in G.named_parameters()}
     assert all(torch.isfinite(v).all() for v in g1.values())
     assert all(float(v.abs().sum()) > 0 for v in g1.values())
+    # bit-reproducible backward at the benchmark's size (no float atomics anywhere on the path)
+    G.zero_grad()
+    torch.manual_seed(321)
+    G(LR, Z).square().mean().backward()
+    assert all(torch.equal(p.grad, g1[k]) for k, p in G.named_parameters())
     # the stacked / in-place backward forms against one launch per conv, same dropout mask (seeded)
     for flag in ("STACK_DGRAD", "GD_INPLACE", "ZFOLD"):
         monkeypatch.setattr(engine, flag, False)
@@ -500,6 +506,42 @@ def test_full_size_c3_generator_properties(hip, monkeypatch):
     G(LR, Z).square().mean().backward()
     worst = max(rel_l2(p.grad, g_ref[k]) for k, p in G.named_parameters())
     assert worst < 6e-2, worst
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_backward_is_bit_reproducible(hip, dtype):
+    """Filter gradients without float atomics (engine.DETERMINISTIC: split copies + ordered sum), two-pass
+    BatchNorm / bias reductions: two backward passes over the same inputs give bit-identical gradients, for the
+    generator (stacked dense-block launches, z-folded last conv) and the discriminator (strided convs, train-mode
+    BatchNorm), on the tile kernels (bf16) and the generic ones (fp32)."""
+    from gan_sr_wind_field_amd import engine
+
+    assert engine.DETERMINISTIC
+    spec = onets.GSpec(upscale=4, in_channels=4, out_channels=3, nf=32, n_rrdb=1, hr_kern=5, gc=16, tf=8)
+    G, _ = build_G(spec, dtype, 3)
+    G.train()
+    LR, HR, Z, x, y = ogan.synthetic_batch(2, 8, 16, 4, seed=13)
+    LR, Z = LR.to(DEV), Z.to(DEV)
+    runs = []
+    for _ in range(2):
+        G.zero_grad(set_to_none=True)
+        torch.manual_seed(5)  # same Dropout3d mask
+        G(LR, Z).square().mean().backward()
+        runs.append({k: p.grad.clone() for k, p in G.named_parameters()})
+    for k in runs[0]:
+        assert torch.equal(runs[0][k], runs[1][k]), k
+    ds = onets.DSpec(bf=8, nz=16, enable_slicing=True)
+    D, _ = build_D(ds, dtype, 4)
+    D.train()
+    xin = (torch.rand((2, 3, 64, 64, 16), generator=torch.Generator().manual_seed(1)) * 2 - 1).to(DEV)
+    runs = []
+    for _ in range(2):
+        D.zero_grad(set_to_none=True)
+        xg = xin.clone().requires_grad_(True)
+        D(xg).sum().backward()
+        runs.append(dict({k: p.grad.clone() for k, p in D.named_parameters()}, x=xg.grad.clone()))
+    for k in runs[0]:
+        assert torch.equal(runs[0][k], runs[1][k]), k
 
 
 def test_full_size_c3_discriminator_properties(hip, monkeypatch):
