@@ -74,19 +74,32 @@ __global__ __launch_bounds__(256) void unpack_reduce_multi_kernel(const wsr_unpa
   __shared__ float sh[64][129];  // [c][tap], taps <= 128
   const wsr_unpack_job_t j = jobs[blockIdx.y];
   const int cchunks = (j.Cin + 63) / 64;
-  const int cl = threadIdx.x & 63, tl = threadIdx.x >> 6;
+  const int c4 = (threadIdx.x & 15) * 4, tl = threadIdx.x >> 4;  // 16 lanes x float4 = 64 channels, 16 taps at a time
   const int nparts = j.n_parts > 0 ? j.n_parts : 1;
+  const bool vec = (j.kpad & 3) == 0 && (j.part_stride & 3) == 0 && (((size_t)j.src) & 15) == 0;
   for (int item = blockIdx.x; item < j.Cout * cchunks; item += gridDim.x) {
     const int n = item / cchunks, c0 = (item - n * cchunks) * 64;
     const int cw = min(64, j.Cin - c0);
     __syncthreads();
-    if (cl < cw) {
-      for (int tap = tl; tap < j.taps; tap += 4) {
-        const float* p = j.src + ((long)n * j.taps + tap) * j.kpad + c0 + cl;
-        float a = 0.f;
-        for (int s = 0; s < nparts; ++s) a += p[(long)s * j.part_stride];
-        sh[cl][tap] = a;
+    for (int tap = tl; tap < j.taps; tap += 16) {
+      const float* p = j.src + ((long)n * j.taps + tap) * j.kpad + c0 + c4;
+      float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (vec && c0 + c4 + 4 <= j.kpad) {  // (the row is kpad long: reading past Cin inside it is harmless)
+#pragma unroll 4
+        for (int s = 0; s < nparts; ++s) {
+          const float4 v = *reinterpret_cast<const float4*>(p + (long)s * j.part_stride);
+          a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+        }
+      } else {
+        for (int s = 0; s < nparts; ++s) {
+          const float* q = p + (long)s * j.part_stride;
+          if (c4 + 0 < cw) a.x += q[0];
+          if (c4 + 1 < cw) a.y += q[1];
+          if (c4 + 2 < cw) a.z += q[2];
+          if (c4 + 3 < cw) a.w += q[3];
+        }
       }
+      sh[c4 + 0][tap] = a.x; sh[c4 + 1][tap] = a.y; sh[c4 + 2][tap] = a.z; sh[c4 + 3][tap] = a.w;
     }
     __syncthreads();
     float* d = j.dst + ((long)n * j.Cin + c0) * j.taps;
@@ -647,7 +660,7 @@ extern "C" int wsr_unpack_wgrad_multi(const wsr_unpack_job_t* jobs_dev, int32_t 
 
 extern "C" int wsr_unpack_wgrad_reduce_multi(const wsr_unpack_job_t* jobs_dev, int32_t n_jobs, void* stream) {
   if (!jobs_dev || n_jobs <= 0 || n_jobs > 65535) return WSR_EINVAL;
-  hipLaunchKernelGGL(unpack_reduce_multi_kernel, dim3(64, (unsigned)n_jobs), dim3(256), 0, as_stream(stream), jobs_dev);
+  hipLaunchKernelGGL(unpack_reduce_multi_kernel, dim3(128, (unsigned)n_jobs), dim3(256), 0, as_stream(stream), jobs_dev);
   WSR_LAUNCH_CHECK();
   return 0;
 }
