@@ -229,6 +229,8 @@ class ProgramBase:
         self.use_tile = True
         self._arena: Optional[Tensor] = None
         self._arena_off = 0
+        self._arena_need = 0
+        self._arena_dev = None
         self._pending_unpack: list = []
         self._unpack_tables: Dict[tuple, Tensor] = {}
         self._scratch_elems_total = 0
@@ -345,7 +347,7 @@ class ProgramBase:
         out = space.view(flat, s.weight) if dst is None else dst
         if DETERMINISTIC:
             n = self._wgrad_nparts(("w", s.name, B) + tuple(x.shape[1:4]), d)
-            parts = torch.empty((n, s.cout, s.taps, cin_p), dtype=torch.float32, device=x.device)
+            parts = self._arena_take(n * s.cout * s.taps * cin_p, x.device).view(n, s.cout, s.taps, cin_p)
             run = lambda: ops.conv_wgrad_parts(d, x, g, parts, n)  # noqa: E731
             self._pending_unpack.append((parts[0], out, scale, n, parts[0].numel()))
         else:
@@ -377,7 +379,7 @@ class ProgramBase:
         taps = convs[0].taps
         if DETERMINISTIC:
             n = self._wgrad_nparts(("tri", convs[0].name, B) + tuple(buf.shape[1:4]), d, nf, gc)
-            parts = torch.empty((n, cout, taps, cin_w), dtype=torch.float32, device=buf.device)
+            parts = self._arena_take(n * cout * taps * cin_w, buf.device).view(n, cout, taps, cin_w)
             run = lambda: ops.conv_wgrad_parts(d, buf, gd, parts, n, nf, gc)  # noqa: E731
             for i, c in enumerate(convs):
                 self._pending_unpack.append((parts[0, i * gc:(i + 1) * gc], space.view(flat, c.weight), 1.0, n,
@@ -504,12 +506,17 @@ class ProgramBase:
     # the master layout in batches (one launch per `flush_unpack`) instead of a fill + an unpack per conv.
     def begin_backward(self, dev) -> None:
         self._pending_unpack = []
-        if DETERMINISTIC:  # split copies are written with plain stores: nothing to zero, no arena
-            self._arena = None
+        self._arena_off = 0
+        self._arena_need = 0
+        self._arena_dev = dev
+        if DETERMINISTIC:
+            # split copies are written with plain stores: nothing to zero.  The arena is PERSISTENT (sized by the
+            # first backward pass of a shape): stable addresses keep the cached unpack job tables valid
+            if self._arena is not None and self._arena.device != torch.device(dev):
+                self._arena = None
             return
         n = int(self._scratch_elems_total * 1.3) + 4096
         self._arena = torch.zeros(n, dtype=torch.float32, device=dev)
-        self._arena_off = 0
 
     def _wgrad_nparts(self, key, desc, tri_base: int = 0, tri_step: int = 0) -> int:
         n = self._nparts.get(key)
@@ -519,8 +526,9 @@ class ProgramBase:
 
     def _arena_take(self, n: int, dev) -> Tensor:
         off = self._arena_off
+        self._arena_need += (n + 63) // 64 * 64
         if self._arena is None or off + n > self._arena.numel():
-            return torch.zeros(n, dtype=torch.float32, device=dev)
+            return (torch.empty if DETERMINISTIC else torch.zeros)(n, dtype=torch.float32, device=dev)
         self._arena_off = off + (n + 63) // 64 * 64
         return self._arena[off:off + n]
 
@@ -545,7 +553,12 @@ class ProgramBase:
 
     def end_backward(self) -> None:
         self.flush_unpack()
-        self._arena = None
+        if not DETERMINISTIC:
+            self._arena = None
+        elif self._arena is None or self._arena.numel() < self._arena_need:
+            dev = self._arena_dev
+            self._arena = None  # (release before growing)
+            self._arena = torch.empty(self._arena_need, dtype=torch.float32, device=dev)
 
     @staticmethod
     def wgrad_scratch_elems(sites: Sequence[ConvSite], e: int) -> int:

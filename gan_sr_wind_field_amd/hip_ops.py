@@ -225,7 +225,14 @@ def pack_job_table(jobs) -> Tensor:
             r[5] = c_lo | (c_n << 32)
             r[6] = red_off | (red_total << 32)
             r[7] = row_off | (rows_total << 32)
-    return torch.from_numpy(rec).to(jobs[0][0].device)
+    return _table_to_device(rec, jobs[0][0].device)
+
+
+def _table_to_device(rec, dev) -> Tensor:
+    """small host table -> device through pinned memory: a pageable copy would block the host until the stream has
+    drained (one pipeline bubble per rebuilt table)"""
+    t = torch.from_numpy(rec)
+    return t.pin_memory().to(dev, non_blocking=True) if torch.device(dev).type == "cuda" else t.to(dev)
 
 
 def pack_filter_frag_multi(table: Tensor) -> None:
@@ -322,7 +329,7 @@ def unpack_job_table(jobs) -> Tensor:
         r[4] = int(np.float32(scale).view(np.int32)) & 0xFFFFFFFF  # accumulate = 0
         r[5] = n_parts
         r[6] = part_stride
-    return torch.from_numpy(rec).to(jobs[0][0].device)
+    return _table_to_device(rec, jobs[0][0].device)
 
 
 def unpack_wgrad_multi(table: Tensor) -> None:
