@@ -64,6 +64,7 @@ struct CtArgs {
   int xbufs;        // activation buffers in LDS: 2 = next chunk prefetched during the MFMAs
   // ceil(2^32 / d) for the runtime divisors of the prologue (fdiv): tile / halo / tap extents, tile counts
   unsigned mg_TZ, mg_TY, mg_Lz, mg_Ly, mg_KZ, mg_KY, mg_ng, mg_tz, mg_ty, mg_tx;
+  int prio;    // 1: waves of the second half of the workgroup run the main loop at s_setprio 1 (tuning switch)
   int ablate;  // -DWSR_CT_STAMPS builds, timing only: skip 1 = activation prefetch, 2 = weight prefetch, 4 = LDS reads, 8 = MFMAs
   unsigned long long* stamps;  // -DWSR_CT_STAMPS builds: [workgroup][8] clock samples of wave 0 (else unused)
 };
@@ -282,6 +283,9 @@ void conv_tile_kernel(const CtArgs a) {
 #endif
   const int total_phases = a.nchunks * nstages;
   int chunk = 0, st = 0;
+  // static priority for the second-dispatched half (it loses the issue arbitration against the older half on
+  // every phase otherwise: MI355X_MICROARCH.md, two waves per SIMD, item 4)
+  if (a.prio && wave >= WAVES / 2) __builtin_amdgcn_s_setprio(1);
   for (int ph = 0; ph < total_phases; ++ph) {
     // ---- prefetch: next weight stage, and a slice of the next chunk's activations.  The burst costs each
     // wave several hundred issue cycles during which it feeds no MFMAs, so the two halves of the workgroup
@@ -584,6 +588,7 @@ int launch_ct(CtArgs& a, hipStream_t st) {
   a.ablate = getenv("WSR_CT_ABL") ? atoi(getenv("WSR_CT_ABL")) : 0;
   a.stamps = getenv("WSR_CT_STAMPS_PTR") ? (unsigned long long*)strtoull(getenv("WSR_CT_STAMPS_PTR"), nullptr, 0) : nullptr;
 #endif
+  a.prio = getenv("WSR_CT_PRIO") ? atoi(getenv("WSR_CT_PRIO")) : 1;  // measured: +1 % on the 144- and 128-wide tiles
   hipLaunchKernelGGL(kern, dim3((unsigned)(a.ntiles * a.ngroups)), dim3(WAVES * 64), lds, st, a);
   WSR_LAUNCH_CHECK();
   return 0;

@@ -59,6 +59,7 @@ struct WgtArgs {
   unsigned char act_nc[64], act_cc[64];
   long part_stride;             // > 0: spatial split s STORES its sums at dw + s*part_stride (no atomics, see
                                 // wsr_conv3d_wgrad_parts); 0: every split adds into dw with float atomics
+  int prio;                     // 1: waves 4..7 at s_setprio 1 in the tile loop (tuning switch)
   int S_forced;                 // > 0: the number of spatial splits the caller was told (wsr_conv3d_wgrad_nparts)
   int plan_only;                // host side: compute the launch geometry (S) and return without launching
   unsigned long long* stamps;  // -DWSR_CT_STAMPS builds: [workgroup][8] clock samples (else unused)
@@ -350,6 +351,7 @@ __global__ __launch_bounds__(512) void wgrad_tile_kernel(const WgtArgs a) {
     }
   };
 
+  if (a.prio && wave >= WAVES / 2) __builtin_amdgcn_s_setprio(1);
   // Software pipeline over the tile list: iteration `it` prefetches tile s0 + it*S into buffer it&1 while
   // tile s0 + (it-1)*S is contracted out of the other buffer (one DMA call site, one MFMA call site).
   for (int it = 0;; ++it) {
@@ -572,6 +574,7 @@ int launch_tile(WgtArgs& a, hipStream_t st) {
   a.stamps = getenv("WSR_CT_STAMPS_PTR") ? (unsigned long long*)strtoull(getenv("WSR_CT_STAMPS_PTR"), nullptr, 0) : nullptr;
   a.ablate = getenv("WSR_CT_ABL") ? atoi(getenv("WSR_CT_ABL")) : 0;
 #endif
+  a.prio = getenv("WSR_CT_PRIO") ? atoi(getenv("WSR_CT_PRIO")) : 0;
   hipLaunchKernelGGL(kern, dim3((unsigned)(combos * a.S)), dim3(WAVES * 64), lds, st, a);
   WSR_LAUNCH_CHECK();
   return 0;
