@@ -344,6 +344,57 @@ def gen_c1_full():
     save("c1_full_step.npz", **out)
 
 
+def gen_data():
+    """Dataset contract: the REFERENCE's process_data / download_data functions run on a small
+    synthetic HARMONIE-SIMRA-format dataset (written by the product's deterministic writer, seed 2001) in a
+    scratch directory: normalisation factors and the chronological split of ``preprosess``, ``reformat_to_torch``
+    for the channel-flag combinations, z-interpolation and its inverse, beta-distributed slice sampling and the
+    rot90 / flip augmentation with the u, v sign rules (``CustomizedDataset.__getitem__`` under seeded numpy RNG)."""
+    import tempfile
+    from datetime import date
+
+    import download_data as ref_dl
+    from gan_sr_wind_field_amd import process_data as pd_
+
+    XD, ZD = {"start": 0, "max": 32, "step": 1}, {"start": 0, "max": 6, "step": 1}
+    d0, d1 = date(2018, 3, 1), date(2018, 3, 2)
+    out = {}
+    cwd = os.getcwd()
+    with tempfile.TemporaryDirectory() as tmp:
+        os.chdir(tmp)
+        try:
+            os.makedirs("./data/downloaded_raw_bessaker_data", exist_ok=True)
+            pd_.write_synthetic_dataset(d0, d1, XD, XD, ZD, seed=2001)
+            for tag, kw in (("slice_aug", dict(include_pressure=False, include_z_channel=True, interpolate_z=False,
+                                                enable_slicing=True, slice_size=16, train_aug_rot=True,
+                                                train_aug_flip=True)),
+                            ("interp", dict(include_pressure=True, include_z_channel=True, interpolate_z=True,
+                                            include_above_ground_channel=True, enable_slicing=False))):
+                tr, te, va, x, y = ref_pd.preprosess(X_DICT=XD, Y_DICT=XD, Z_DICT=ZD, start_date=d0, end_date=d1,
+                                                     COARSENESS_FACTOR=4, **kw)
+                out[f"{tag}.n"] = np.array([len(tr), len(te), len(va)])
+                out[f"{tag}.first_names"] = np.array([tr.filenames[0], te.filenames[0], va.filenames[0]])
+                out[f"{tag}.norms"] = np.array([tr.Z_MIN, tr.Z_MAX, tr.Z_ABOVE_GROUND_MAX, tr.UVW_MAX, tr.P_MIN, tr.P_MAX])
+                out[f"{tag}.x"], out[f"{tag}.y"] = np_(x), np_(y)
+                np.random.seed(77)
+                for i in range(6 if tag == "slice_aug" else 2):  # 6 draws: every rotation count and flip state occurs
+                    LR, HR, Z = tr[i]
+                    out[f"{tag}.train{i}.LR"], out[f"{tag}.train{i}.HR"], out[f"{tag}.train{i}.Z"] = np_(LR), np_(HR), np_(Z)
+                item = te[0]
+                out[f"{tag}.test0.LR"], out[f"{tag}.test0.HR"], out[f"{tag}.test0.Z"] = (np_(t) for t in item[:3])
+                out[f"{tag}.test0.name"] = np.array(item[3])
+                if tag == "interp":
+                    out["interp.test0.HR_raw"], out["interp.test0.Z_raw"] = np_(item[4]), np_(item[5])
+                    # inverse of the z-interpolation applied to the interpolated HR field
+                    out["interp.test0.HR_back"] = np_(ref_dl.reverse_interpolate_z_axis(
+                        item[1].numpy()[None], item[5].numpy()[None], item[2].numpy()[None]))
+                LR, HR, Z = va[1]
+                out[f"{tag}.val1.LR"] = np_(LR)
+        finally:
+            os.chdir(cwd)
+    save("dataset_contract.npz", **out)
+
+
 def gen_init_manifest():
     """Seeded-init checksums of the full-size nets (RNG-order parity of init_weights)."""
     cfg = RefConfig(os.path.join(REF, "config", "wind_field_GAN_3D_config_local.ini"))
@@ -379,7 +430,7 @@ def gen_config_golden():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["conv", "blocks", "G", "D", "physics", "trace", "init", "config", "c1"]
+    which = sys.argv[1:] or ["conv", "blocks", "G", "D", "physics", "trace", "init", "config", "c1", "data"]
     if "config" in which:
         gen_config_golden()
     if "conv" in which:
@@ -399,5 +450,7 @@ if __name__ == "__main__":
         gen_trace("plain_w8", use_noise=False, dropout=0.0, its=[1, 2, 3, 4, 5, 6], tf=8, bf=8)
     if "c1" in which:
         gen_c1_full()
+    if "data" in which:
+        gen_data()
     if "init" in which:
         gen_init_manifest()

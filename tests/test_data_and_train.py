@@ -44,6 +44,52 @@ def test_synthetic_dataset_layout_and_validity(data_root):
     assert len(mx) == 6 and mx[0] == z.min() and mx[1] == z.max() and mx[3] == max(u.max(), v.max(), w.max())
 
 
+def test_dataset_contract_vs_reference_fixture(golden, data_root):
+    """process_data against fixtures the REFERENCE's own process_data / download_data produced on the same files
+    (tests/golden/dataset_contract.npz, make_golden.py gen_data): split and normalisation factors of ``preprosess``,
+    ``reformat_to_torch`` channel layouts, z-interpolation (+ its inverse), beta slice sampling and the rot90 / flip
+    augmentation with the u, v sign rules under the same seeded numpy RNG stream (reference :159-262, :420-494)."""
+    from gan_sr_wind_field_amd import process_data as pd
+
+    g = golden("dataset_contract.npz")
+    XS, ZS = {"start": 0, "max": 32, "step": 1}, {"start": 0, "max": 6, "step": 1}
+    d0, d1 = date(2018, 3, 1), date(2018, 3, 2)
+    pd.write_synthetic_dataset(d0, d1, XS, XS, ZS, seed=2001)
+    T = torch.from_numpy
+    for tag, kw in (("slice_aug", dict(include_pressure=False, include_z_channel=True, interpolate_z=False,
+                                        enable_slicing=True, slice_size=16, train_aug_rot=True, train_aug_flip=True)),
+                    ("interp", dict(include_pressure=True, include_z_channel=True, interpolate_z=True,
+                                    include_above_ground_channel=True, enable_slicing=False))):
+        tr, te, va, x, y = pd.preprosess(X_DICT=XS, Y_DICT=XS, Z_DICT=ZS, start_date=d0, end_date=d1,
+                                         COARSENESS_FACTOR=4, **kw)
+        assert [len(tr), len(te), len(va)] == list(g[f"{tag}.n"])
+        assert [tr.filenames[0], te.filenames[0], va.filenames[0]] == [str(n) for n in g[f"{tag}.first_names"]]
+        np.testing.assert_allclose([tr.Z_MIN, tr.Z_MAX, tr.Z_ABOVE_GROUND_MAX, tr.UVW_MAX, tr.P_MIN, tr.P_MAX],
+                                   g[f"{tag}.norms"], rtol=1e-12)
+        assert torch.equal(x, T(g[f"{tag}.x"])) and torch.equal(y, T(g[f"{tag}.y"]))
+        np.random.seed(77)
+        n_draws = 6 if tag == "slice_aug" else 2
+        rots = set()
+        for i in range(n_draws):
+            LR, HR, Z = tr[i]
+            for name, t in (("LR", LR), ("HR", HR), ("Z", Z)):
+                want = T(g[f"{tag}.train{i}.{name}"])
+                assert t.shape == want.shape and t.dtype == torch.float32
+                assert torch.allclose(t, want, rtol=1e-6, atol=1e-7), (tag, i, name)
+            rots.add(float(HR[0].sum()))
+        assert len(rots) == n_draws  # (different augmentations / slices were drawn)
+        item = te[0]
+        for name, t in zip(("LR", "HR", "Z"), item[:3]):
+            assert torch.allclose(t, T(g[f"{tag}.test0.{name}"]), rtol=1e-6, atol=1e-7), (tag, name)
+        assert item[3] == str(g[f"{tag}.test0.name"])
+        if tag == "interp":
+            assert torch.allclose(item[4], T(g["interp.test0.HR_raw"]), rtol=1e-6, atol=1e-7)
+            assert torch.allclose(item[5], T(g["interp.test0.Z_raw"]), rtol=1e-6, atol=1e-7)
+            back = pd.reverse_interpolate_z_axis(item[1].numpy()[None], item[5].numpy()[None], item[2].numpy()[None])
+            assert torch.allclose(back, T(g["interp.test0.HR_back"]), rtol=1e-5, atol=1e-6)
+        assert torch.allclose(va[1][0], T(g[f"{tag}.val1.LR"]), rtol=1e-6, atol=1e-7)
+
+
 def test_preprosess_split_shapes_and_normalisation(data_root):
     from gan_sr_wind_field_amd import process_data as pd
 
