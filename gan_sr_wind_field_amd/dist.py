@@ -11,8 +11,9 @@ single-GPU step on the concatenated batch:
   rest of backward keeps the compute stream busy.  xGMI is point-to-point, a ring
   all-reduce is per-link bound, so buckets are large (default 32 MB: 139 MB of G
   gradients = 5 collectives) rather than DDP's 25 MB-of-small-tensors default;
-* BatchNorm3d batch statistics (forward sums, backward sums) are sum-reduced
-  (SyncBN), the RaGAN average logits are batch-global means with a matching
+* BatchNorm3d batch statistics are synchronised (SyncBN) with ONE collective per layer and pass: the forward
+  all-gathers every rank's (mean, centred second moment) and combines them exactly, the backward sum-reduces
+  its two sums; the RaGAN average logits are batch-global means with a matching
   backward, the four physics-loss normalisers are max-reduced;
 * parameters and BN buffers are broadcast from rank 0 at attach time; RNG streams
   for dropout / instance noise are offset per rank.
@@ -121,6 +122,15 @@ class DataParallel:
     def stat_allreduce(self, t: Tensor) -> None:
         dist.all_reduce(t, group=self.group)
 
+    def stat_allgather(self, t: Tensor) -> Tensor:
+        """(world, len(t)) copies of a small vector from every rank - the one collective of a SyncBN forward"""
+        out = torch.empty((self.world,) + tuple(t.shape), dtype=t.dtype, device=t.device)
+        if self._avg_native:  # nccl / RCCL
+            dist.all_gather_into_tensor(out, t.contiguous(), group=self.group)
+        else:
+            dist.all_gather(list(out.unbind(0)), t.contiguous(), group=self.group)
+        return out
+
     def _avg_async(self, t: Tensor) -> None:
         if self._avg_native:
             work = dist.all_reduce(t, op=dist.ReduceOp.AVG, group=self.group, async_op=True)
@@ -198,6 +208,7 @@ class DataParallel:
                 progD.grad_done_hook = lambda: self.grad_done("D")
                 if self.sync_bn:
                     progD.stat_allreduce = self.stat_allreduce
+                    progD.stat_allgather = self.stat_allgather
                     progD.stat_world = self.world
             # the classifier head is ordinary torch autograd: reduce its 4 small tensors per step
             for p in gan.D.classifier.parameters():

@@ -964,8 +964,10 @@ class DiscriminatorProgram(ProgramBase):
     """conv (+BatchNorm3d) + LeakyReLU pyramid of ``Discriminator_3D.features``
     (reference Discriminator_3D.py:66-169, torch_blocks.py:372-521)."""
 
-    #: set by dist.py: all-reduce (sum) of a small fp32 tensor across the DP group, or None
+    #: set by dist.py: all-reduce (sum) of a small fp32 tensor across the DP group, or None (backward sums)
     stat_allreduce: Optional[Callable[[Tensor], None]] = None
+    #: set by dist.py: all-gather of a small fp32 vector -> (world, len) (forward statistics), or None
+    stat_allgather: Optional[Callable[[Tensor], Tensor]] = None
     #: ranks in that group (equal shards per rank)
     stat_world: int = 1
 
@@ -1024,15 +1026,22 @@ class DiscriminatorProgram(ProgramBase):
                 ops.bn_stats(y, s1)
                 cdev = None
                 count = float(n)
-                if self.stat_allreduce is not None:
-                    # SyncBN: sums over all ranks.  Shards are equal (dist.py splits the batch evenly), so the
-                    # global voxel count is n * world - known on the host, no device round trip per layer
-                    self.stat_allreduce(s1)
-                    count = float(n) * self.stat_world
                 ops.bn_mean(s1, mean, count, cdev)
                 ops.bn_stats(y, s2, shift=mean)
-                if self.stat_allreduce is not None:
-                    self.stat_allreduce(s2)
+                if self.stat_allgather is not None:
+                    # SyncBN in ONE collective per layer: every rank contributes its local mean and its local
+                    # centred second moment M2 = sum (x - mean_r)^2 (both passes above are local), and the global
+                    # statistics follow from the pairwise-combination rule (Chan et al.) for equal shard sizes:
+                    #   mean = avg_r mean_r ,  M2 = sum_r M2_r + n * sum_r (mean_r - mean)^2
+                    # - no cancellation beyond the per-rank two-pass one.  (Was: two blocking all-reduces.)
+                    m2_local = s2[C_:] - s2[:C_] ** 2 / count  # (sum d is ~0 but not exactly)
+                    allr = self.stat_allgather(torch.cat([mean, m2_local]))  # (world, 2C)
+                    mean_r, m2_r = allr[:, :C_], allr[:, C_:]
+                    gmean = mean_r.mean(dim=0)
+                    s2[:C_].zero_()
+                    s2[C_:].copy_(m2_r.sum(dim=0) + count * ((mean_r - gmean) ** 2).sum(dim=0))
+                    mean.copy_(gmean)
+                    count = float(n) * self.stat_world
                 track = bn.track_running_stats
                 mom = 0.0
                 if track:

@@ -64,7 +64,7 @@ def _g_iteration(gan, cfg, LR, HR, Z, x, y):
     return {k: sd[k].clone() for k in keys}, losses
 
 
-def _worker(rank, world, port, out_dir):
+def _worker(rank, world, port, out_dir, hr_scale=1.0):
     import sys
     sys.path.insert(0, os.path.join(REPO, "tests"))
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
@@ -78,6 +78,7 @@ def _worker(rank, world, port, out_dir):
     gan, cfg = _build_gan()
     dp = wdist.attach(gan, bucket_mb=0.05, sync_bn=True)
     LR, HR, Z, x, y = synthetic_batch(world, 16, 4, 4, seed=2001)
+    HR = HR * hr_scale
     sl = slice(rank, rank + 1)  # one sample per rank
     w, losses = _g_iteration(gan, cfg, LR[sl], HR[sl], Z[sl], x, y)
     # primitives
@@ -89,6 +90,37 @@ def _worker(rank, world, port, out_dir):
                 "n_coll": dp.n_collectives}, os.path.join(out_dir, f"rank{rank}.pt"))
     dist.barrier()
     dist.destroy_process_group()
+
+
+def test_two_rank_g_iteration_sr_normaliser_branch(tmp_path):
+    """HR scaled by 1e-4: every physics normaliser is SR_max / 100, the branch in which the reference
+    differentiates the maxima (wind_field_GAN_3D.py:773-814).  Under data parallelism the maxima are max-reduced
+    and the gradient goes to the rank and element that own them (dist._GlobalMax): the 2-rank G-iteration still
+    equals the single-process step on the full batch."""
+    import sys
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    from oracle.gan import synthetic_batch
+
+    world, port = 2, _free_port()
+    mp.spawn(_worker, args=(world, port, str(tmp_path), 1e-4), nprocs=world, join=True)
+    r0 = torch.load(tmp_path / "rank0.pt")
+    r1 = torch.load(tmp_path / "rank1.pt")
+    gan, cfg = _build_gan()
+    LR, HR, Z, x, y = synthetic_batch(world, 16, 4, 4, seed=2001)
+    HR = HR * 1e-4
+    # the normalisers really come from SR here
+    from gan_sr_wind_field_amd.process_data import calculate_gradient_of_wind_field as jac
+    with torch.no_grad():
+        sr = gan.G(LR, Z)
+        g_hr, g_sr = jac(HR, x, y, Z), jac(sr, x, y, Z)
+    assert float(g_sr[:, :6].abs().max()) / 100 > float(g_hr[:, :6].abs().max())
+    w_ref, losses_ref = _g_iteration(gan, cfg, LR, HR, Z, x, y)
+    for k, v in w_ref.items():
+        assert torch.equal(r0["w"][k], r1["w"][k]), k
+        np.testing.assert_allclose(r0["w"][k].numpy(), v.numpy(), rtol=2e-5, atol=1e-7, err_msg=k)
+    # the normalised terms are batch-global, so both ranks log the full-batch value
+    np.testing.assert_allclose(0.5 * (r0["losses"]["xy_gradient"] + r1["losses"]["xy_gradient"]),
+                               losses_ref["xy_gradient"], rtol=1e-4)
 
 
 def test_two_rank_g_iteration_equals_full_batch(tmp_path):
