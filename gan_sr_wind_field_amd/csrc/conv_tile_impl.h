@@ -600,6 +600,9 @@ static void pick_tile(CtArgs& a, int M) {
   if (a.Zo <= 16) tz = a.Zo;
   else if (a.Zo % 16 == 0 || a.Zo > 64) tz = 16;
   else tz = 8;
+  // no taps along z (the z-folded last conv, 5x5x1): a flat tile has no z halo and a smaller x-y one
+  // (8x16x4: 1.9x its 512 voxels instead of 3x for 4x8x16) - these launches are bound by the halo re-reads
+  if (a.KZ == 1 && a.KX * a.KY > 1 && tz > 4 && !getenv("WSR_CT_NOFLAT")) tz = 4;
   while (tz > M) tz >>= 1;
   const int rest = M / tz;
   int tx = 1, ty = 1;

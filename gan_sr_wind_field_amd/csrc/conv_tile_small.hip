@@ -15,7 +15,9 @@ static int run(CtArgs& a, hipStream_t st) {
     if (N <= 32) { pick_tile(a, 128); return launch_ct<2, 1, 4, 2, TPK>(a, st); }
     // 128 voxels x 128 channels as 2 x 4 waves of 64 x 32: four times the waves of a <2,1,4,8> tile, a quarter of
     // the work each - at these sizes the chip is latency-, not throughput-bound
-    if (N > 64 && N <= 128) { pick_tile(a, 128); return launch_ct<2, 4, 4, 2, TPK>(a, st); }
+    // (wider outputs - the discriminator's 256-channel layers on 16x16x64 and 8x8x64 voxels - run as groups of 128
+    // channels: 64..256 workgroups instead of the 16..64 of the 256-voxel x 256-channel tile)
+    if (N > 64 && N <= 256) { pick_tile(a, 128); return launch_ct<2, 4, 4, 2, TPK>(a, st); }
   }
   return WSR_EUNSUPPORTED;
 }
