@@ -95,6 +95,14 @@ CASES = {
     "lr": lambda: [conv_case("lr_conv 128->128", 128, 128, (3, 3, 3), LR, what=w) for w in ("fwd", "dgrad", "wgrad")],
 }
 
+S10 = (32, 32, 10)  # the reference's real patch size at the trunk's resolution (C1b)
+CASES["c1b"] = lambda: [conv_case("pre 128->128 @32x32x10", 128, 128, (3, 3, 3), S10, 256, 256, 128),
+                        conv_case("pre dgrad @32x32x10", 128, 128, (3, 3, 3), S10, 256, 256, 0, what="dgrad"),
+                        conv_case("grow 96->32 @32x32x10", 96, 32, (3, 3, 3), S10, 256, 256, 224),
+                        conv_case("up2 128->128 @64x64x10", 128, 128, (3, 3, 3), (64, 64, 10), ups=True),
+                        conv_case("hr0 @128x128x10", 144, 144, (5, 5, 5), (128, 128, 10)),
+                        conv_case("lr wgrad @32x32x10", 128, 128, (3, 3, 3), S10, what="wgrad")]
+
 if __name__ == "__main__":
     names = sys.argv[1:] or ["all"]
     if names == ["all"]:
