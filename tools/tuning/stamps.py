@@ -50,6 +50,9 @@ def run(name, cin, cout, k, xyz, in_ctot, out_ctot, out_off, what="fwd", red_dy=
     print("   shader clock %.0f MHz (mean)" % clk.mean())
 
 LR = (32, 32, 128)
+if len(sys.argv) > 1 and sys.argv[1] == "hr0":
+    run("hr0 144->144 k5 (N=144 tile)", 144, 144, (5, 5, 5), (128, 128, 128), 144, 144, 0)
+    sys.exit(0)
 run("pre 128->128 (N=128 tile)", 128, 128, (3, 3, 3), LR, 256, 256, 128)
 run("grow 64->32", 64, 32, (3, 3, 3), LR, 256, 256, 192)
 run("up2 128->128 @128^2", 128, 128, (3, 3, 3), (128, 128, 128), 128, 128, 0)
