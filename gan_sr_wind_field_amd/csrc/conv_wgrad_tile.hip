@@ -492,7 +492,10 @@ int launch_tile(WgtArgs& a, hipStream_t st) {
   }
   // tile: z whole when short, else 16 (the two z-octets of a half-wave read stay in one row run); x, y as
   // large as two LDS buffers and the per-wave DMA unit registers allow
-  const int tz = a.Zo <= 16 ? a.Zo : ((a.Zo % 16 == 0 || a.Zo > 64) ? 16 : 8);
+  int tz = a.Zo <= 16 ? a.Zo : ((a.Zo % 16 == 0 || a.Zo > 64) ? 16 : 8);
+  // no taps along z (the z-folded last conv, 5x5x1): a flat tile has no z halo and a far smaller x-y one
+  // (8x8x4: 2.25x its voxels; 2x4x16: 6x) - that launch is bound by the halo re-reads of its 144-channel input
+  if (a.KZ == 1 && a.KX * a.KY > 1 && tz > 4 && a.Zo % 4 == 0 && !getenv("WSR_CT_NOFLAT")) tz = 4;
   static const int cand[][2] = {{8, 8}, {4, 8}, {4, 4}, {2, 4}, {2, 2}, {1, 2}, {1, 1}};
   int best = -1, best_nbuf = 0;
   for (int nbuf = 2; nbuf >= 2 && best < 0; --nbuf) {  // the kernel is written for two buffers
