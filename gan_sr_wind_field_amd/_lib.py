@@ -19,7 +19,7 @@ WSR_EUNSUPPORTED = -2
 EXPORTS = [
     "wsr_abi_version", "wsr_error_string", "wsr_conv3d_fwd", "wsr_conv3d_dgrad", "wsr_conv3d_wgrad", "wsr_conv3d_wgrad_tri", "wsr_conv3d_wgrad_nparts", "wsr_conv3d_wgrad_parts", "wsr_unpack_wgrad_reduce_multi", "wsr_conv3d_fwd_tile", "wsr_conv3d_dgrad_tile",
     "wsr_frag_filter_elems", "wsr_pack_filter_frag", "wsr_pack_filter_frag_multi",
-    "wsr_pack_filter", "wsr_unpack_wgrad", "wsr_unpack_wgrad_multi", "wsr_lrelu_bwd_inplace", "wsr_chan_axpby", "wsr_chan_sum", "wsr_upsample2_bwd",
+    "wsr_pack_filter", "wsr_unpack_wgrad", "wsr_unpack_wgrad_multi", "wsr_lrelu_bwd_inplace", "wsr_chan_axpby", "wsr_chan_sum", "wsr_upsample2_bwd", "wsr_subpixel_fold", "wsr_subpixel_unfold",
     "wsr_planar_to_ndhwc", "wsr_ndhwc_to_planar", "wsr_zfold", "wsr_zunfold", "wsr_wind_gradient", "wsr_wind_gradient_bwd", "wsr_plane_sum", "wsr_physics_loss_workspace_floats", "wsr_physics_loss_stats", "wsr_physics_loss_bwd", "wsr_bn_stats", "wsr_bn_mean", "wsr_bn_finalize", "wsr_bn_apply_lrelu", "wsr_bn_bwd_reduce",
     "wsr_bn_bwd_apply", "wsr_adam_step",
 ]
@@ -30,7 +30,8 @@ class ConvDesc(C.Structure):
 
     _fields_ = [(n, C.c_int32) for n in (
         "dtype", "B", "Xi", "Yi", "Zi", "Xo", "Yo", "Zo", "Cin", "in_ctot", "in_off", "Cout", "out_ctot",
-        "out_off", "KX", "KY", "KZ", "sx", "sy", "sz", "px", "py", "pz", "upsample_xy")]
+        "out_off", "KX", "KY", "KZ", "sx", "sy", "sz", "px", "py", "pz", "upsample_xy", "lat", "lat_ox", "lat_oy",
+        "lat_phases")]
 
 
 class Epilogue(C.Structure):
@@ -91,6 +92,8 @@ def lib() -> C.CDLL:
         "wsr_chan_axpby": [vp, i32, i32, vp, i32, i32, i32, i64, f32, f32, i32, vp],
         "wsr_chan_sum": [vp, i32, i32, i32, i64, f32, vp, vp, i32, vp],
         "wsr_upsample2_bwd": [vp, vp, i32, i32, i32, i32, i32, i32, vp],
+        "wsr_subpixel_fold": [vp, vp, i64, i32, vp],
+        "wsr_subpixel_unfold": [vp, vp, i64, i32, vp],
         "wsr_planar_to_ndhwc": [vp, vp, i32, i32, i64, i32, i32, i32, i32, vp],
         "wsr_ndhwc_to_planar": [vp, vp, i32, i32, i64, i32, i32, i32, vp],
         "wsr_zfold": [vp, vp, vp, i32, i32, i32, i32, i64, i32, vp],
@@ -116,7 +119,7 @@ def lib() -> C.CDLL:
     L.wsr_frag_filter_elems.restype = C.c_int64
     L.wsr_physics_loss_workspace_floats.argtypes = []
     L.wsr_physics_loss_workspace_floats.restype = C.c_int64
-    if L.wsr_abi_version() != 2:
+    if L.wsr_abi_version() != 3:
         raise RuntimeError("libwindsr_hip.so ABI version mismatch")
     _lib = L
     return L

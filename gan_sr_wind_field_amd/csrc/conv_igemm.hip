@@ -362,6 +362,7 @@ int run_igemm(IgemmArgs& a, int dtype, bool general, hipStream_t st) {
 extern "C" int wsr_conv3d_fwd(const wsr_conv_t* c, const void* x, const void* w, void* y,
                               const wsr_epilogue_t* ep, void* stream) {
   if (!conv_geom_ok(c) || !x || !w || !y) return WSR_EINVAL;
+  if (c->lat) return WSR_EUNSUPPORTED;  // parity convs of the sub-pixel form: tile kernels only
   IgemmArgs a{};
   a.in = (const char*)x;
   a.w = (const char*)w;
@@ -401,6 +402,7 @@ extern "C" int wsr_conv3d_fwd(const wsr_conv_t* c, const void* x, const void* w,
 extern "C" int wsr_conv3d_dgrad(const wsr_conv_t* c, const void* dy, const void* wt, void* dx, float alpha,
                                 int accumulate, int dx_planar, void* stream) {
   if (!conv_geom_ok(c) || !dy || !wt || !dx) return WSR_EINVAL;
+  if (c->lat) return WSR_EUNSUPPORTED;  // parity convs of the sub-pixel form: tile kernels only
   const int ux = c->upsample_xy ? 2 : 1;
   IgemmArgs a{};
   a.in = (const char*)dy;

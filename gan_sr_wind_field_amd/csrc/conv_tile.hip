@@ -252,7 +252,13 @@ extern "C" int wsr_conv3d_fwd_tile(const wsr_conv_t* c, const void* x, const voi
   a.Cout = c->Cout; a.out_ctot = c->out_ctot; a.out_off = c->out_off;
   a.KX = c->KX; a.KY = c->KY; a.KZ = c->KZ;
   a.px = c->px; a.py = c->py; a.pz = c->pz;
-  if (c->KX * c->KY * c->KZ == 1 && !a.ups && !a.out_planar && !a.chan_scale && (c->px | c->py | c->pz) == 0 &&
+  if (c->lat) {  // parity conv(s) of a sub-pixel up-sampling conv: y is written on the (2x + ox, 2y + oy) lattice
+    if (a.res || a.out_planar) return WSR_EUNSUPPORTED;
+    a.ol_m = 2; a.ol_ox = c->lat_ox; a.ol_oy = c->lat_oy;
+    a.nphase = c->lat_phases == 4 ? 4 : 1;
+    a.ph_wstride = (long)wsr_frag_filter_elems(c->Cout, c->Cin, c->KX * c->KY * c->KZ);
+  }
+  if (c->KX * c->KY * c->KZ == 1 && !c->lat && !a.ups && !a.out_planar && !a.chan_scale && (c->px | c->py | c->pz) == 0 &&
       (c->sx | c->sy | c->sz) == 1 && a.act <= 1 && a.act_c1 == 0x7FFFFFFF) {
     const int rc = wsr_conv1x1_bf16(a.in, a.in_ctot, a.in_off, c->Cin, a.wf, (unsigned short*)a.out, a.out_ctot,
                                     a.out_off, a.Cout, (long)c->B * c->Xo * c->Yo * c->Zo, a.bias, a.res, a.res_ctot,
@@ -299,8 +305,12 @@ extern "C" int wsr_conv3d_dgrad_tile(const wsr_conv_t* c, const void* dy, const 
   a.Cout = c->Cin; a.out_ctot = c->in_ctot; a.out_off = c->in_off;
   a.KX = c->KX; a.KY = c->KY; a.KZ = c->KZ;
   a.px = c->KX - 1 - c->px; a.py = c->KY - 1 - c->py; a.pz = c->KZ - 1 - c->pz;
+  if (c->lat) {  // parity conv of a sub-pixel up-sampling conv: dy is read on the (2x + ox, 2y + oy) lattice
+    if (c->lat_phases) return WSR_EUNSUPPORTED;  // the parities add into the same dx: one launch each
+    a.il_m = 2; a.il_ox = c->lat_ox; a.il_oy = c->lat_oy;
+  }
   if (mask && mask->chan_scale) a.chan_scale = mask->chan_scale;
-  if (c->KX * c->KY * c->KZ == 1 && ux == 1 && !a.out_planar && (c->px | c->py | c->pz) == 0 && !a.chan_scale) {
+  if (c->KX * c->KY * c->KZ == 1 && !c->lat && ux == 1 && !a.out_planar && (c->px | c->py | c->pz) == 0 && !a.chan_scale) {
     const int rc = wsr_conv1x1_bf16(a.in, a.in_ctot, a.in_off, c->Cout, a.wf, (unsigned short*)a.out, a.out_ctot,
                                     a.out_off, a.Cout, (long)c->B * c->Xo * c->Yo * c->Zo, nullptr, a.res, a.res_ctot,
                                     a.res_off, a.res ? a.res_c1 : 0, a.alpha, a.beta, 0, 0.f, mask, nullptr, 0, 0, 0.f,

@@ -64,6 +64,12 @@ struct CtArgs {
   int xbufs;        // activation buffers in LDS: 2 = next chunk prefetched during the MFMAs
   // ceil(2^32 / d) for the runtime divisors of the prologue (fdiv): tile / halo / tap extents, tile counts
   unsigned mg_TZ, mg_TY, mg_Lz, mg_Ly, mg_KZ, mg_KY, mg_ng, mg_tz, mg_ty, mg_tx;
+  // Sub-pixel form of an up-sampling conv (wsr_conv_t.lat): the gathered tensor (il_*) or the produced tensor (ol_*)
+  // is the sub-lattice (m*x + ox, m*y + oy, z) of a tensor m times as large along x and y (m = 1: the tensor itself).
+  // nphase = 4: the four parity convs in one launch - parity (a, b) = bits of the tile index: pads (px - a, py - b),
+  // produced lattice offsets (a, b), filter wf + (2a + b) * ph_wstride.
+  int il_m, il_ox, il_oy, ol_m, ol_ox, ol_oy, nphase;
+  long ph_wstride;
   int prio;    // 1: waves of the second half of the workgroup run the main loop at s_setprio 1 (tuning switch)
   int ablate;  // -DWSR_CT_STAMPS builds, timing only: skip 1 = activation prefetch, 2 = weight prefetch, 4 = LDS reads, 8 = MFMAs
   unsigned long long* stamps;  // -DWSR_CT_STAMPS builds: [workgroup][8] clock samples of wave 0 (else unused)
@@ -136,7 +142,10 @@ void conv_tile_kernel(const CtArgs a) {
   const unsigned bid = (unsigned)xcd_remap(blockIdx.x, gridDim.x);
   const unsigned tile = fdiv(bid, a.ngroups, a.mg_ng);
   const int ng = (int)(bid - tile * a.ngroups);
-  unsigned r = tile, r2;
+  // the four parity convs of a sub-pixel launch sit side by side in the grid: they gather the same halo (L2)
+  const int pha = a.nphase == 4 ? (int)((tile >> 1) & 1) : 0, phb = a.nphase == 4 ? (int)(tile & 1) : 0;
+  const int ppx = a.px - pha, ppy = a.py - phb;
+  unsigned r = a.nphase == 4 ? tile >> 2 : tile, r2;
   r2 = fdiv(r, a.tiles_z, a.mg_tz); const int tz = (int)(r - r2 * a.tiles_z); r = r2;
   r2 = fdiv(r, a.tiles_y, a.mg_ty); const int ty = (int)(r - r2 * a.tiles_y); r = r2;
   r2 = fdiv(r, a.tiles_x, a.mg_tx); const int tx = (int)(r - r2 * a.tiles_x);
@@ -161,7 +170,7 @@ void conv_tile_kernel(const CtArgs a) {
   const int UPP = VM ? (L + 31) >> 5 : (L + 63) >> 6;  // 1 KB DMA units per activation plane (VM: per chunk)
   const int HU = VM ? UPP : UPP * PL;                   // ... per chunk
   const int xs_bytes = VM ? a.P : PL * a.P;
-  const unsigned short* wbase = a.wf + (size_t)nt0 * 512;
+  const unsigned short* wbase = a.wf + (size_t)(2 * pha + phb) * a.ph_wstride + (size_t)nt0 * 512;
   typedef __attribute__((address_space(3))) char* lptr_t;
   const unsigned xs_lds = (unsigned)(unsigned long)(lptr_t)Xs;  // LDS byte addresses
   const unsigned ws_lds = (unsigned)(unsigned long)(lptr_t)Ws;
@@ -204,12 +213,13 @@ void conv_tile_kernel(const CtArgs a) {
       }
       if (v < L) {
         const unsigned q = fdiv((unsigned)v, Lz, a.mg_Lz), hx = fdiv(q, Ly, a.mg_Ly);
-        const int gx = x0 * a.sx - a.px + (int)hx, gy = y0 * a.sy - a.py + (int)(q - hx * Ly),
+        const int gx = x0 * a.sx - ppx + (int)hx, gy = y0 * a.sy - ppy + (int)(q - hx * Ly),
                   gz = z0 * a.sz - a.pz + (int)(v - q * Lz);
         if ((unsigned)gx < (unsigned)(a.Xi << U) && (unsigned)gy < (unsigned)(a.Yi << U) &&
             (unsigned)gz < (unsigned)a.Zi) {
           // 32-bit arithmetic: the host checked that the whole tensor is below 2^32 elements
-          const unsigned vox = (((unsigned)b * a.Xi + (gx >> U)) * a.Yi + (gy >> U)) * a.Zi + gz;
+          const unsigned vox = ((((unsigned)b * a.Xi + (gx >> U)) * a.il_m + a.il_ox) * (a.Yi * a.il_m) +
+                                (gy >> U) * a.il_m + a.il_oy) * a.Zi + gz;
           off = vox * (unsigned)a.in_ctot + (unsigned)(a.in_off + 8 * pl);
         }
       }
@@ -386,7 +396,8 @@ void conv_tile_kernel(const CtArgs a) {
   // every tile would pay a full memory round trip).  The n-tiles are walked one at a time; the operands
   // of n-tile j+1 (bias, channel scale, residual and mask values of its TM rows) are fetched before the
   // stores of n-tile j are issued.
-  const long vox_per_b = (long)a.Xo * a.Yo * a.Zo;
+  const long vox_per_b = (long)a.Xo * a.Yo * a.Zo * (a.ol_m * a.ol_m);
+  const int olx = a.ol_ox + pha, oly = a.ol_oy + phb, oYo = a.Yo * a.ol_m;
   const int cob = (nt0 + wn * TN) * 16 + fg * 4;  // this lane's first channel of n-tile j is cob + 16*j
   const bool fast = a.vec_ok && !a.out_planar && (a.Cout & 3) == 0 && (a.mask_c1 & 3) == 0;
   long mrow[TM];   // flat output voxel of row `fr` of m-tile i, or -1
@@ -395,7 +406,7 @@ void conv_tile_kernel(const CtArgs a) {
     const unsigned mv = mtab[(wm * TM + i) * 16 + fr];
     const int gx = x0 + (int)(mv & 255), gy = y0 + (int)((mv >> 8) & 255), gz = z0 + (int)((mv >> 16) & 255);
     const bool ok = !(mv >> 24) && gx < a.Xo && gy < a.Yo && gz < a.Zo;
-    mrow[i] = ok ? (long)b * vox_per_b + ((long)gx * a.Yo + gy) * a.Zo + gz : -1;
+    mrow[i] = ok ? (long)b * vox_per_b + ((long)(gx * a.ol_m + olx) * oYo + gy * a.ol_m + oly) * a.Zo + gz : -1;
   }
   // row base pointers once (64-bit multiply-adds), n-tile offsets are immediates
   unsigned short* orow[TM];
@@ -524,6 +535,10 @@ int launch_ct(CtArgs& a, hipStream_t st) {
   constexpr int M = WM * TM * 16;  // table sizes follow the MFMA rows; the tile volume may be smaller
   if (a.TX * a.TY * a.TZ > M) return WSR_EUNSUPPORTED;
   if (a.sx < 1) a.sx = a.sy = a.sz = 1;
+  if (a.il_m < 1) a.il_m = 1;
+  if (a.ol_m < 1) a.ol_m = 1;
+  if (a.nphase != 4) a.nphase = 1;
+  if ((a.il_m > 1 || a.ol_m > 1 || a.nphase > 1) && (a.ups || a.sx != 1 || a.sy != 1 || a.sz != 1)) return WSR_EUNSUPPORTED;
   const int L = ((a.TX - 1) * a.sx + a.KX) * ((a.TY - 1) * a.sy + a.KY) * ((a.TZ - 1) * a.sz + a.KZ);
   if (L > 65535) return WSR_EUNSUPPORTED;
   a.nts = (taps + TPK - 1) / TPK;
@@ -552,7 +567,7 @@ int launch_ct(CtArgs& a, hipStream_t st) {
   }
   if (ts_max < 1) return WSR_EUNSUPPORTED;
   if ((VM ? (L + 31) / 32 : ((L + 63) / 64) * PL) > ct_xk(WAVES, TM) * WAVES) return WSR_EUNSUPPORTED;  // XK units per wave
-  if ((long)a.B * a.Xi * a.Yi * a.Zi * a.in_ctot >= 0xFFFFFFFFL) return WSR_EUNSUPPORTED;  // 32-bit element offsets
+  if ((long)a.B * a.Xi * a.Yi * a.Zi * a.in_ctot * (a.il_m * a.il_m) >= 0xFFFFFFFFL) return WSR_EUNSUPPORTED;  // 32-bit element offsets
   const int nph = (a.nts + ts_max - 1) / ts_max;
   a.TS = (a.nts + nph - 1) / nph;  // balanced stages
   const size_t lds = (size_t)a.off_ws + (size_t)2 * a.TS * NTW * 1024;
@@ -566,7 +581,7 @@ int launch_ct(CtArgs& a, hipStream_t st) {
     if (a.tiles_z > dmax) dmax = a.tiles_z;
     if (a.tiles_y > dmax) dmax = a.tiles_y;
     if (a.tiles_x > dmax) dmax = a.tiles_x;
-    if ((long)a.ntiles * a.ngroups * dmax >= (1l << 32)) return WSR_EUNSUPPORTED;
+    if ((long)a.ntiles * a.nphase * a.ngroups * dmax >= (1l << 32)) return WSR_EUNSUPPORTED;
   }
   a.mg_TZ = fdiv_magic(a.TZ); a.mg_TY = fdiv_magic(a.TY);
   a.mg_Lz = fdiv_magic((a.TZ - 1) * a.sz + a.KZ); a.mg_Ly = fdiv_magic((a.TY - 1) * a.sy + a.KY);
@@ -589,7 +604,7 @@ int launch_ct(CtArgs& a, hipStream_t st) {
   a.stamps = getenv("WSR_CT_STAMPS_PTR") ? (unsigned long long*)strtoull(getenv("WSR_CT_STAMPS_PTR"), nullptr, 0) : nullptr;
 #endif
   a.prio = getenv("WSR_CT_PRIO") ? atoi(getenv("WSR_CT_PRIO")) : 1;  // measured: +1 % on the 144- and 128-wide tiles
-  hipLaunchKernelGGL(kern, dim3((unsigned)(a.ntiles * a.ngroups)), dim3(WAVES * 64), lds, st, a);
+  hipLaunchKernelGGL(kern, dim3((unsigned)(a.ntiles * a.nphase * a.ngroups)), dim3(WAVES * 64), lds, st, a);
   WSR_LAUNCH_CHECK();
   return 0;
 }

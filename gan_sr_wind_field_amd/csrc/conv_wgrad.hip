@@ -259,6 +259,7 @@ static int wgrad_any(const wsr_conv_t* c, const void* x, const void* dy, float* 
     const int rc = wsr_wgrad_tile_bf16(c, x, dy, dw, tri_base, tri_step, part_stride, n_parts, plan, stream);
     if (rc != WSR_EUNSUPPORTED || tri_step > 0) return rc;
   }
+  if (c->lat) return WSR_EUNSUPPORTED;  // parity convs of the sub-pixel form: tile kernels only
   const int epp = c->dtype == WSR_BF16 ? 8 : 4;
   if (c->Cin % epp || c->in_ctot % epp || c->in_off % epp) return WSR_EUNSUPPORTED;
   if (c->out_ctot % epp || c->out_off % epp) return WSR_EUNSUPPORTED;

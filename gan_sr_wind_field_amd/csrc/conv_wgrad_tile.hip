@@ -596,6 +596,7 @@ int run_tile(WgtArgs& a, int taps, int Cout, int Cin, hipStream_t st);
 int wsr_wgrad_tile_bf16(const wsr_conv_t* c, const void* x, const void* dy, float* dw, int tri_base, int tri_step,
                         long part_stride, int n_parts, int* plan, void* stream) {
   if (c->dtype != WSR_BF16 || (c->sx | c->sy | c->sz) != 1) return WSR_EUNSUPPORTED;
+  if (c->lat) return WSR_EUNSUPPORTED;
   const int taps = c->KX * c->KY * c->KZ;
   if (taps > 128) return WSR_EUNSUPPORTED;
   if (c->Cin % 8 || c->in_ctot % 8 || c->in_off % 8 || c->out_ctot % 8 || c->out_off % 8) return WSR_EUNSUPPORTED;

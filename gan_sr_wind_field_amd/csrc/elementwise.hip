@@ -179,6 +179,51 @@ __global__ void upsample2_bwd_kernel(const typename T::elem* dy, typename T::ele
   }
 }
 
+// Sub-pixel filters of an up-sampling conv (see wsr_subpixel_fold): tap i of parity a collects the taps of the
+// 3-wide filter that read the same un-sampled voxel:  a = 0: {0}, {1, 2};  a = 1: {0, 1}, {2}.
+__device__ __forceinline__ void subpixel_set(int a, int i, int& lo, int& hi) {
+  lo = a == 0 ? (i == 0 ? 0 : 1) : (i == 0 ? 0 : 2);
+  hi = a == 0 ? (i == 0 ? 0 : 2) : (i == 0 ? 1 : 2);
+}
+
+__global__ void subpixel_fold_kernel(const float* __restrict__ w, float* __restrict__ wp, long n, int KZ) {
+  const long per = (long)4 * KZ;            // elements of one parity filter (2, 2, KZ)
+  const long total = 4 * n * per;
+  for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const int kz = (int)(idx % KZ);
+    long q = idx / KZ;
+    const int j = (int)(q & 1), i = (int)((q >> 1) & 1);
+    q >>= 2;
+    const long f = q % n;
+    const int ph = (int)(q / n), a = ph >> 1, b = ph & 1;
+    int x0, x1, y0, y1;
+    subpixel_set(a, i, x0, x1);
+    subpixel_set(b, j, y0, y1);
+    float v = 0.f;
+    for (int kx = x0; kx <= x1; ++kx)
+      for (int ky = y0; ky <= y1; ++ky) v += w[(f * 9 + kx * 3 + ky) * KZ + kz];
+    wp[idx] = v;
+  }
+}
+
+__global__ void subpixel_unfold_kernel(const float* __restrict__ dwp, float* __restrict__ dw, long n, int KZ) {
+  const long total = n * 9 * KZ;
+  for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const int kz = (int)(idx % KZ);
+    long q = idx / KZ;
+    const int ky = (int)(q % 3), kx = (int)((q / 3) % 3);
+    const long f = q / 9;
+    float v = 0.f;
+    for (int a = 0; a < 2; ++a)
+      for (int b = 0; b < 2; ++b) {
+        const int i = a == 0 ? (kx == 0 ? 0 : 1) : (kx == 2 ? 1 : 0);  // the tap of parity a that holds kx
+        const int j = b == 0 ? (ky == 0 ? 0 : 1) : (ky == 2 ? 1 : 0);
+        v += dwp[((((long)(2 * a + b) * n + f) * 2 + i) * 2 + j) * KZ + kz];
+      }
+    dw[idx] = v;
+  }
+}
+
 template <class T>
 __global__ void planar_to_ndhwc_kernel(const float* __restrict__ src, typename T::elem* __restrict__ dst, int B, int C,
                                        long vpb, int d_ctot, int d_off, int cfill) {
@@ -708,6 +753,22 @@ extern "C" int wsr_upsample2_bwd(const void* dy, void* dx, int32_t B, int32_t Xi
                                 (const unsigned short*)dy, (unsigned short*)dx, B, Xi, Yi, Zi, C),
              hipLaunchKernelGGL(upsample2_bwd_kernel<F32>, dim3(ew_grid(total)), dim3(EW_BLOCK), 0, as_stream(stream),
                                 (const float*)dy, (float*)dx, B, Xi, Yi, Zi, C));
+  WSR_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int wsr_subpixel_fold(const float* w, float* wp, int64_t n, int32_t KZ, void* stream) {
+  if (!w || !wp || n <= 0 || KZ <= 0) return WSR_EINVAL;
+  hipLaunchKernelGGL(subpixel_fold_kernel, dim3(ew_grid(16 * n * KZ)), dim3(EW_BLOCK), 0, as_stream(stream), w, wp,
+                     (long)n, KZ);
+  WSR_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int wsr_subpixel_unfold(const float* dwp, float* dw, int64_t n, int32_t KZ, void* stream) {
+  if (!dwp || !dw || n <= 0 || KZ <= 0) return WSR_EINVAL;
+  hipLaunchKernelGGL(subpixel_unfold_kernel, dim3(ew_grid(9 * n * KZ)), dim3(EW_BLOCK), 0, as_stream(stream), dwp, dw,
+                     (long)n, KZ);
   WSR_LAUNCH_CHECK();
   return 0;
 }

@@ -45,6 +45,9 @@ POISON_BUFFERS = bool(int(__import__("os").environ.get("WSR_POISON_BUFFERS", "0"
 #: copy and the unpack pass adds the copies in index order - two backward passes give bit-identical gradients
 #: (WSR_DETERMINISTIC=0: one shared copy, float atomics)
 DETERMINISTIC = __import__("os").environ.get("WSR_DETERMINISTIC", "1") != "0"
+#: run the up-sampling convs (nearest x(2,2,1) + 3x3x3) in their sub-pixel form: four 2x2x3 parity convs on the
+#: un-sampled input, 4/9 of the multiply-adds (WSR_SUBPIXEL=0: gather through the up-sampling, 27 taps)
+SUBPIXEL = __import__("os").environ.get("WSR_SUBPIXEL", "1") != "0"
 
 
 def compute_dtype_of(flag) -> torch.dtype:
@@ -146,6 +149,12 @@ class FilterCache:
 
     def get_stacked(self, skey) -> Tensor:
         return self._c[(skey, "dstack")][1]
+
+    def touch(self) -> None:
+        """a source of the packed copies was rewritten behind torch's back (kernel writing through a raw pointer:
+        no version bump): the next refresh_frags re-packs"""
+        for k in [k for k in self._tables if k[0] == "probe"]:
+            del self._tables[k]
 
     def invalidate(self) -> None:
         """Mark every compute copy stale (called from an optimizer post-step hook: the fused multi-tensor
@@ -615,6 +624,26 @@ class GeneratorProgram(ProgramBase):
             wz = torch.empty((self.hr1.cout * k[2], self.hr1.cin, k[0], k[1], 1), dtype=torch.float32, device=w.device)
             self.hr1z = ConvSite("hr_convs.2.zfold", wz, None, (k[0], k[1], 1), (1, 1, 1),
                                  (self.hr1.pad[0], self.hr1.pad[1], 0))
+        # Sub-pixel form of the up-sampling convs (reference torch_blocks.py:345-347: nn.Upsample(scale_factor=(2,2,1),
+        # mode="nearest") in front of a 3x3x3 conv): output parity (a, b) only ever sees 2x2 distinct un-sampled
+        # voxels per z level, so the conv is four 2x2x3 convs on the un-sampled input whose filters are sums of the
+        # master taps (wsr_subpixel_fold) - 12 instead of 27 taps per output voxel.  Parity sites are twins of the
+        # master filter like hr1z; they exist only for the bf16 tile path.
+        self.up_parity: List[Optional[List[ConvSite]]] = []
+        self._up_wp: List[Optional[Tensor]] = []
+        self._up_stamp: List[object] = []
+        for u in self.ups:
+            ok = (u.kernel[0], u.kernel[1]) == (3, 3) and (u.pad[0], u.pad[1]) == (1, 1) and u.stride == (1, 1, 1)
+            if ok:
+                kz = u.kernel[2]
+                wp = torch.empty((4, u.cout, u.cin, 2, 2, kz), dtype=torch.float32, device=u.weight.device)
+                self.up_parity.append([ConvSite(f"{u.name}.parity{ph}", wp[ph], None, (2, 2, kz), (1, 1, 1),
+                                                (1 - (ph >> 1), 1 - (ph & 1), u.pad[2])) for ph in range(4)])
+            else:
+                wp = None
+                self.up_parity.append(None)
+            self._up_wp.append(wp)
+            self._up_stamp.append(None)
         self.nf = self.feature.cout
         self.gc = self.rrdbs[0][0][0][0].cout if self.rrdbs and self.rrdbs[0][0][0] else 0
         self.tf = self.terrain1.cout
@@ -645,9 +674,41 @@ class GeneratorProgram(ProgramBase):
     def zfold_active(self) -> bool:
         return ZFOLD and self.hr1z is not None and self.tile_ok(self.hr1z)
 
+    def subpixel_active(self, u: int) -> bool:
+        return (SUBPIXEL and self.up_parity[u] is not None and self.use_tile and self.dt == torch.bfloat16
+                and self.cp(self.ups[u].cin) == self.ups[u].cin)
+
     def conv_sites(self) -> Sequence[ConvSite]:
         zf = self.zfold_active()
-        return [s for s in self.all_sites if s is not (self.hr1 if zf else self.hr1z)]
+        sites = [s for s in self.all_sites if s is not (self.hr1 if zf else self.hr1z)]
+        for u, par in enumerate(self.up_parity):
+            if self.subpixel_active(u):  # the parity twins are what the tile kernels read; the master is not packed
+                sites = [s for s in sites if s is not self.ups[u]] + par
+        return sites
+
+    def _refresh_parity(self, u: int) -> None:
+        """parity filters of up-conv u from its master filter, when that changed"""
+        site, par = self.ups[u], self.up_parity[u]
+        w = site.weight
+        wp = self._up_wp[u]
+        if wp.device != w.device:
+            wp = self._up_wp[u] = torch.empty_like(wp, device=w.device)
+            for ph, s in enumerate(par):
+                s.weight = wp[ph]
+            self._up_stamp[u] = None
+        # the four forward fragment filters share one buffer, parity-major: one launch runs all parities
+        n = ops.frag_filter_elems(par[0].weight, False)
+        hit = self.filters._c.get((id(par[0].weight), "frag", False))
+        if hit is None or hit[1].device != w.device:
+            big = torch.empty(4 * n, dtype=torch.bfloat16, device=w.device)
+            for ph, s in enumerate(par):
+                self.filters._c[(id(s.weight), "frag", False)] = (None, big[ph * n:(ph + 1) * n])
+            self._up_stamp[u] = None
+        stamp = (w._version, w.data_ptr(), self.filters._gen)
+        if stamp != self._up_stamp[u]:
+            ops.subpixel_fold(w.detach().contiguous(), wp)
+            self.filters.touch()
+            self._up_stamp[u] = stamp
 
     def refresh_filters(self, backward: bool) -> None:
         if self.zfold_active():  # hr1's filter in the folded arrangement [c*KZ + kz][ci][kx][ky][0]
@@ -661,7 +722,61 @@ class GeneratorProgram(ProgramBase):
                 kx, ky, kz = self.hr1.kernel
                 wz.view(self.hr1.cout, kz, self.hr1.cin, kx, ky).copy_(w.detach().permute(0, 4, 1, 2, 3))
                 self._hr1z_stamp = stamp
+        for u in range(len(self.ups)):
+            if self.subpixel_active(u):
+                self._refresh_parity(u)
         super().refresh_filters(backward)
+
+    def up_conv(self, u: int, cur: Tensor, out: Tensor) -> None:
+        """up-conv u: nearest x(2,2,1) + conv + LeakyReLU, ``cur`` (B, X, Y, Z, nf) -> window [0, cout) of ``out``
+        (B, 2X, 2Y, Z, .)"""
+        site, sl = self.ups[u], self.slope
+        if not self.subpixel_active(u):
+            self.conv(site, cur, 0, out, 0, act=True, slope=sl)
+            return
+        par = self.up_parity[u]
+        B, xyz = cur.shape[0], tuple(cur.shape[1:4])
+        bias = site.bias.detach() if site.bias is not None else None
+        frs = [self.filters.get_frag(s.weight, False) for s in par]
+        n = frs[0].numel()
+        batched = all(f.data_ptr() == frs[0].data_ptr() + 2 * n * ph for ph, f in enumerate(frs))
+
+        def run():
+            if batched:  # one launch, parity = two bits of the workgroup index
+                d = ops.make_desc(ConvGeom(site.cin, site.cout, par[0].kernel, (1, 1, 1), par[0].pad), self.dt, B, xyz,
+                                  cur.shape[-1], 0, out.shape[-1], 0, lat=(0, 0, 4))
+                if ops.conv_fwd_tile(d, cur, frs[0], out, bias=bias, act=True, slope=sl):
+                    return
+            for ph, s in enumerate(par):
+                d = ops.make_desc(ConvGeom(site.cin, site.cout, s.kernel, (1, 1, 1), s.pad), self.dt, B, xyz,
+                                  cur.shape[-1], 0, out.shape[-1], 0, lat=(ph >> 1, ph & 1, 0))
+                if not ops.conv_fwd_tile(d, cur, frs[ph], out, bias=bias, act=True, slope=sl):
+                    raise RuntimeError("sub-pixel up-conv outside the tile kernels (set WSR_SUBPIXEL=0)")
+
+        if self.launch_probe is not None:
+            self.launch_probe("fwd:" + site.name, run)
+        else:
+            run()
+
+    def up_dgrad(self, u: int, g: Tensor, gin: Tensor, mask=None) -> None:
+        """input gradient of up-conv u in its sub-pixel form: ``gin`` (B, X, Y, Z, nf) = sum over the four parities of
+        the 2x2x3 input gradient of the output gradient on that parity's lattice of ``g`` (B, 2X, 2Y, Z, .)"""
+        site, par = self.ups[u], self.up_parity[u]
+        B, xyz = g.shape[0], tuple(gin.shape[1:4])
+
+        def run():
+            for ph, s in enumerate(par):
+                d = ops.make_desc(ConvGeom(site.cin, site.cout, s.kernel, (1, 1, 1), s.pad), self.dt, B, xyz,
+                                  gin.shape[-1], 0, g.shape[-1], 0, cin=self.cp(site.cin), cout=self.cp(site.cout),
+                                  lat=(ph >> 1, ph & 1, 0))
+                m = None if (mask is None or ph < 3) else (mask[0], mask[1], mask[2], mask[3], self.slope)
+                if not ops.conv_dgrad_tile(d, g, self.filters.get_frag(s.weight, True), gin, accumulate=ph > 0, mask=m):
+                    raise RuntimeError("sub-pixel up-conv gradient outside the tile kernels (set WSR_SUBPIXEL=0)")
+
+        if self.launch_probe is not None:
+            self.launch_probe("dgrad:" + site.name, run)
+        else:
+            run()
 
     # ---- forward -------------------------------------------------------------------
     def forward(self, x: Tensor, Z: Tensor, training: bool, save: bool, drop_scale: Optional[Tensor]):
@@ -716,7 +831,7 @@ class GeneratorProgram(ProgramBase):
         for u, site in enumerate(self.ups):
             last = u == len(self.ups) - 1
             out = hcat if last else self._empty((B, cur.shape[1] * 2, cur.shape[2] * 2, nz, nf), x)
-            self.conv(site, cur, 0, out, 0, act=True, slope=sl)
+            self.up_conv(u, cur, out)
             up_io.append((cur, out))
             cur = out
         if not self.ups:
@@ -816,15 +931,19 @@ class GeneratorProgram(ProgramBase):
         del gt0
         # ---- up-convs, last to first.  g lives in window [0, nf) of gbuf
         gbuf = ghcat
-        for site, (inp, outp) in zip(reversed(self.ups), reversed(saved["up_io"])):
+        for u in reversed(range(len(self.ups))):
+            site, (inp, outp) = self.ups[u], saved["up_io"][u]
             ops.lrelu_bwd_(gbuf, 0, outp, 0, nf, sl)
             self.wgrad(site, inp, 0, gbuf, 0, flat, sp, scratch)
-            fine = self._empty((B, inp.shape[1] * 2, inp.shape[2] * 2, nz, nf), g_out)
-            self.dgrad(site, gbuf, 0, fine, 0, tuple(inp.shape[1:4]))
             gin = self._empty(inp.shape, g_out)
-            ops.upsample2_bwd(fine, gin)
+            if self.subpixel_active(u):
+                self.up_dgrad(u, gbuf, gin)
+            else:
+                fine = self._empty((B, inp.shape[1] * 2, inp.shape[2] * 2, nz, nf), g_out)
+                self.dgrad(site, gbuf, 0, fine, 0, tuple(inp.shape[1:4]))
+                ops.upsample2_bwd(fine, gin)
+                del fine
             ready(site.weight)
-            del fine
             gbuf = gin
         if not self.ups:
             gs = self._empty((B, X, Y, nz, nf), g_out)

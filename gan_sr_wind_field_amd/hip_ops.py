@@ -85,8 +85,13 @@ class ConvGeom:
 
 
 def make_desc(g: ConvGeom, dt: torch.dtype, B: int, in_xyz, in_ctot: int, in_off: int, out_ctot: int,
-              out_off: int, cin: Optional[int] = None, cout: Optional[int] = None) -> ConvDesc:
+              out_off: int, cin: Optional[int] = None, cout: Optional[int] = None, lat=None) -> ConvDesc:
+    """``lat`` = (ox, oy, phases): a parity conv of the sub-pixel form of an up-sampling conv (``wsr_conv_t.lat``) -
+    same-size, ``g.pad`` = the LOW pads, output voxels on the (2x + ox, 2y + oy) lattice of a tensor twice as large
+    along x and y; phases = 4: all four parities in one forward launch."""
     xo, yo, zo = g.out_extent(*in_xyz)
+    if lat is not None:
+        xo, yo = in_xyz[0], in_xyz[1]
     d = ConvDesc()
     d.dtype = dtype_id(dt)
     d.B = B
@@ -98,6 +103,8 @@ def make_desc(g: ConvGeom, dt: torch.dtype, B: int, in_xyz, in_ctot: int, in_off
     d.sx, d.sy, d.sz = g.stride
     d.px, d.py, d.pz = g.pad
     d.upsample_xy = 1 if g.upsample else 0
+    if lat is not None:
+        d.lat, d.lat_ox, d.lat_oy, d.lat_phases = 2, lat[0], lat[1], lat[2]
     return d
 
 
@@ -398,6 +405,29 @@ def upsample2_bwd(dy: Tensor, dx: Tensor) -> Tensor:
     check(_lib.lib().wsr_upsample2_bwd(_p(dy), _p(dx), B, X, Y, Z, C_, dtype_id(dx.dtype), _stream()),
           "upsample2_bwd")
     return dx
+
+
+def subpixel_fold(w: Tensor, wp: Tensor) -> Tensor:
+    """master fp32 (Cout, Cin, 3, 3, KZ) -> the four parity filters (4, Cout, Cin, 2, 2, KZ) of the sub-pixel form of
+    nearest x(2,2,1) + conv (``wsr_subpixel_fold``)."""
+    _need_cuda(w, wp)
+    cout, cin, kx, ky, kz = w.shape
+    if (kx, ky) != (3, 3) or tuple(wp.shape) != (4, cout, cin, 2, 2, kz) or not (w.is_contiguous() and wp.is_contiguous()) \
+            or w.dtype != torch.float32 or wp.dtype != torch.float32:
+        raise ValueError("subpixel_fold: fp32 (Cout, Cin, 3, 3, KZ) -> (4, Cout, Cin, 2, 2, KZ)")
+    check(_lib.lib().wsr_subpixel_fold(_p(w), _p(wp), cout * cin, kz, _stream()), "subpixel_fold")
+    return wp
+
+
+def subpixel_unfold(dwp: Tensor, dw: Tensor) -> Tensor:
+    """adjoint of :func:`subpixel_fold`: parity filter gradients (4, Cout, Cin, 2, 2, KZ) -> (Cout, Cin, 3, 3, KZ)"""
+    _need_cuda(dwp, dw)
+    cout, cin, kx, ky, kz = dw.shape
+    if (kx, ky) != (3, 3) or tuple(dwp.shape) != (4, cout, cin, 2, 2, kz) or not (dw.is_contiguous() and dwp.is_contiguous()) \
+            or dw.dtype != torch.float32 or dwp.dtype != torch.float32:
+        raise ValueError("subpixel_unfold: fp32 (4, Cout, Cin, 2, 2, KZ) -> (Cout, Cin, 3, 3, KZ)")
+    check(_lib.lib().wsr_subpixel_unfold(_p(dwp), _p(dw), cout * cin, kz, _stream()), "subpixel_unfold")
+    return dw
 
 
 class _WindGradient(torch.autograd.Function):

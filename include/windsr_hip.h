@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define WSR_ABI_VERSION 2
+#define WSR_ABI_VERSION 3
 
 enum wsr_dtype { WSR_F32 = 0, WSR_BF16 = 1 };
 
@@ -53,6 +53,15 @@ typedef struct wsr_conv {
   int32_t px, py, pz;            /* zero padding                                  */
   int32_t upsample_xy;           /* 1: input is read through nearest x(2,2,1)
                                     up-sampling (torch_blocks.py:345-347)        */
+  /* Sub-pixel form of that up-sampling conv (tile entry points only; all zero = none).  Nearest x(2,2,1)
+   * followed by a 3x3xKZ conv equals four 2x2xKZ convs on the un-sampled input, one per output parity (a, b):
+   * 4/9 of the multiply-adds (filters from wsr_subpixel_fold).  lat = 2 marks such a parity conv: a same-size
+   * conv (Xo = Xi, Yo = Yi, stride 1, low pads px / py, high pads K-1-p) whose OUTPUT voxel (x, y, z) is voxel
+   * (2x + lat_ox, 2y + lat_oy, z) of a tensor of extent (2Xo, 2Yo, Zo) - y in the forward pass, dy in the
+   * input / filter gradient.  lat_phases = 4 (wsr_conv3d_fwd_tile only): all four parities in ONE launch -
+   * parity (a, b) runs with low pads (px - a, py - b), lattice offsets (a, b) and the fragment filter at
+   * wfrag + (2a + b) * wsr_frag_filter_elems(Cout, Cin, taps).                                          */
+  int32_t lat, lat_ox, lat_oy, lat_phases;
 } wsr_conv_t;
 
 /* Fused epilogue:  v = conv (+ bias[c]);  v = lrelu(v, slope) if act;
@@ -218,6 +227,16 @@ int wsr_chan_sum(const void* x, int32_t x_ctot, int32_t x_off, int32_t C, int64_
 /* backward of nearest x(2,2,1) up-sampling: dx[b,x,y,z,c] = sum of the 4 dy    */
 int wsr_upsample2_bwd(const void* dy, void* dx, int32_t B, int32_t Xi, int32_t Yi, int32_t Zi,
                       int32_t C, int32_t dtype, void* stream);
+/* Filters of the sub-pixel form of an up-sampling conv (wsr_conv_t.lat): master fp32 w (n, 3, 3, KZ), n =
+ * Cout*Cin, -> wp (4, n, 2, 2, KZ), parity (a, b) at index 2a + b:
+ *   wp[2a+b][f][i][j][kz] = sum over kx in S_a(i), ky in S_b(j) of w[f][kx][ky][kz],
+ *   S_0(0) = {0}, S_0(1) = {1, 2} (input offsets -1, 0);  S_1(0) = {0, 1}, S_1(1) = {2} (offsets 0, +1)
+ * - the taps of the 3x3 filter that read the same un-sampled voxel, summed in fp32 (torch_blocks.py:345-347:
+ * nn.Upsample(scale_factor=(2,2,1), mode="nearest") in front of the conv).  _unfold is the adjoint:
+ * dw[f][kx][ky][kz] = sum over (a, b, i, j) with kx in S_a(i), ky in S_b(j) of dwp[2a+b][f][i][j][kz]
+ * (dw is overwritten).                                                                                  */
+int wsr_subpixel_fold(const float* w, float* wp, int64_t n, int32_t KZ, void* stream);
+int wsr_subpixel_unfold(const float* dwp, float* dw, int64_t n, int32_t KZ, void* stream);
 /* planar fp32 (B,C,X,Y,Z) <-> NDHWC `dtype` window; c_fill >= C channels are
  * written, those beyond C with zeros                                           */
 int wsr_planar_to_ndhwc(const float* src, void* dst, int32_t B, int32_t C, int64_t vox_per_b,

@@ -141,6 +141,95 @@ def test_upconv_fused_upsample(golden, hip, dt):
     assert rel_l2(dw.cpu(), dw_ref) < tol_w
 
 
+def _subpixel_sets(a, i):
+    """taps of the 3-wide filter that read un-sampled offset i of output parity a (wsr_subpixel_fold)"""
+    return ([0], [1, 2])[i] if a == 0 else ([0, 1], [2])[i]
+
+
+def test_subpixel_fold_and_adjoint(hip):
+    """wsr_subpixel_fold against its definition; wsr_subpixel_unfold is its adjoint (and exact on fold outputs)."""
+    o = ops()
+    torch.manual_seed(5)
+    w = torch.randn(6, 5, 3, 3, 3)
+    ref = torch.zeros(4, 6, 5, 2, 2, 3)
+    for a in range(2):
+        for b in range(2):
+            for i in range(2):
+                for j in range(2):
+                    for kx in _subpixel_sets(a, i):
+                        for ky in _subpixel_sets(b, j):
+                            ref[2 * a + b, :, :, i, j] += w[:, :, kx, ky]
+    wp = torch.empty(4, 6, 5, 2, 2, 3, device=DEV)
+    o.subpixel_fold(w.to(DEV), wp)
+    assert rel_l2(wp.cpu(), ref) < 1e-6
+    g = torch.randn(4, 6, 5, 2, 2, 3)
+    dw = torch.empty(6, 5, 3, 3, 3, device=DEV)
+    o.subpixel_unfold(g.to(DEV), dw)
+    lhs, rhs = float((ref * g).sum()), float((w * dw.cpu()).sum())
+    assert abs(lhs - rhs) <= 1e-4 * abs(lhs)
+
+
+@pytest.mark.parametrize("batched", [True, False])
+@pytest.mark.parametrize("shape", [(2, 32, 48, 8, 16, 16), (1, 16, 16, 5, 7, 10), (1, 128, 128, 8, 8, 32)])
+def test_subpixel_upconv_forward_and_dgrad(hip, shape, batched):
+    """Sub-pixel form of nearest x(2,2,1) + 3x3x3 conv (+bias, LeakyReLU) on the tile kernels: four 2x2x3 parity
+    convs on the un-sampled input (reference torch_blocks.py:345-347).  Against the fp32 CPU conv of the up-sampled
+    bf16-rounded input with the master filter (1e-2: the parity filters are bf16 roundings of tap SUMS) and against
+    the same parity convs evaluated in fp32 on the CPU with the same rounded filters (4e-3: output rounding only);
+    the input gradient (four accumulating launches on the output-gradient lattices) against autograd."""
+    o = ops()
+    B, cin, cout, X, Y, Z = shape
+    dt = torch.bfloat16
+    torch.manual_seed(11)
+    x = torch.randn(B, cin, X, Y, Z).to(dt).float()
+    w = torch.randn(cout, cin, 3, 3, 3) / math.sqrt(27 * cin)
+    bias = torch.randn(cout) * 0.1
+    xb = to_ndhwc(x, cin, 0, dt)
+    wp = torch.empty(4, cout, cin, 2, 2, 3, device=DEV)
+    o.subpixel_fold(w.to(DEV), wp)
+    n = o.frag_filter_elems(wp[0], False)
+    frag = torch.empty(4 * n, dtype=dt, device=DEV)
+    for ph in range(4):
+        o.pack_filter_frag(wp[ph], out=frag[ph * n:(ph + 1) * n])
+    ctot = cout + 8  # the last up-conv writes a window of the wider concat buffer
+    yb = torch.full((B, 2 * X, 2 * Y, Z, ctot), float("nan"), dtype=dt, device=DEV)
+    bd = bias.to(DEV)
+    if batched:
+        d = o.make_desc(o.ConvGeom(cin, cout, (2, 2, 3), (1, 1, 1), (1, 1, 1)), dt, B, (X, Y, Z), cin, 0, ctot, 0,
+                        lat=(0, 0, 4))
+        assert o.conv_fwd_tile(d, xb, frag, yb, bias=bd, act=True, slope=0.2)
+    else:
+        for ph in range(4):
+            a, b = ph >> 1, ph & 1
+            d = o.make_desc(o.ConvGeom(cin, cout, (2, 2, 3), (1, 1, 1), (1 - a, 1 - b, 1)), dt, B, (X, Y, Z), cin, 0,
+                            ctot, 0, lat=(a, b, 0))
+            assert o.conv_fwd_tile(d, xb, frag[ph * n:(ph + 1) * n], yb, bias=bd, act=True, slope=0.2)
+    y = from_ndhwc(yb, 0, cout)
+    assert torch.isnan(yb[..., cout:].float()).all()  # nothing outside the window was written
+    xr = x.clone().requires_grad_(True)
+    up = F.interpolate(xr, scale_factor=(2, 2, 1), mode="nearest")
+    y_ref = F.leaky_relu(F.conv3d(up, w, bias, padding=1), 0.2)
+    assert rel_l2(y, y_ref.detach()) < 1e-2
+    wpr = wp.cpu().to(dt).float()
+    y_par = torch.empty_like(y_ref)
+    for ph in range(4):
+        a, b = ph >> 1, ph & 1
+        xp = F.pad(x, (1, 1, 1 - b, b, 1 - a, a))
+        y_par[:, :, a::2, b::2] = F.leaky_relu(F.conv3d(xp, wpr[ph], bias), 0.2)
+    assert rel_l2(y, y_par.detach()) < 4e-3
+    # input gradient
+    gy = torch.randn_like(y_ref).to(dt).float()
+    (dx_ref,) = torch.autograd.grad(F.conv3d(up, w, None, padding=1), xr, gy)
+    gb = to_ndhwc(gy, ctot, 0, dt)
+    dxb = torch.full((B, X, Y, Z, cin), float("nan"), dtype=dt, device=DEV)
+    for ph in range(4):
+        a, b = ph >> 1, ph & 1
+        d = o.make_desc(o.ConvGeom(cin, cout, (2, 2, 3), (1, 1, 1), (1 - a, 1 - b, 1)), dt, B, (X, Y, Z), cin, 0,
+                        ctot, 0, lat=(a, b, 0))
+        assert o.conv_dgrad_tile(d, gb, o.pack_filter_frag(wp[ph].contiguous(), transpose=True), dxb, accumulate=ph > 0)
+    assert rel_l2(from_ndhwc(dxb, 0, cin), dx_ref) < 1.5e-2
+
+
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
 def test_epilogue_residual_dropout_planar(hip, dt):
     """bias + LReLU + channel scale + alpha*v + beta*res, NDHWC and planar outputs."""
