@@ -17,7 +17,7 @@ WSR_F32, WSR_BF16 = 0, 1
 WSR_EUNSUPPORTED = -2
 
 EXPORTS = [
-    "wsr_abi_version", "wsr_error_string", "wsr_conv3d_fwd", "wsr_conv3d_dgrad", "wsr_conv3d_wgrad", "wsr_conv3d_wgrad_tri", "wsr_conv3d_wgrad_nparts", "wsr_conv3d_wgrad_parts", "wsr_unpack_wgrad_reduce_multi", "wsr_conv3d_fwd_tile", "wsr_conv3d_dgrad_tile",
+    "wsr_abi_version", "wsr_error_string", "wsr_conv3d_fwd", "wsr_conv3d_dgrad", "wsr_conv3d_wgrad", "wsr_conv3d_wgrad_tri", "wsr_conv3d_wgrad_nparts", "wsr_conv3d_wgrad_parts", "wsr_unpack_wgrad_reduce_multi", "wsr_conv3d_fwd_tile", "wsr_conv3d_dgrad_tile", "wsr_conv_tile_workspace",
     "wsr_frag_filter_elems", "wsr_pack_filter_frag", "wsr_pack_filter_frag_multi",
     "wsr_pack_filter", "wsr_unpack_wgrad", "wsr_unpack_wgrad_multi", "wsr_lrelu_bwd_inplace", "wsr_chan_axpby", "wsr_chan_sum", "wsr_upsample2_bwd", "wsr_subpixel_fold", "wsr_subpixel_unfold",
     "wsr_planar_to_ndhwc", "wsr_ndhwc_to_planar", "wsr_zfold", "wsr_zunfold", "wsr_wind_gradient", "wsr_wind_gradient_bwd", "wsr_plane_sum", "wsr_physics_loss_workspace_floats", "wsr_physics_loss_stats", "wsr_physics_loss_bwd", "wsr_bn_stats", "wsr_bn_mean", "wsr_bn_finalize", "wsr_bn_apply_lrelu", "wsr_bn_bwd_reduce",
@@ -83,6 +83,7 @@ def lib() -> C.CDLL:
         "wsr_unpack_wgrad_reduce_multi": [vp, i32, vp],
         "wsr_conv3d_fwd_tile": [C.POINTER(ConvDesc), vp, vp, vp, C.POINTER(Epilogue), vp],
         "wsr_conv3d_dgrad_tile": [C.POINTER(ConvDesc), vp, vp, vp, f32, C.c_int, C.c_int, C.POINTER(LreluMask), vp],
+        "wsr_conv_tile_workspace": [vp, i64],
         "wsr_pack_filter_frag": [vp, vp, i32, i32, i32, i32, i32, i32, vp],
         "wsr_pack_filter_frag_multi": [vp, i32, vp],
         "wsr_pack_filter": [vp, vp, i32, i32, i32, i32, i32, i32, vp],

@@ -144,7 +144,55 @@ __global__ void pack_frag_multi_kernel(const wsr_pack_job_t* __restrict__ jobs) 
   }
 }
 
+// Second pass of a split-reduction launch: out[v, c] = alpha * act(sum_s part[s][v][c] + bias[c]), splits added in
+// index order (bit-reproducible); one thread per voxel x 4 channels, coalesced on both sides.
+__global__ void splitk_reduce_kernel(const float* __restrict__ part, long part_stride, int ksplit, int cpad,
+                                     unsigned short* __restrict__ out, int out_ctot, int out_off, int Cout, long nvox,
+                                     const float* __restrict__ bias, int act, float slope, float alpha) {
+  const int c4n = Cout >> 2;
+  const long total = nvox * c4n;
+  for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(idx % c4n) * 4;
+    const long v = idx / c4n;
+    const float* p = part + v * cpad + c;
+    float4 s = *reinterpret_cast<const float4*>(p);
+    for (int k = 1; k < ksplit; ++k) {
+      const float4 t = *reinterpret_cast<const float4*>(p + (long)k * part_stride);
+      s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
+    }
+    if (bias) { s.x += bias[c]; s.y += bias[c + 1]; s.z += bias[c + 2]; s.w += bias[c + 3]; }
+    if (act) {
+      s.x = s.x > 0.f ? s.x : s.x * slope; s.y = s.y > 0.f ? s.y : s.y * slope;
+      s.z = s.z > 0.f ? s.z : s.z * slope; s.w = s.w > 0.f ? s.w : s.w * slope;
+    }
+    s.x *= alpha; s.y *= alpha; s.z *= alpha; s.w *= alpha;
+    st4<BF16>(out + v * out_ctot + out_off + c, s);
+  }
+}
+
+void* g_ct_ws = nullptr;  // caller's split-reduction workspace (wsr_conv_tile_workspace)
+long g_ct_ws_bytes = 0;
+
 }  // namespace
+
+int wsr_ct_splitk_reduce(const CtArgs& a, hipStream_t st) {
+  const long nvox = (long)a.B * a.Xo * a.Yo * a.Zo;
+  const long total = nvox * (a.Cout >> 2);
+  long grid = (total + 255) / 256;
+  if (grid > 4096) grid = 4096;
+  hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)grid), dim3(256), 0, st, a.part, a.part_stride, a.ksplit,
+                     a.NT_total * 16, (unsigned short*)a.out, a.out_ctot, a.out_off, a.Cout, nvox, a.bias, a.act,
+                     a.slope, a.alpha);
+  WSR_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int wsr_conv_tile_workspace(void* ws, int64_t bytes) {
+  if (bytes < 0 || (ws == nullptr) != (bytes == 0)) return WSR_EINVAL;
+  g_ct_ws = ws;
+  g_ct_ws_bytes = (long)bytes;
+  return 0;
+}
 
 extern "C" int wsr_pack_filter_frag_multi(const wsr_pack_job_t* jobs_dev, int32_t n_jobs, void* stream) {
   if (!jobs_dev || n_jobs <= 0 || n_jobs > 65535) return WSR_EINVAL;
@@ -208,6 +256,8 @@ static int run_conv_tile(CtArgs& a, int red, hipStream_t st) {
                  ? 1
                  : 0;
   if (a.act == 2 && !(a.vec_ok && (a.Cout & 3) == 0)) return WSR_EUNSUPPORTED;  // vector epilogue only
+  a.ws = g_ct_ws;
+  a.ws_bytes = g_ct_ws_bytes;
   if (a.act_c1 != 0x7FFFFFFF && (a.act_c1 & 3)) return WSR_EINVAL;
   return dispatch_ct(a, tpk, st);
 }

@@ -70,10 +70,22 @@ struct CtArgs {
   // produced lattice offsets (a, b), filter wf + (2a + b) * ph_wstride.
   int il_m, il_ox, il_oy, ol_m, ol_ox, ol_oy, nphase;
   long ph_wstride;
+  // Split reduction (launches with few workgroups and long reductions: the deep layers of the discriminator): the
+  // grid is ksplit times as large, split s contracts chunks [s*cps, (s+1)*cps) and stores its raw fp32 sums to
+  // part + s*part_stride as [voxel][16*NT_total] rows; splitk_reduce_kernel adds the splits in order and applies the
+  // epilogue.  ws / ws_bytes: the caller's workspace (wsr_conv_tile_workspace), NULL = never split.
+  int ksplit, cps;
+  float* part;
+  long part_stride;
+  void* ws;
+  long ws_bytes;
   int prio;    // 1: waves of the second half of the workgroup run the main loop at s_setprio 1 (tuning switch)
   int ablate;  // -DWSR_CT_STAMPS builds, timing only: skip 1 = activation prefetch, 2 = weight prefetch, 4 = LDS reads, 8 = MFMAs
   unsigned long long* stamps;  // -DWSR_CT_STAMPS builds: [workgroup][8] clock samples of wave 0 (else unused)
 };
+
+// adds the ksplit partial images of a split-reduction launch in index order and applies the epilogue (conv_tile.hip)
+int wsr_ct_splitk_reduce(const CtArgs& a, hipStream_t st);
 
 namespace {
 
@@ -139,7 +151,16 @@ void conv_tile_kernel(const CtArgs a) {
   char* Xs = smem + a.off_xs;
   char* Ws = smem + a.off_ws;
 
-  const unsigned bid = (unsigned)xcd_remap(blockIdx.x, gridDim.x);
+  unsigned bid = (unsigned)xcd_remap(blockIdx.x, gridDim.x);
+  int c_begin = 0, nchunks_l = a.nchunks;  // this workgroup's slice of the reduction channels
+  float* part = nullptr;
+  if (a.ksplit > 1) {
+    const unsigned per = gridDim.x / (unsigned)a.ksplit, ksi = bid / per;
+    bid -= ksi * per;
+    c_begin = (int)ksi * a.cps;
+    nchunks_l = min(a.cps, a.nchunks - c_begin);
+    part = a.part + (size_t)ksi * a.part_stride;
+  }
   const unsigned tile = fdiv(bid, a.ngroups, a.mg_ng);
   const int ng = (int)(bid - tile * a.ngroups);
   // the four parity convs of a sub-pixel launch sit side by side in the grid: they gather the same halo (L2)
@@ -183,7 +204,7 @@ void conv_tile_kernel(const CtArgs a) {
       const int tsi = u / NTW, nl = u - tsi * NTW;
       const int ts = st * a.TS + tsi;
       if (ts < a.nts && nt0 + nl < a.NT_total) {
-        const unsigned short* src = wbase + ((size_t)(chunk * a.nts + ts) * a.NT_total + nl) * 512 + lane * 8;
+        const unsigned short* src = wbase + ((size_t)((chunk + c_begin) * a.nts + ts) * a.NT_total + nl) * 512 + lane * 8;
         glds16(src, __builtin_amdgcn_readfirstlane(dst + u * 1024));
       }
     }
@@ -238,8 +259,8 @@ void conv_tile_kernel(const CtArgs a) {
     for (int k = 0; k < XK; ++k) {
       const int u = wave + WAVES * k;
       if (u >= u0 && u < u1) {
-        const bool ok = xoff[k] != 0xFFFFFFFFu && chunk * CK + xo8[VM ? 0 : k] < a.cin_valid;
-        const unsigned short* src = ok ? a.in + (size_t)xoff[k] + chunk * CK
+        const bool ok = xoff[k] != 0xFFFFFFFFu && (chunk + c_begin) * CK + xo8[VM ? 0 : k] < a.cin_valid;
+        const unsigned short* src = ok ? a.in + (size_t)xoff[k] + (chunk + c_begin) * CK
                                        : reinterpret_cast<const unsigned short*>(a.zero16);
         glds16(src, dst + (VM ? u * 1024 : xdst[VM ? 0 : k]));
       }
@@ -291,7 +312,7 @@ void conv_tile_kernel(const CtArgs a) {
 #ifdef WSR_CT_STAMPS
   long long st_dma = 0, st_bar = 0;  // shader cycles this wave spent waiting for its DMAs / at the phase barrier
 #endif
-  const int total_phases = a.nchunks * nstages;
+  const int total_phases = nchunks_l * nstages;
   int chunk = 0, st = 0;
   // static priority for the second-dispatched half (it loses the issue arbitration against the older half on
   // every phase otherwise: MI355X_MICROARCH.md, two waves per SIMD, item 4)
@@ -318,7 +339,7 @@ void conv_tile_kernel(const CtArgs a) {
     skip_w:
       if (a.ablate & 1) return;
 #endif
-      if (a.xbufs == 2 && chunk + 1 < a.nchunks)
+      if (a.xbufs == 2 && chunk + 1 < nchunks_l)
         x_issue(chunk + 1, (chunk + 1) & 1, (HU * st) / nstages, (HU * (st + 1)) / nstages);
     };
 
@@ -407,6 +428,19 @@ void conv_tile_kernel(const CtArgs a) {
     const int gx = x0 + (int)(mv & 255), gy = y0 + (int)((mv >> 8) & 255), gz = z0 + (int)((mv >> 16) & 255);
     const bool ok = !(mv >> 24) && gx < a.Xo && gy < a.Yo && gz < a.Zo;
     mrow[i] = ok ? (long)b * vox_per_b + ((long)(gx * a.ol_m + olx) * oYo + gy * a.ol_m + oly) * a.Zo + gz : -1;
+  }
+  if (part) {  // split reduction: raw sums, [voxel][16*NT_total] fp32 rows; the reduce pass applies the epilogue
+    const int cpad = a.NT_total * 16;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      if (mrow[i] < 0) continue;
+      float* prow = part + mrow[i] * cpad + cob;
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+        if (nt0 + wn * TN + j < a.NT_total)
+          *reinterpret_cast<float4*>(prow + 16 * j) = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+    }
+    return;
   }
   // row base pointers once (64-bit multiply-adds), n-tile offsets are immediates
   unsigned short* orow[TM];
@@ -604,8 +638,28 @@ int launch_ct(CtArgs& a, hipStream_t st) {
   a.stamps = getenv("WSR_CT_STAMPS_PTR") ? (unsigned long long*)strtoull(getenv("WSR_CT_STAMPS_PTR"), nullptr, 0) : nullptr;
 #endif
   a.prio = getenv("WSR_CT_PRIO") ? atoi(getenv("WSR_CT_PRIO")) : 1;  // measured: +1 % on the 144- and 128-wide tiles
-  hipLaunchKernelGGL(kern, dim3((unsigned)(a.ntiles * a.nphase * a.ngroups)), dim3(WAVES * 64), lds, st, a);
+  // Few workgroups and a long reduction (the deep layers of the discriminator: 16..128 workgroups walking
+  // 16..32 chunks x 27..48 taps one after the other, 50-90 us at a few per cent of the chip): split the chunks over
+  // ksplit times as many workgroups; the partial sums go through the caller's workspace.
+  a.ksplit = 1;
+  a.part = nullptr;
+  const int wg = a.ntiles * a.nphase * a.ngroups;
+  if (a.ws && wg <= 128 && a.nchunks >= 4 && a.nphase == 1 && a.ol_m == 1 && !a.res && !a.mask_y && !a.chan_scale &&
+      !a.out_planar && a.act <= 1 && a.act_c1 == 0x7FFFFFFF && (a.Cout & 3) == 0 && a.vec_ok && !getenv("WSR_CT_NOSPLITK")) {
+    int ks = 256 / wg;
+    if (ks > a.nchunks / 2) ks = a.nchunks / 2;
+    if (ks >= 2) {
+      const int cps = (a.nchunks + ks - 1) / ks;
+      ks = (a.nchunks + cps - 1) / cps;
+      const long stride = (long)a.B * a.Xo * a.Yo * a.Zo * a.NT_total * 16;
+      if (ks >= 2 && (long)ks * stride * 4 <= a.ws_bytes) {
+        a.ksplit = ks; a.cps = cps; a.part = (float*)a.ws; a.part_stride = stride;
+      }
+    }
+  }
+  hipLaunchKernelGGL(kern, dim3((unsigned)(wg * a.ksplit)), dim3(WAVES * 64), lds, st, a);
   WSR_LAUNCH_CHECK();
+  if (a.ksplit > 1) return wsr_ct_splitk_reduce(a, st);
   return 0;
 }
 

@@ -98,11 +98,16 @@ __device__ __forceinline__ void dma_wait() { asm volatile("s_waitcnt vmcnt(0)" :
 
 template <int TN> __device__ __forceinline__ int ysw(int v) { return TN <= 4 ? (v >> 1) & 3 : v & 7; }
 
+// DMA units (1 KB) a wave may have to issue per tile for the x / dy image: registers of the resolved source geometry.
+// The accumulator-heavy instantiations (5x5x5, 192 accumulators) get what their 4x4x16 tile needs and no more.
+constexpr int wgt_xk(int spw, int tn) { return spw * tn * 4 >= 192 ? 5 : 6; }
+constexpr int wgt_yk(int spw, int tn) { return spw * tn * 4 >= 192 ? 4 : 5; }
+
 template <int TN, int SPW, int CT, bool Z16>
 __global__ __launch_bounds__(512) void wgrad_tile_kernel(const WgtArgs a) {
   constexpr int WAVES = 8, NT = 512;
   constexpr int XRPU = 32;            // x rows (32 B) per 1 KB DMA unit
-  constexpr int XK = 6, YK = 5;       // DMA units per wave per tile (checked on the host)
+  constexpr int XK = wgt_xk(SPW, TN), YK = wgt_yk(SPW, TN);  // DMA units per wave per tile (checked on the host)
   constexpr int RBY = TN <= 4 ? 128 : 256;  // bytes per dy row
   constexpr int YRPU = 1024 / RBY;          // dy rows per 1 KB DMA unit
   static_assert(TN <= 8, "dy rows hold at most 128 channels");
@@ -365,18 +370,26 @@ __global__ __launch_bounds__(512) void wgrad_tile_kernel(const WgtArgs a) {
       const char* Xs = buf0 + ((it - 1) & 1) * a.buf_bytes;
       const char* Ys = Xs + a.xs_bytes;
       if constexpr (LEAN) {
+        // One x fragment ahead (ring of two): the transposing reads of slot j+1 are in flight during the MFMAs of
+        // slot j; the scheduler is fenced, or it sinks the request back to its use and every slot pays an LDS round
+        // trip (counters before: waves parked at s_waitcnt half of the time).  8.65 -> 8.0 ms on the 5x5x5 144 -> 144
+        // gradient.  Measured and NOT kept: carrying the ring and the dy fragments across K-steps (in-place reload
+        // after the last use: +3 %, a second dy set: spills) - the plain per-K-step form is the fastest.
         for (int ks = 0; ks < ksteps; ++ks) {
           const KP k = kp_of(Xs, Ys, ks);
-          uint4 af[TN];
+          uint4 af[TN], bfr[2];
 #pragma unroll
           for (int i = 0; i < TN; ++i) af[i] = af_of(k, i);
+          bfr[0] = bf_of(k, 0);
 #pragma unroll
           for (int j = 0; j < SPW; ++j) {
-            const uint4 bf = bf_of(k, j);
+            if (j + 1 < SPW) bfr[(j + 1) & 1] = bf_of(k, j + 1);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int i = 0; i < TN; ++i)
               acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, af[i]),
-                                                                  __builtin_bit_cast(bf16x8_t, bf), acc[j][i], 0, 0, 0);
+                                                                  __builtin_bit_cast(bf16x8_t, bfr[j & 1]), acc[j][i], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
           }
         }
       } else {
@@ -506,7 +519,7 @@ int launch_tile(WgtArgs& a, hipStream_t st) {
       if (a.ups && ((tx | ty) & 1)) continue;  // the x0 - px parity must not depend on the tile
       const int L = (tx + a.KX - 1) * (ty + a.KY - 1) * (tz + a.KZ - 1);
       const int xs = CT * round_up(L * 32, 1024), ys = round_up(M * (TN <= 4 ? 128 : 256), 1024);
-      if (xs / 1024 > 6 * WAVES || ys / 1024 > 5 * WAVES || L > 65535) continue;
+      if (xs / 1024 > wgt_xk(SPW, TN) * WAVES || ys / 1024 > wgt_yk(SPW, TN) * WAVES || L > 65535) continue;
       if (round_up(M * 2, 1024) + nbuf * (xs + ys) > 160 * 1024) continue;
       best = ci;
       best_nbuf = nbuf;

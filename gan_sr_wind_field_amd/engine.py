@@ -256,6 +256,7 @@ class ProgramBase:
         """bring the fragment-order filter copies of all tile-kernel convs up to date in one launch"""
         if not (self.use_tile and self.dt == torch.bfloat16):
             return
+        ops.ensure_tile_workspace(self.conv_sites()[0].weight.device)  # split reductions of small launches
         sites = [s for s in self.conv_sites() if self.tile_ok(s)]
         fstack = list(self.stacked_fwd_specs())
         fcov = {id(p) for _, parts, _, _ in fstack for p, *_ in parts}

@@ -124,6 +124,20 @@ def conv_fwd(desc: ConvDesc, x: Tensor, w: Tensor, y: Tensor, *, bias: Optional[
     return y
 
 
+_tile_ws: dict = {}
+
+
+def ensure_tile_workspace(dev, nbytes: int = 32 << 20) -> None:
+    """Give the tile entry points their split-reduction workspace (``wsr_conv_tile_workspace``) once per process:
+    launches with few workgroups and a long reduction (the discriminator's deep layers) then spread the reduction
+    channels over up to 256 workgroups.  The buffer is owned here and lives as long as the process."""
+    if _tile_ws.get("dev") == dev:
+        return
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    check(_lib.lib().wsr_conv_tile_workspace(_p(ws), ws.numel()), "conv_tile_workspace")
+    _tile_ws["dev"], _tile_ws["ws"] = dev, ws
+
+
 def conv_fwd_tile(desc: ConvDesc, x: Tensor, wfrag: Tensor, y: Tensor, *, bias: Optional[Tensor] = None,
                   chan_scale: Optional[Tensor] = None, res: Optional[Tensor] = None, res_off: int = 0,
                   alpha: float = 1.0, beta: float = 0.0, act=False, slope: float = 0.2,

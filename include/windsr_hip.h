@@ -130,6 +130,14 @@ typedef struct wsr_lrelu_mask {
 } wsr_lrelu_mask_t;
 int wsr_conv3d_dgrad_tile(const wsr_conv_t* c, const void* dy, const void* wfrag_t, void* dx, float alpha,
                           int accumulate, int dx_planar, const wsr_lrelu_mask_t* mask, void* stream);
+/* Optional workspace of the tile entry points (device memory, caller-owned; NULL / 0 withdraws it).  With it,
+ * launches that would otherwise run on a few workgroups with a long reduction (the deep layers of the
+ * discriminator, Discriminator_3D.py:66-169: 128..1024 voxels x 256..512 channels x 27..48 taps) split the
+ * reduction channels over up to 256 workgroups; the fp32 partial sums go through the workspace and a second
+ * launch adds them in index order (bit-reproducible) and applies the epilogue.  One workspace per process; the
+ * launches that use it must be stream-ordered with each other.  Results do not depend on its presence beyond
+ * fp32 summation order.                                                                                   */
+int wsr_conv_tile_workspace(void* ws, int64_t bytes);
 int64_t wsr_frag_filter_elems(int32_t rows, int32_t red, int32_t taps);
 int wsr_pack_filter_frag(const float* w, void* out, int32_t Cout, int32_t Cin, int32_t KX, int32_t KY, int32_t KZ,
                          int32_t transpose, void* stream);

@@ -141,6 +141,69 @@ def test_upconv_fused_upsample(golden, hip, dt):
     assert rel_l2(dw.cpu(), dw_ref) < tol_w
 
 
+@pytest.mark.parametrize("case", [
+    # (cin, cout, kernel, stride, pad, xyz, bias, act): the discriminator's deep layers at the benchmark's size
+    (256, 256, (4, 4, 3), (2, 2, 2), (1, 1, 1), (8, 8, 64), False, False),   # features.4.1.0 -> 4x4x32
+    (256, 256, (3, 3, 3), (1, 1, 1), (1, 1, 1), (8, 8, 64), False, False),   # features.4.0.0
+    (256, 256, (4, 4, 3), (2, 2, 1), (1, 1, 1), (16, 16, 64), True, True),   # features.3.1.0 -> 8x8x64 (+bias, act)
+    (128, 64, (3, 3, 3), (1, 1, 1), (1, 1, 1), (6, 5, 7), True, True),
+])
+def test_split_reduction_matches_single_pass(hip, case):
+    """Launches with few workgroups and long reductions split the reduction channels over more workgroups when the
+    caller provides a workspace (wsr_conv_tile_workspace): same result as the single-pass launch up to the fp32
+    summation order (both sides round the same sums to bf16 once: 2e-3), forward and input gradient, and as the fp32
+    CPU conv of the same bf16-rounded operands (4e-3); two split launches are bit-identical."""
+    o = ops()
+    cin, cout, k, st, pad, xyz, has_bias, act = case
+    dt = torch.bfloat16
+    torch.manual_seed(3)
+    B = 1
+    x = torch.randn(B, cin, *xyz).to(dt).float()
+    w = (torch.randn(cout, cin, *k) / math.sqrt(cin * k[0] * k[1] * k[2])).to(dt).float()
+    bias = torch.randn(cout) * 0.1 if has_bias else None
+    geom = o.ConvGeom(cin, cout, k, st, pad)
+    d = o.make_desc(geom, dt, B, xyz, cin, 0, cout, 0)
+    oxyz = (d.Xo, d.Yo, d.Zo)
+    xb = to_ndhwc(x, cin, 0, dt)
+    wf = o.pack_filter_frag(w.to(DEV))
+    bd = bias.to(DEV) if has_bias else None
+    ys = []
+    for ws in (False, True, True):
+        if ws:
+            o._tile_ws.clear()
+            o.ensure_tile_workspace(torch.device(DEV))
+        else:
+            assert hip.wsr_conv_tile_workspace(None, 0) == 0
+            o._tile_ws.clear()
+        yb = torch.full((B,) + oxyz + (cout,), float("nan"), dtype=dt, device=DEV)
+        assert o.conv_fwd_tile(d, xb, wf, yb, bias=bd, act=act, slope=0.2)
+        ys.append(from_ndhwc(yb, 0, cout))
+    y_ref = F.conv3d(x, w, bias, stride=st, padding=pad)
+    if act:
+        y_ref = F.leaky_relu(y_ref, 0.2)
+    assert rel_l2(ys[0], y_ref) < 4e-3 and rel_l2(ys[1], y_ref) < 4e-3
+    assert rel_l2(ys[1], ys[0]) < 2e-3
+    assert torch.equal(ys[1], ys[2])
+    if st == (1, 1, 1):  # input gradient on the tile kernel (stride 1)
+        gy = torch.randn(B, cout, *oxyz).to(dt).float()
+        gb = to_ndhwc(gy, cout, 0, dt)
+        wft = o.pack_filter_frag(w.to(DEV), transpose=True)
+        dxs = []
+        for ws in (False, True):
+            if ws:
+                o.ensure_tile_workspace(torch.device(DEV))
+            else:
+                assert hip.wsr_conv_tile_workspace(None, 0) == 0
+                o._tile_ws.clear()
+            dxb = torch.full((B,) + xyz + (cin,), float("nan"), dtype=dt, device=DEV)
+            assert o.conv_dgrad_tile(d, gb, wft, dxb, alpha=0.5)
+            dxs.append(from_ndhwc(dxb, 0, cin))
+        xr = x.clone().requires_grad_(True)
+        (dx_ref,) = torch.autograd.grad(F.conv3d(xr, w, None, stride=st, padding=pad), xr, gy)
+        assert rel_l2(dxs[0], 0.5 * dx_ref) < 4e-3 and rel_l2(dxs[1], 0.5 * dx_ref) < 4e-3
+    o.ensure_tile_workspace(torch.device(DEV))
+
+
 def _subpixel_sets(a, i):
     """taps of the 3-wide filter that read un-sampled offset i of output parity a (wsr_subpixel_fold)"""
     return ([0], [1, 2])[i] if a == 0 else ([0, 1], [2])[i]
