@@ -98,9 +98,11 @@ static inline int conv_geom_ok(const wsr_conv_t* c) {
     if ((unsigned)c->lat_ox > 1u || (unsigned)c->lat_oy > 1u || (c->lat_phases != 0 && c->lat_phases != 4)) return 0;
     if (c->Xo != c->Xi || c->Yo != c->Yi || c->px >= c->KX || c->py >= c->KY) return 0;
     if (c->lat_phases == 4 && (c->px < 1 || c->py < 1 || c->lat_ox || c->lat_oy)) return 0;
-    return c->Zi + 2 * c->pz - c->KZ + 1 == c->Zo;
+    if (c->lat_mz != 0 && c->lat_mz != 1 && c->lat_mz != 2) return 0;
+    if (c->lat_oz < 0 || c->lat_oz >= (c->lat_mz > 1 ? c->lat_mz : 1)) return 0;
+    return c->Zo == c->Zi && c->pz < c->KZ;
   }
-  if (c->lat_ox | c->lat_oy | c->lat_phases) return 0;
+  if (c->lat_ox | c->lat_oy | c->lat_phases | c->lat_mz | c->lat_oz) return 0;
   const int ux = c->upsample_xy ? 2 : 1;
   if ((c->Xi * ux + 2 * c->px - c->KX) / c->sx + 1 != c->Xo) return 0;
   if ((c->Yi * ux + 2 * c->py - c->KY) / c->sy + 1 != c->Yo) return 0;

@@ -305,6 +305,7 @@ extern "C" int wsr_conv3d_fwd_tile(const wsr_conv_t* c, const void* x, const voi
   if (c->lat) {  // parity conv(s) of a sub-pixel up-sampling conv: y is written on the (2x + ox, 2y + oy) lattice
     if (a.res || a.out_planar) return WSR_EUNSUPPORTED;
     a.ol_m = 2; a.ol_ox = c->lat_ox; a.ol_oy = c->lat_oy;
+    a.ol_mz = c->lat_mz > 1 ? c->lat_mz : 1; a.ol_oz = c->lat_oz;
     a.nphase = c->lat_phases == 4 ? 4 : 1;
     a.ph_wstride = (long)wsr_frag_filter_elems(c->Cout, c->Cin, c->KX * c->KY * c->KZ);
   }
@@ -356,7 +357,7 @@ extern "C" int wsr_conv3d_dgrad_tile(const wsr_conv_t* c, const void* dy, const 
   a.KX = c->KX; a.KY = c->KY; a.KZ = c->KZ;
   a.px = c->KX - 1 - c->px; a.py = c->KY - 1 - c->py; a.pz = c->KZ - 1 - c->pz;
   if (c->lat) {  // parity conv of a sub-pixel up-sampling conv: dy is read on the (2x + ox, 2y + oy) lattice
-    if (c->lat_phases) return WSR_EUNSUPPORTED;  // the parities add into the same dx: one launch each
+    if (c->lat_phases || c->lat_mz > 1) return WSR_EUNSUPPORTED;  // the parities add into the same dx: one launch each
     a.il_m = 2; a.il_ox = c->lat_ox; a.il_oy = c->lat_oy;
   }
   if (mask && mask->chan_scale) a.chan_scale = mask->chan_scale;

@@ -69,6 +69,7 @@ struct CtArgs {
   // nphase = 4: the four parity convs in one launch - parity (a, b) = bits of the tile index: pads (px - a, py - b),
   // produced lattice offsets (a, b), filter wf + (2a + b) * ph_wstride.
   int il_m, il_ox, il_oy, ol_m, ol_ox, ol_oy, nphase;
+  int ol_mz, ol_oz;  // the same for the produced tensor's z axis (input gradients of z-strided convs)
   long ph_wstride;
   // Split reduction (launches with few workgroups and long reductions: the deep layers of the discriminator): the
   // grid is ksplit times as large, split s contracts chunks [s*cps, (s+1)*cps) and stores its raw fp32 sums to
@@ -417,8 +418,8 @@ void conv_tile_kernel(const CtArgs a) {
   // every tile would pay a full memory round trip).  The n-tiles are walked one at a time; the operands
   // of n-tile j+1 (bias, channel scale, residual and mask values of its TM rows) are fetched before the
   // stores of n-tile j are issued.
-  const long vox_per_b = (long)a.Xo * a.Yo * a.Zo * (a.ol_m * a.ol_m);
-  const int olx = a.ol_ox + pha, oly = a.ol_oy + phb, oYo = a.Yo * a.ol_m;
+  const long vox_per_b = (long)a.Xo * a.Yo * a.Zo * (a.ol_m * a.ol_m * a.ol_mz);
+  const int olx = a.ol_ox + pha, oly = a.ol_oy + phb, oYo = a.Yo * a.ol_m, oZo = a.Zo * a.ol_mz;
   const int cob = (nt0 + wn * TN) * 16 + fg * 4;  // this lane's first channel of n-tile j is cob + 16*j
   const bool fast = a.vec_ok && !a.out_planar && (a.Cout & 3) == 0 && (a.mask_c1 & 3) == 0;
   long mrow[TM];   // flat output voxel of row `fr` of m-tile i, or -1
@@ -427,7 +428,9 @@ void conv_tile_kernel(const CtArgs a) {
     const unsigned mv = mtab[(wm * TM + i) * 16 + fr];
     const int gx = x0 + (int)(mv & 255), gy = y0 + (int)((mv >> 8) & 255), gz = z0 + (int)((mv >> 16) & 255);
     const bool ok = !(mv >> 24) && gx < a.Xo && gy < a.Yo && gz < a.Zo;
-    mrow[i] = ok ? (long)b * vox_per_b + ((long)(gx * a.ol_m + olx) * oYo + gy * a.ol_m + oly) * a.Zo + gz : -1;
+    mrow[i] = ok ? (long)b * vox_per_b + ((long)(gx * a.ol_m + olx) * oYo + gy * a.ol_m + oly) * oZo +
+                       gz * a.ol_mz + a.ol_oz
+                 : -1;
   }
   if (part) {  // split reduction: raw sums, [voxel][16*NT_total] fp32 rows; the reduce pass applies the epilogue
     const int cpad = a.NT_total * 16;
@@ -571,8 +574,9 @@ int launch_ct(CtArgs& a, hipStream_t st) {
   if (a.sx < 1) a.sx = a.sy = a.sz = 1;
   if (a.il_m < 1) a.il_m = 1;
   if (a.ol_m < 1) a.ol_m = 1;
+  if (a.ol_mz < 1) a.ol_mz = 1;
   if (a.nphase != 4) a.nphase = 1;
-  if ((a.il_m > 1 || a.ol_m > 1 || a.nphase > 1) && (a.ups || a.sx != 1 || a.sy != 1 || a.sz != 1)) return WSR_EUNSUPPORTED;
+  if ((a.il_m > 1 || a.ol_m > 1 || a.ol_mz > 1 || a.nphase > 1) && (a.ups || a.sx != 1 || a.sy != 1 || a.sz != 1)) return WSR_EUNSUPPORTED;
   const int L = ((a.TX - 1) * a.sx + a.KX) * ((a.TY - 1) * a.sy + a.KY) * ((a.TZ - 1) * a.sz + a.KZ);
   if (L > 65535) return WSR_EUNSUPPORTED;
   a.nts = (taps + TPK - 1) / TPK;
@@ -644,7 +648,7 @@ int launch_ct(CtArgs& a, hipStream_t st) {
   a.ksplit = 1;
   a.part = nullptr;
   const int wg = a.ntiles * a.nphase * a.ngroups;
-  if (a.ws && wg <= 128 && a.nchunks >= 4 && a.nphase == 1 && a.ol_m == 1 && !a.res && !a.mask_y && !a.chan_scale &&
+  if (a.ws && wg <= 128 && a.nchunks >= 4 && a.nphase == 1 && a.ol_m == 1 && a.ol_mz == 1 && !a.res && !a.mask_y && !a.chan_scale &&
       !a.out_planar && a.act <= 1 && a.act_c1 == 0x7FFFFFFF && (a.Cout & 3) == 0 && a.vec_ok && !getenv("WSR_CT_NOSPLITK")) {
     int ks = 256 / wg;
     if (ks > a.nchunks / 2) ks = a.nchunks / 2;

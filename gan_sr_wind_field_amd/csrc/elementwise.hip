@@ -85,8 +85,24 @@ __global__ __launch_bounds__(256) void unpack_reduce_multi_kernel(const wsr_unpa
       const float* p = j.src + ((long)n * j.taps + tap) * j.kpad + c0 + c4;
       float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
       if (vec && c0 + c4 + 4 <= j.kpad) {  // (the row is kpad long: reading past Cin inside it is harmless)
-#pragma unroll 4
-        for (int s = 0; s < nparts; ++s) {
+        // eight copies in flight per thread (the copies are megabytes apart: every load is an HBM round trip), added
+        // in index order
+        int s = 0;
+        for (; s + 8 <= nparts; s += 8) {
+          float4 v[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const float4*>(p + (long)(s + u) * j.part_stride);
+#pragma unroll
+          for (int u = 0; u < 8; ++u) { a.x += v[u].x; a.y += v[u].y; a.z += v[u].z; a.w += v[u].w; }
+        }
+        for (; s + 4 <= nparts; s += 4) {
+          float4 v[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const float4*>(p + (long)(s + u) * j.part_stride);
+#pragma unroll
+          for (int u = 0; u < 4; ++u) { a.x += v[u].x; a.y += v[u].y; a.z += v[u].z; a.w += v[u].w; }
+        }
+        for (; s < nparts; ++s) {
           const float4 v = *reinterpret_cast<const float4*>(p + (long)s * j.part_stride);
           a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
         }
@@ -184,6 +200,25 @@ __global__ void upsample2_bwd_kernel(const typename T::elem* dy, typename T::ele
 __device__ __forceinline__ void subpixel_set(int a, int i, int& lo, int& hi) {
   lo = a == 0 ? (i == 0 ? 0 : 1) : (i == 0 ? 0 : 2);
   hi = a == 0 ? (i == 0 ? 0 : 2) : (i == 0 ? 1 : 2);
+}
+
+__global__ void strided_parity_filters_kernel(const float* __restrict__ w, float* __restrict__ out, int Cout, int Cin,
+                                              int sz, int zc) {
+  const int KZp = sz == 1 ? 3 : (zc == 0 ? 1 : 2);
+  const long total = 4l * Cin * Cout * 4 * KZp;
+  for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const int t = (int)(idx % KZp);
+    long q = idx / KZp;
+    const int j = (int)(q & 1), i = (int)((q >> 1) & 1);
+    q >>= 2;
+    const int co = (int)(q % Cout); q /= Cout;
+    const int ci = (int)(q % Cin);
+    const int ph = (int)(q / Cin), a = ph >> 1, b = ph & 1;
+    const int kx = a == 0 ? (i == 0 ? 3 : 1) : (i == 0 ? 2 : 0);
+    const int ky = b == 0 ? (j == 0 ? 3 : 1) : (j == 0 ? 2 : 0);
+    const int kz = sz == 1 ? 2 - t : (zc == 0 ? 1 : (t == 0 ? 2 : 0));
+    out[idx] = w[(((long)co * Cin + ci) * 16 + kx * 4 + ky) * 3 + kz];
+  }
 }
 
 __global__ void subpixel_fold_kernel(const float* __restrict__ w, float* __restrict__ wp, long n, int KZ) {
@@ -753,6 +788,16 @@ extern "C" int wsr_upsample2_bwd(const void* dy, void* dx, int32_t B, int32_t Xi
                                 (const unsigned short*)dy, (unsigned short*)dx, B, Xi, Yi, Zi, C),
              hipLaunchKernelGGL(upsample2_bwd_kernel<F32>, dim3(ew_grid(total)), dim3(EW_BLOCK), 0, as_stream(stream),
                                 (const float*)dy, (float*)dx, B, Xi, Yi, Zi, C));
+  WSR_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int wsr_strided_parity_filters(const float* w, float* out, int32_t Cout, int32_t Cin, int32_t sz, int32_t zc,
+                                          void* stream) {
+  if (!w || !out || Cout <= 0 || Cin <= 0 || (sz != 1 && sz != 2) || zc < 0 || zc >= sz) return WSR_EINVAL;
+  const int KZp = sz == 1 ? 3 : (zc == 0 ? 1 : 2);
+  hipLaunchKernelGGL(strided_parity_filters_kernel, dim3(ew_grid(16l * Cin * Cout * KZp)), dim3(EW_BLOCK), 0,
+                     as_stream(stream), w, out, Cout, Cin, sz, zc);
   WSR_LAUNCH_CHECK();
   return 0;
 }

@@ -45,6 +45,9 @@ POISON_BUFFERS = bool(int(__import__("os").environ.get("WSR_POISON_BUFFERS", "0"
 #: copy and the unpack pass adds the copies in index order - two backward passes give bit-identical gradients
 #: (WSR_DETERMINISTIC=0: one shared copy, float atomics)
 DETERMINISTIC = __import__("os").environ.get("WSR_DETERMINISTIC", "1") != "0"
+#: input gradients of the discriminator's stride-(2,2,s) 4x4x3 convs as parity convs over dy on the tile kernels
+#: (WSR_STRIDED_DGRAD=0: generic implicit-GEMM kernel)
+STRIDED_DGRAD = __import__("os").environ.get("WSR_STRIDED_DGRAD", "1") != "0"
 #: run the up-sampling convs (nearest x(2,2,1) + 3x3x3) in their sub-pixel form: four 2x2x3 parity convs on the
 #: un-sampled input, 4/9 of the multiply-adds (WSR_SUBPIXEL=0: gather through the up-sampling, 27 taps)
 SUBPIXEL = __import__("os").environ.get("WSR_SUBPIXEL", "1") != "0"
@@ -150,6 +153,10 @@ class FilterCache:
     def get_stacked(self, skey) -> Tensor:
         return self._c[(skey, "dstack")][1]
 
+    def drop_tables(self) -> None:
+        """forget the cached pack job tables (their destination pointers): a destination buffer was replaced"""
+        self._tables.clear()
+
     def touch(self) -> None:
         """a source of the packed copies was rewritten behind torch's back (kernel writing through a raw pointer:
         no version bump): the next refresh_frags re-packs"""
@@ -179,6 +186,7 @@ class ConvSite:
     stride: Tuple[int, int, int] = (1, 1, 1)
     pad: Tuple[int, int, int] = (1, 1, 1)
     upsample: bool = False
+    fwd_only: bool = False    # no transposed compute copy is ever needed (parity filters of a strided input gradient)
 
     @property
     def cin(self) -> int:
@@ -260,12 +268,13 @@ class ProgramBase:
         sites = [s for s in self.conv_sites() if self.tile_ok(s)]
         fstack = list(self.stacked_fwd_specs())
         fcov = {id(p) for _, parts, _, _ in fstack for p, *_ in parts}
-        wanted = [(s.weight, False) for s in self.conv_sites() if self.tile_fwd_ok(s) and id(s.weight) not in fcov]
+        wanted = [(s.weight, False) for s in self.conv_sites() if self.tile_fwd_ok(s) and id(s.weight) not in fcov
+                  and (backward or not s.fwd_only)]  # (fwd_only: filters of a backward pass in forward-conv form)
         stacked = fstack
         if backward:
             dstack = list(self.stacked_dgrad_specs())
             covered = {id(p) for _, parts, _, _ in dstack for p, *_ in parts}
-            wanted += [(s.weight, True) for s in sites if id(s.weight) not in covered]
+            wanted += [(s.weight, True) for s in sites if id(s.weight) not in covered and not s.fwd_only]
             stacked = fstack + dstack
         self.filters.refresh_frags(wanted, stacked)
 
@@ -286,6 +295,27 @@ class ProgramBase:
         """forward only: also the stride-2 down-sampling convs of D"""
         return self.tile_ok(s) or (self.use_tile and self.dt == torch.bfloat16 and max(s.stride) <= 2
                                    and not s.upsample)
+
+    def _seed_parity_frags(self, par: Sequence[ConvSite], dev) -> bool:
+        """The forward fragment filters of the four parity convs of one launch must sit in ONE buffer, parity-major
+        (``wsr_conv_t.lat_phases``): seed the cache with views of it, refresh_frags re-packs into them.  True when a
+        new buffer was made."""
+        n = ops.frag_filter_elems(par[0].weight, False)
+        hits = [self.filters._c.get((id(s.weight), "frag", False)) for s in par]
+        if all(h is not None and h[1].device == torch.device(dev) and h[1].numel() == n and
+               h[1].data_ptr() == hits[0][1].data_ptr() + 2 * n * ph for ph, h in enumerate(hits)):
+            return False
+        big = torch.empty(len(par) * n, dtype=torch.bfloat16, device=dev)
+        for ph, s in enumerate(par):
+            self.filters._c[(id(s.weight), "frag", False)] = (None, big[ph * n:(ph + 1) * n])
+        self.filters.drop_tables()  # (cached job tables hold the old destinations)
+        return True
+
+    def _parity_frags(self, par: Sequence[ConvSite]):
+        """(fragment filters of the parity sites, whether they are contiguous parity-major)"""
+        frs = [self.filters.get_frag(s.weight, False) for s in par]
+        n = frs[0].numel()
+        return frs, all(f.data_ptr() == frs[0].data_ptr() + 2 * n * ph for ph, f in enumerate(frs))
 
     def _w(self, s: ConvSite) -> Tensor:
         return self.filters.get(s.weight, self.dt, False, self.cp(s.cin), s.cout)
@@ -698,12 +728,7 @@ class GeneratorProgram(ProgramBase):
                 s.weight = wp[ph]
             self._up_stamp[u] = None
         # the four forward fragment filters share one buffer, parity-major: one launch runs all parities
-        n = ops.frag_filter_elems(par[0].weight, False)
-        hit = self.filters._c.get((id(par[0].weight), "frag", False))
-        if hit is None or hit[1].device != w.device:
-            big = torch.empty(4 * n, dtype=torch.bfloat16, device=w.device)
-            for ph, s in enumerate(par):
-                self.filters._c[(id(s.weight), "frag", False)] = (None, big[ph * n:(ph + 1) * n])
+        if self._seed_parity_frags(par, w.device):
             self._up_stamp[u] = None
         stamp = (w._version, w.data_ptr(), self.filters._gen)
         if stamp != self._up_stamp[u]:
@@ -738,9 +763,7 @@ class GeneratorProgram(ProgramBase):
         par = self.up_parity[u]
         B, xyz = cur.shape[0], tuple(cur.shape[1:4])
         bias = site.bias.detach() if site.bias is not None else None
-        frs = [self.filters.get_frag(s.weight, False) for s in par]
-        n = frs[0].numel()
-        batched = all(f.data_ptr() == frs[0].data_ptr() + 2 * n * ph for ph, f in enumerate(frs))
+        frs, batched = self._parity_frags(par)
 
         def run():
             if batched:  # one launch, parity = two bits of the workgroup index
@@ -1109,6 +1132,87 @@ class DiscriminatorProgram(ProgramBase):
             if l.bn is not None and (l.conv.cout > 256 or 256 % l.conv.cout or l.conv.cout % self.e):
                 raise ValueError(f"BatchNorm3d kernels need a channel count dividing 256 and a multiple of {self.e} "
                                  f"for {dt}; got {l.conv.cout}")
+        # Input gradient of the down-sampling convs (reference torch_blocks.py:372-521: kernel (4,4,3), stride
+        # (2,2,1|2), padding 1) in parity form: input voxel (2m+a, 2n+b, s*l+c) only meets the taps of matching
+        # parity, so dx is written lattice by lattice by 2x2xKZ' forward convs over dy on the tile kernels (one launch
+        # per z class, the four (a, b) parities side by side) instead of the generic gather kernel.  The parity
+        # filters are tap selections of the master filter (wsr_strided_parity_filters), twins like the generator's.
+        self.dparity: Dict[int, list] = {}
+        self._dparity_stamp: Dict[int, object] = {}
+        for li, l in enumerate(self.layers):
+            s = l.conv
+            if li > 0 and s.kernel == (4, 4, 3) and s.pad == (1, 1, 1) and s.stride[:2] == (2, 2) and s.stride[2] in (1, 2) \
+                    and s.cout % 16 == 0 and s.cin % 8 == 0:
+                sz = s.stride[2]
+                groups = []
+                for zc in range(sz):
+                    kzp = 3 if sz == 1 else (1 if zc == 0 else 2)
+                    wp = torch.empty((4, s.cin, s.cout, 2, 2, kzp), dtype=torch.float32, device=s.weight.device)
+                    par = [ConvSite(f"{s.name}.dparity{zc}.{ph}", wp[ph], None, (2, 2, kzp), (1, 1, 1),
+                                    (1 - (ph >> 1), 1 - (ph & 1), 1 if sz == 1 else 0), fwd_only=True) for ph in range(4)]
+                    groups.append([zc, wp, par])
+                self.dparity[li] = groups
+
+    def strided_dgrad_active(self, li: int) -> bool:
+        return STRIDED_DGRAD and li in self.dparity and self.use_tile and self.dt == torch.bfloat16
+
+    def conv_sites(self) -> Sequence[ConvSite]:
+        sites = list(self.all_sites)
+        for li, groups in self.dparity.items():
+            if self.strided_dgrad_active(li):
+                for _, _, par in groups:
+                    sites += par
+        return sites
+
+    def refresh_filters(self, backward: bool) -> None:
+        if backward:
+            for li, groups in self.dparity.items():
+                if not self.strided_dgrad_active(li):
+                    continue
+                w = self.layers[li].conv.weight
+                fresh = False
+                for g in groups:
+                    zc, wp, par = g
+                    if wp.device != w.device:
+                        wp = g[1] = torch.empty_like(wp, device=w.device)
+                        for ph, s in enumerate(par):
+                            s.weight = wp[ph]
+                        fresh = True
+                    fresh = self._seed_parity_frags(par, w.device) or fresh
+                stamp = (w._version, w.data_ptr(), self.filters._gen)
+                if fresh or stamp != self._dparity_stamp.get(li):
+                    for zc, wp, par in groups:
+                        ops.strided_parity_filters(w.detach().contiguous(), wp, self.layers[li].conv.stride[2], zc)
+                    self.filters.touch()
+                    self._dparity_stamp[li] = stamp
+        super().refresh_filters(backward)
+
+    def strided_dgrad(self, li: int, gy: Tensor, gin: Tensor) -> None:
+        """gin (B, X, Y, Z, cin) = input gradient of down-sampling conv ``li`` from gy (B, X/2, Y/2, Z/s, cout)"""
+        s = self.layers[li].conv
+        sz = s.stride[2]
+        B, oxyz = gy.shape[0], tuple(gy.shape[1:4])
+
+        def run():
+            for zc, wp, par in self.dparity[li]:
+                frs, batched = self._parity_frags(par)
+                g = ConvGeom(s.cout, s.cin, par[0].kernel, (1, 1, 1), par[0].pad)
+                if batched:
+                    d = ops.make_desc(g, self.dt, B, oxyz, gy.shape[-1], 0, gin.shape[-1], 0, cin=self.cp(s.cout),
+                                      cout=self.cp(s.cin), lat=(0, 0, 4, sz, zc))
+                    if ops.conv_fwd_tile(d, gy, frs[0], gin):
+                        continue
+                for ph, ps in enumerate(par):
+                    d = ops.make_desc(ConvGeom(s.cout, s.cin, ps.kernel, (1, 1, 1), ps.pad), self.dt, B, oxyz,
+                                      gy.shape[-1], 0, gin.shape[-1], 0, cin=self.cp(s.cout), cout=self.cp(s.cin),
+                                      lat=(ph >> 1, ph & 1, 0, sz, zc))
+                    if not ops.conv_fwd_tile(d, gy, frs[ph], gin):
+                        raise RuntimeError("strided input gradient outside the tile kernels (set WSR_STRIDED_DGRAD=0)")
+
+        if self.launch_probe is not None:
+            self.launch_probe("dgrad:" + s.name, run)
+        else:
+            run()
 
     def forward(self, x: Tensor, training: bool, save: bool):
         """x (B, C, X, Y, Z) planar fp32 -> NDHWC feature tensor (+ saved state)"""
@@ -1235,7 +1339,11 @@ class DiscriminatorProgram(ProgramBase):
                     done = hi
             if li > 0:
                 gin = self._empty(inp.shape, g)
-                self.dgrad(s, gy, 0, gin, 0, tuple(inp.shape[1:4]))
+                if self.strided_dgrad_active(li) and tuple(inp.shape[1:3]) == (2 * gy.shape[1], 2 * gy.shape[2]) \
+                        and inp.shape[3] == s.stride[2] * gy.shape[3] and inp.shape[-1] == self.cp(s.cin):
+                    self.strided_dgrad(li, gy, gin)
+                else:
+                    self.dgrad(s, gy, 0, gin, 0, tuple(inp.shape[1:4]))
                 g = gin
             elif need_dx:
                 dx = torch.empty(saved["in_shape"], dtype=torch.float32, device=dev)

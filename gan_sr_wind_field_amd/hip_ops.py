@@ -91,7 +91,7 @@ def make_desc(g: ConvGeom, dt: torch.dtype, B: int, in_xyz, in_ctot: int, in_off
     along x and y; phases = 4: all four parities in one forward launch."""
     xo, yo, zo = g.out_extent(*in_xyz)
     if lat is not None:
-        xo, yo = in_xyz[0], in_xyz[1]
+        xo, yo, zo = in_xyz
     d = ConvDesc()
     d.dtype = dtype_id(dt)
     d.B = B
@@ -105,6 +105,8 @@ def make_desc(g: ConvGeom, dt: torch.dtype, B: int, in_xyz, in_ctot: int, in_off
     d.upsample_xy = 1 if g.upsample else 0
     if lat is not None:
         d.lat, d.lat_ox, d.lat_oy, d.lat_phases = 2, lat[0], lat[1], lat[2]
+        if len(lat) > 3:  # (ox, oy, phases, mz, oz): z lattice of the output as well
+            d.lat_mz, d.lat_oz = lat[3], lat[4]
     return d
 
 
@@ -419,6 +421,19 @@ def upsample2_bwd(dy: Tensor, dx: Tensor) -> Tensor:
     check(_lib.lib().wsr_upsample2_bwd(_p(dy), _p(dx), B, X, Y, Z, C_, dtype_id(dx.dtype), _stream()),
           "upsample2_bwd")
     return dx
+
+
+def strided_parity_filters(w: Tensor, out: Tensor, sz: int, zc: int) -> Tensor:
+    """parity filters (4, Cin, Cout, 2, 2, KZp) of the input gradient of a stride-(2, 2, sz) 4x4x3 conv
+    (``wsr_strided_parity_filters``): forward-conv filters over dy, rows = the conv's input channels"""
+    _need_cuda(w, out)
+    cout, cin = w.shape[:2]
+    kzp = 3 if sz == 1 else (1 if zc == 0 else 2)
+    if tuple(w.shape[2:]) != (4, 4, 3) or tuple(out.shape) != (4, cin, cout, 2, 2, kzp) or \
+            not (w.is_contiguous() and out.is_contiguous()) or w.dtype != torch.float32 or out.dtype != torch.float32:
+        raise ValueError("strided_parity_filters: fp32 (Cout, Cin, 4, 4, 3) -> (4, Cin, Cout, 2, 2, KZp)")
+    check(_lib.lib().wsr_strided_parity_filters(_p(w), _p(out), cout, cin, sz, zc, _stream()), "strided_parity_filters")
+    return out
 
 
 def subpixel_fold(w: Tensor, wp: Tensor) -> Tensor:

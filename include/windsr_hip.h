@@ -60,8 +60,14 @@ typedef struct wsr_conv {
    * (2x + lat_ox, 2y + lat_oy, z) of a tensor of extent (2Xo, 2Yo, Zo) - y in the forward pass, dy in the
    * input / filter gradient.  lat_phases = 4 (wsr_conv3d_fwd_tile only): all four parities in ONE launch -
    * parity (a, b) runs with low pads (px - a, py - b), lattice offsets (a, b) and the fragment filter at
-   * wfrag + (2a + b) * wsr_frag_filter_elems(Cout, Cin, taps).                                          */
+   * wfrag + (2a + b) * wsr_frag_filter_elems(Cout, Cin, taps).
+   * The same machinery runs the INPUT gradient of the discriminator's stride-(2,2,s) 4x4x3 convs
+   * (torch_blocks.py:372-521) as forward convs over dy: input voxel (2m + a, 2n + b, s*l + c) only meets the filter
+   * taps of matching parity, so each parity class is a 2x2xKZ' conv on dy that writes its own lattice of dx (filters
+   * from wsr_strided_parity_filters).  lat_mz = 2 puts the output on the z lattice lat_mz*z + lat_oz as well
+   * (0 / 1: z is not strided); with lat set the conv is same-size along z too (Zo = Zi, low pad pz).     */
   int32_t lat, lat_ox, lat_oy, lat_phases;
+  int32_t lat_mz, lat_oz;
 } wsr_conv_t;
 
 /* Fused epilogue:  v = conv (+ bias[c]);  v = lrelu(v, slope) if act;
@@ -243,6 +249,15 @@ int wsr_upsample2_bwd(const void* dy, void* dx, int32_t B, int32_t Xi, int32_t Y
  * nn.Upsample(scale_factor=(2,2,1), mode="nearest") in front of the conv).  _unfold is the adjoint:
  * dw[f][kx][ky][kz] = sum over (a, b, i, j) with kx in S_a(i), ky in S_b(j) of dwp[2a+b][f][i][j][kz]
  * (dw is overwritten).                                                                                  */
+/* Parity filters of the input gradient of a stride-(2, 2, sz) conv with a 4x4x3 filter and padding 1 (the
+ * discriminator's down-sampling convs): w (Cout, Cin, 4, 4, 3) fp32 -> out (4, Cin, Cout, 2, 2, KZp), parity (a, b)
+ * at index 2a + b, for z parity class zc:
+ *   out[2a+b][ci][co][i][j][t] = w[co][ci][kx(a,i)][ky(b,j)][kz(t)],  k(0,.) = {3, 1} (dy offsets -1, 0),
+ *   k(1,.) = {2, 0} (offsets 0, +1);  sz = 1: KZp = 3, kz(t) = 2 - t (offsets -1, 0, +1);  sz = 2: zc = 0: KZp = 1,
+ *   kz = 1 (offset 0); zc = 1: KZp = 2, kz = {2, 0} (offsets 0, +1).
+ * Rows are the conv's INPUT channels: the result is the filter of a forward conv over dy (wsr_conv_t.lat).   */
+int wsr_strided_parity_filters(const float* w, float* out, int32_t Cout, int32_t Cin, int32_t sz, int32_t zc,
+                               void* stream);
 int wsr_subpixel_fold(const float* w, float* wp, int64_t n, int32_t KZ, void* stream);
 int wsr_subpixel_unfold(const float* dwp, float* dw, int64_t n, int32_t KZ, void* stream);
 /* planar fp32 (B,C,X,Y,Z) <-> NDHWC `dtype` window; c_fill >= C channels are

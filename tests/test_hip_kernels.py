@@ -204,6 +204,52 @@ def test_split_reduction_matches_single_pass(hip, case):
     o.ensure_tile_workspace(torch.device(DEV))
 
 
+@pytest.mark.parametrize("batched", [True, False])
+@pytest.mark.parametrize("case", [(32, 32, 2, (16, 16, 16)), (64, 64, 1, (8, 16, 16)), (128, 256, 2, (8, 8, 8)),
+                                  (32, 64, 1, (4, 6, 5))])
+def test_strided_input_gradient_in_parity_form(hip, case, batched):
+    """Input gradient of the discriminator's down-sampling convs (4x4x3, stride (2,2,1|2), padding 1; reference
+    torch_blocks.py:372-521) as 2x2xKZ' parity convs over dy on the tile kernels, each writing its own lattice of dx:
+    against autograd of the fp32 CPU conv on the same bf16-rounded operands (4e-3: output rounding only - the parity
+    filters are selections of the master taps, nothing is summed before the rounding)."""
+    o = ops()
+    cin, cout, sz, oxyz = case
+    dt = torch.bfloat16
+    torch.manual_seed(17)
+    B = 2
+    ixyz = (2 * oxyz[0], 2 * oxyz[1], sz * oxyz[2])
+    w = (torch.randn(cout, cin, 4, 4, 3) / math.sqrt(cin * 48)).to(dt).float()
+    gy = torch.randn(B, cout, *oxyz).to(dt).float()
+    x = torch.zeros(B, cin, *ixyz, requires_grad=True)
+    y = F.conv3d(x, w, None, stride=(2, 2, sz), padding=1)
+    assert tuple(y.shape[2:]) == oxyz
+    (dx_ref,) = torch.autograd.grad(y, x, gy)
+    gb = to_ndhwc(gy, cout, 0, dt)
+    dxb = torch.full((B,) + ixyz + (cin,), float("nan"), dtype=dt, device=DEV)
+    for zc in range(sz):
+        kzp = 3 if sz == 1 else (1 if zc == 0 else 2)
+        wp = torch.empty(4, cin, cout, 2, 2, kzp, device=DEV)
+        o.strided_parity_filters(w.to(DEV), wp, sz, zc)
+        n = o.frag_filter_elems(wp[0], False)
+        frag = torch.empty(4 * n, dtype=dt, device=DEV)
+        for ph in range(4):
+            o.pack_filter_frag(wp[ph], out=frag[ph * n:(ph + 1) * n])
+        pz = 1 if sz == 1 else 0
+        if batched:
+            d = o.make_desc(o.ConvGeom(cout, cin, (2, 2, kzp), (1, 1, 1), (1, 1, pz)), dt, B, oxyz, cout, 0, cin, 0,
+                            lat=(0, 0, 4, sz, zc))
+            assert o.conv_fwd_tile(d, gb, frag, dxb)
+        else:
+            for ph in range(4):
+                a, b = ph >> 1, ph & 1
+                d = o.make_desc(o.ConvGeom(cout, cin, (2, 2, kzp), (1, 1, 1), (1 - a, 1 - b, pz)), dt, B, oxyz, cout, 0,
+                                cin, 0, lat=(a, b, 0, sz, zc))
+                assert o.conv_fwd_tile(d, gb, frag[ph * n:(ph + 1) * n], dxb)
+    dx = from_ndhwc(dxb, 0, cin)
+    assert not torch.isnan(dx).any()  # every lattice was written
+    assert rel_l2(dx, dx_ref) < 4e-3
+
+
 def _subpixel_sets(a, i):
     """taps of the 3-wide filter that read un-sampled offset i of output parity a (wsr_subpixel_fold)"""
     return ([0], [1, 2])[i] if a == 0 else ([0, 1], [2])[i]
