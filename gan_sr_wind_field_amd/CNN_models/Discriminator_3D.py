@@ -54,6 +54,13 @@ class FeaturePyramid(nn.Sequential):
             raise RuntimeError("Discriminator_3D runs on the MI355X HIP kernels only (no CPU fallback)")
         return engine.run_discriminator_features(self.program(), x, self.training)
 
+    def forward_pair(self, xa: torch.Tensor, xb: torch.Tensor) -> torch.Tensor:
+        """features of two equally shaped inputs in one batched pass, stacked along the batch axis: the
+        convolutions run once on both, BatchNorm keeps per-call statistics (training mode: xa's call first)"""
+        if not (xa.is_cuda and xb.is_cuda):
+            raise RuntimeError("Discriminator_3D runs on the MI355X HIP kernels only (no CPU fallback)")
+        return engine.run_discriminator_features_pair(self.program(), xa, xb, self.training)
+
     def __deepcopy__(self, memo):
         import copy
         new = FeaturePyramid(*[copy.deepcopy(m, memo) for m in self])
@@ -130,3 +137,26 @@ class Discriminator_3D(nn.Module, lc.GlobalLoggingClass):
         h = self.dropout(self.features(x))
         h = h.reshape(h.shape[0], -1)  # logical (C, X, Y, Z) order, as in the reference (:191-192)
         return self.classifier(h)
+
+    def forward_pair(self, xa: torch.Tensor, xb):
+        """(D(xa), D(xb)) as two consecutive calls would give them - the reference's D(real), D(fake) of one iteration
+        (wind_field_GAN_3D.py:247-304) - with the feature pyramid run once on both inputs (see
+        ``FeaturePyramid.forward_pair``).  ``xb`` may be a callable that builds the second input (the reference draws
+        the fake sample's instance noise AFTER the first call): the random draws keep the reference's order - first
+        call's Dropout3d mask, ``xb()``, second call's mask; a Dropout3d mask is one Bernoulli draw per (sample,
+        channel), whatever the spatial extent, so it is drawn on a (B, C, 1, 1, 1) tensor ahead of the features."""
+        b = xa.shape[0]
+        c = self.features.program().layers[-1].conv.cout if xa.is_cuda else None
+        drop = self.training and self.dropout.p > 0
+        ones = (lambda: torch.ones((b, c, 1, 1, 1), dtype=torch.float32, device=xa.device)) if drop else None
+        mask_a = self.dropout(ones()) if drop else None
+        if callable(xb):
+            xb = xb()
+        mask_b = self.dropout(ones()) if drop else None
+        f = self.features.forward_pair(xa, xb)
+        outs = []
+        for h, m in ((f[:b], mask_a), (f[b:], mask_b)):
+            if m is not None:
+                h = h * m
+            outs.append(self.classifier(h.reshape(h.shape[0], -1)))
+        return outs[0], outs[1]

@@ -32,6 +32,9 @@ from ..process_data import calculate_gradient_of_wind_field
 from ..tools import initialization, trainingtricks
 from .baseGAN import BaseGAN
 
+#: D(real) and D(fake) of an iteration as ONE batched pass of the discriminator's feature pyramid (WSR_D_PAIR=0: two)
+D_PAIR = __import__("os").environ.get("WSR_D_PAIR", "1") != "0"
+
 _G_LOSS_KEYS = ("total", "adversarial", "pix", "xy_gradient", "z_gradient", "divergence", "xy_divergence",
                 "feature_D")
 
@@ -176,19 +179,29 @@ class wind_field_GAN_3D(BaseGAN):
             # the reference builds a debug string here whose last term draws one noise tensor (:228-246)
             self.device_check = str(HR.device) + str(self._noise(2.0, HR.size(), it).device)
         noise_on = self.cfg.training.use_instance_noise
+        # D(real) and D(fake) in one batched pass of the feature pyramid (per-call BatchNorm semantics kept, see
+        # Discriminator_3D.forward_pair); WSR_D_PAIR=0: two passes
+        pair = D_PAIR and hasattr(self.D, "forward_pair") and HR.shape == fake_HR.shape
         if train_D:
             self.D.train()
             real_in = HR + self._noise(1.0, HR.size(), it) if noise_on else HR
-            y_pred = self.D(real_in).squeeze()
             fake = fake_HR.detach()
-            fake_in = fake + self._noise(1.0, HR.size(), it) if noise_on else fake
-            fake_y_pred = self.D(fake_in).squeeze()
+            fake_in = lambda: fake + self._noise(1.0, HR.size(), it) if noise_on else fake  # noqa: E731 (drawn in call order)
+            if pair:
+                y_pred, fake_y_pred = (v.squeeze() for v in self.D.forward_pair(real_in, fake_in))
+            else:
+                y_pred = self.D(real_in).squeeze()
+                fake_y_pred = self.D(fake_in()).squeeze()
         else:
             self.D.eval()
             real_in = HR + self._noise(2.0, HR.size(), it) if noise_on else HR
-            y_pred = self.D(real_in).squeeze().detach()
-            fake_in = fake_HR + self._noise(2.0, HR.size(), it) if noise_on else fake_HR
-            fake_y_pred = self.D(fake_in).squeeze()
+            fake_in = lambda: fake_HR + self._noise(2.0, HR.size(), it) if noise_on else fake_HR  # noqa: E731
+            if pair:
+                y_pred, fake_y_pred = (v.squeeze() for v in self.D.forward_pair(real_in.detach(), fake_in))
+                y_pred = y_pred.detach()
+            else:
+                y_pred = self.D(real_in).squeeze().detach()
+                fake_y_pred = self.D(fake_in()).squeeze()
         return y_pred, fake_y_pred
 
     # ------------------------------------------------------------------ G losses

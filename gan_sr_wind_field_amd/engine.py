@@ -1214,16 +1214,27 @@ class DiscriminatorProgram(ProgramBase):
         else:
             run()
 
-    def forward(self, x: Tensor, training: bool, save: bool):
-        """x (B, C, X, Y, Z) planar fp32 -> NDHWC feature tensor (+ saved state)"""
+    def forward(self, x, training: bool, save: bool):
+        """x (B, C, X, Y, Z) planar fp32 -> NDHWC feature tensor (+ saved state).
+
+        ``x`` may be a tuple of G equally shaped inputs - the reference's D(real) and D(fake) of one iteration
+        (wind_field_GAN_3D.py:247-304).  The convolutions then run ONCE on the G*B samples (the deep layers are
+        latency-bound: a second sample costs them next to nothing) while BatchNorm keeps the reference's per-call
+        semantics: in training mode every group of B samples gets its own batch statistics and its own running-stat
+        update, in call order."""
         sl = self.slope
-        B = x.shape[0]
-        ops._need_cuda(x, self.layers[0].conv.weight)  # input and parameters on the current device
+        xs = tuple(x) if isinstance(x, (tuple, list)) else (x,)
+        G, Bg = len(xs), xs[0].shape[0]
+        B = G * Bg
+        ops._need_cuda(*xs, self.layers[0].conv.weight)  # inputs and parameters on the current device
         self.refresh_filters(backward=save)
-        x = x.contiguous().float()
         c0 = self.cp(self.layers[0].conv.cin)
-        h = self._empty((B,) + tuple(x.shape[2:]) + (c0,), x)
-        ops.planar_to_ndhwc(x, h, 0, c0)
+        h = self._empty((B,) + tuple(xs[0].shape[2:]) + (c0,), xs[0])
+        for gi, xg in enumerate(xs):
+            if xg.shape != xs[0].shape:
+                raise ValueError("grouped discriminator inputs must have one shape")
+            ops.planar_to_ndhwc(xg.contiguous().float(), h[gi * Bg:(gi + 1) * Bg], 0, c0)
+        x = xs[0]
         recs = []
         for l in self.layers:
             s = l.conv
@@ -1239,19 +1250,30 @@ class DiscriminatorProgram(ProgramBase):
             self.conv(s, h, 0, y, 0)
             bn = l.bn
             C_ = s.cout
-            n = y.numel() // y.shape[-1]
-            if training:
+            a = self._empty(y.shape, x)
+            if not training:
+                mean = bn.running_mean.detach().float()
+                invstd = torch.rsqrt(bn.running_var.detach().float() + bn.eps)
+                ops.bn_apply_lrelu(y, a, mean, invstd, bn.weight.detach(), bn.bias.detach(), l.act, sl)
+                recs.append(dict(inp=h, y=y, a=a, mean=[mean], invstd=[invstd], count=[float(y.numel() // y.shape[-1])],
+                                 training=False, groups=1))
+                h = a
+                continue
+            means, invstds, counts = [], [], []
+            for gi in range(G):
+                yg, ag = y[gi * Bg:(gi + 1) * Bg], a[gi * Bg:(gi + 1) * Bg]
+                n = yg.numel() // yg.shape[-1]
                 # pass 1: sum x -> mean ; pass 2: sum (x - mean)^2 -> variance without cancellation.
                 # The per-channel steps in between are two tiny fused kernels (was ~14 torch ops per layer).
                 st = torch.empty(4 * C_ + 1, dtype=torch.float32, device=x.device)  # (bn_stats overwrites)
                 s1, s2 = st[:2 * C_], st[2 * C_:4 * C_]
                 work = torch.empty(2 * C_, dtype=torch.float32, device=x.device)
                 mean, invstd = work[:C_], work[C_:]
-                ops.bn_stats(y, s1)
+                ops.bn_stats(yg, s1)
                 cdev = None
                 count = float(n)
                 ops.bn_mean(s1, mean, count, cdev)
-                ops.bn_stats(y, s2, shift=mean)
+                ops.bn_stats(yg, s2, shift=mean)
                 if self.stat_allgather is not None:
                     # SyncBN in ONE collective per layer: every rank contributes its local mean and its local
                     # centred second moment M2 = sum (x - mean_r)^2 (both passes above are local), and the global
@@ -1274,19 +1296,19 @@ class DiscriminatorProgram(ProgramBase):
                     mom = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked)
                 ops.bn_finalize(s2, mean, invstd, count, bn.eps, mom, bn.running_mean if track else None,
                                 bn.running_var if track else None, cdev)
-            else:
-                mean = bn.running_mean.detach().float()
-                invstd = torch.rsqrt(bn.running_var.detach().float() + bn.eps)
-                count = float(n)
-            a = self._empty(y.shape, x)
-            ops.bn_apply_lrelu(y, a, mean, invstd, bn.weight.detach(), bn.bias.detach(), l.act, sl)
-            recs.append(dict(inp=h, y=y, a=a, mean=mean, invstd=invstd, count=count, training=training))
+                ops.bn_apply_lrelu(yg, ag, mean, invstd, bn.weight.detach(), bn.bias.detach(), l.act, sl)
+                means.append(mean)
+                invstds.append(invstd)
+                counts.append(count)
+            recs.append(dict(inp=h, y=y, a=a, mean=means, invstd=invstds, count=counts, training=True, groups=G))
             h = a
-        saved = dict(recs=recs, in_shape=tuple(x.shape)) if save else None
+        saved = dict(recs=recs, in_shape=tuple(x.shape), groups=G, group_batch=Bg) if save else None
         return h, saved
 
-    def backward(self, saved: dict, g_feat: Tensor, need_dx: bool, need_dw: bool):
-        """g_feat NDHWC (compute dtype) -> (dx planar fp32 | None, flat grads | None)"""
+    def backward(self, saved: dict, g_feat: Tensor, need_dx: bool, need_dw: bool, lo: int = 0):
+        """g_feat NDHWC (compute dtype) -> (dx planar fp32 | None, flat grads | None).  ``lo`` > 0: samples [0, lo) of
+        the (grouped) batch take no part - no parameter gradients are wanted and their inputs need no gradient (the
+        detached D(real) of a generator iteration): the pass runs on samples [lo, B) only; g_feat and dx cover those."""
         sl = self.slope
         dev = g_feat.device
         flat = self.space.new(dev) if need_dw else None
@@ -1295,41 +1317,55 @@ class DiscriminatorProgram(ProgramBase):
             self.begin_backward(dev)
         sp = self.space
         done = 0
-        g = g_feat.contiguous()
+        Bg = saved.get("group_batch", g_feat.shape[0])
+        if lo and (need_dw or lo % Bg):
+            raise ValueError("a partial backward pass starts at a group boundary and has no parameter gradients")
+        g = g_feat.contiguous()  # (covers samples [lo, B) only)
         dx = None
         recs = saved["recs"]
         for li in reversed(range(len(self.layers))):
             l, r = self.layers[li], recs[li]
             s = l.conv
             C_ = s.cout
+            act_o = r["a"][lo:]
             if l.bn is None:
                 if l.act:
-                    ops.lrelu_bwd_(g, 0, r["a"], 0, g.shape[-1], sl)
+                    ops.lrelu_bwd_(g, 0, act_o, 0, g.shape[-1], sl)
                 gy = g
             else:
                 bn = l.bn
-                gy = self._empty(r["y"].shape, g)
+                y_o = r["y"][lo:]
+                gy = self._empty(y_o.shape, g)
                 if r["training"]:
-                    sums = torch.empty(2 * C_, dtype=torch.float32, device=dev)  # (overwritten)
-                    ops.bn_bwd_reduce(g, r["a"], r["y"], r["mean"], r["invstd"], l.act, sl, sums)
-                    if need_dw:
-                        sp.view(flat, bn.bias).copy_(sums[:C_])
-                        sp.view(flat, bn.weight).copy_(sums[C_:])
-                    if self.stat_allreduce is not None:
-                        sums = sums.clone()
-                        self.stat_allreduce(sums)
-                    ops.bn_bwd_apply(g, r["y"], gy, r["mean"], r["invstd"], bn.weight.detach(), sums,
-                                     1.0 / r["count"])
+                    G = r["groups"]
+                    for gi in range(lo // Bg, G):
+                        o = gi * Bg - lo
+                        gg, ag, yg, gyg = g[o:o + Bg], act_o[o:o + Bg], y_o[o:o + Bg], gy[o:o + Bg]
+                        sums = torch.empty(2 * C_, dtype=torch.float32, device=dev)  # (overwritten)
+                        ops.bn_bwd_reduce(gg, ag, yg, r["mean"][gi], r["invstd"][gi], l.act, sl, sums)
+                        if need_dw:  # (every group's batch statistics are a call of their own: the gradients add)
+                            if gi == 0:
+                                sp.view(flat, bn.bias).copy_(sums[:C_])
+                                sp.view(flat, bn.weight).copy_(sums[C_:])
+                            else:
+                                sp.view(flat, bn.bias).add_(sums[:C_])
+                                sp.view(flat, bn.weight).add_(sums[C_:])
+                        if self.stat_allreduce is not None:
+                            sums = sums.clone()
+                            self.stat_allreduce(sums)
+                        ops.bn_bwd_apply(gg, yg, gyg, r["mean"][gi], r["invstd"][gi], bn.weight.detach(), sums,
+                                         1.0 / r["count"][gi])
                 else:
+                    mean, invstd = r["mean"][0], r["invstd"][0]
                     if l.act:
-                        ops.lrelu_bwd_(g, 0, r["a"], 0, g.shape[-1], sl)
+                        ops.lrelu_bwd_(g, 0, act_o, 0, g.shape[-1], sl)
                     if need_dw:  # eval-mode BN: d beta = sum g, d gamma = sum g * xhat
                         sums = torch.empty(2 * C_, dtype=torch.float32, device=dev)
-                        ops.bn_bwd_reduce(g, r["a"], r["y"], r["mean"], r["invstd"], False, sl, sums)
+                        ops.bn_bwd_reduce(g, act_o, y_o, mean, invstd, False, sl, sums)
                         sp.view(flat, bn.bias).copy_(sums[:C_])
                         sp.view(flat, bn.weight).copy_(sums[C_:])
-                    ops.bn_bwd_apply(g, r["y"], gy, r["mean"], r["invstd"], bn.weight.detach(), None, 0.0)
-            inp = r["inp"]
+                    ops.bn_bwd_apply(g, y_o, gy, mean, invstd, bn.weight.detach(), None, 0.0)
+            inp = r["inp"][lo:]
             if need_dw:
                 self.wgrad(s, inp, 0, gy, 0, flat, sp, scratch)
                 if self.grad_ready_hook is not None:
@@ -1346,7 +1382,7 @@ class DiscriminatorProgram(ProgramBase):
                     self.dgrad(s, gy, 0, gin, 0, tuple(inp.shape[1:4]))
                 g = gin
             elif need_dx:
-                dx = torch.empty(saved["in_shape"], dtype=torch.float32, device=dev)
+                dx = torch.empty((inp.shape[0],) + tuple(saved["in_shape"][1:]), dtype=torch.float32, device=dev)
                 self.dgrad(s, gy, 0, dx, 0, tuple(inp.shape[1:4]), dx_planar=True)
         if need_dw:
             self.end_backward()
@@ -1385,6 +1421,54 @@ class _DiscriminatorFeaturesFn(torch.autograd.Function):
         grads = tuple(prog.space.view(flat, p) if (need_dw and ctx.needs_input_grad[4 + i]) else None
                       for i, p in enumerate(prog.param_list))
         return (dx, None, None, None) + grads
+
+
+class _DiscriminatorPairFn(torch.autograd.Function):
+    """features of two inputs in ONE batched pass (see DiscriminatorProgram.forward): (xa, xb) -> (2B, C, X, Y, Z)"""
+
+    @staticmethod
+    def forward(ctx, xa, xb, prog: DiscriminatorProgram, training: bool, save: bool, *params):
+        feat, saved = prog.forward((xa, xb), training, save)
+        ctx.prog, ctx.saved = prog, saved
+        ctx.feat_c = prog.layers[-1].conv.cout
+        ctx.bg = xa.shape[0]
+        return feat[..., :ctx.feat_c].permute(0, 4, 1, 2, 3).float()
+
+    @staticmethod
+    def backward(ctx, g_out):
+        prog, saved = ctx.prog, ctx.saved
+        if saved is None:
+            raise RuntimeError("Discriminator_3D.features backward without saved activations")
+        need_a, need_b = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        need_dw = any(ctx.needs_input_grad[5:])
+        c = ctx.feat_c
+        cp_ = prog.cp(c)
+        # the first input's half of the pass is skipped when nothing wants it (generator iteration: D(real) is detached)
+        lo = 0 if (need_a or need_dw) else ctx.bg
+        g = g_out[lo:].permute(0, 2, 3, 4, 1)
+        if cp_ != c:
+            gp = torch.zeros(g.shape[:-1] + (cp_,), dtype=prog.dt, device=g.device)
+            gp[..., :c] = g
+            g = gp
+        else:
+            g = g.to(prog.dt).contiguous()
+        dx, flat = prog.backward(saved, g, need_a or need_b, need_dw, lo=lo)
+        ctx.saved = None
+        dxa = dxb = None
+        if dx is not None:
+            if lo:
+                dxb = dx
+            else:
+                dxa, dxb = (dx[:ctx.bg] if need_a else None), (dx[ctx.bg:] if need_b else None)
+        grads = tuple(prog.space.view(flat, p) if (need_dw and ctx.needs_input_grad[5 + i]) else None
+                      for i, p in enumerate(prog.param_list))
+        return (dxa, dxb, None, None, None) + grads
+
+
+def run_discriminator_features_pair(prog: DiscriminatorProgram, xa: Tensor, xb: Tensor, training: bool) -> Tensor:
+    save = torch.is_grad_enabled() and (xa.requires_grad or xb.requires_grad
+                                        or any(p.requires_grad for p in prog.param_list))
+    return _DiscriminatorPairFn.apply(xa, xb, prog, training, save, *prog.param_list)
 
 
 def run_discriminator_features(prog: DiscriminatorProgram, x: Tensor, training: bool) -> Tensor:

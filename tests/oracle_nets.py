@@ -38,3 +38,9 @@ class OracleDiscriminator(Discriminator_3D):
     def forward(self, x):
         sd = self.state_dict(keep_vars=True)
         return onets.discriminator_forward(sd, x, self._spec, training=self.training)
+
+    def forward_pair(self, xa, xb):
+        # the product batches the two calls of an iteration; the oracle answers them one after the other (the second
+        # input may be a callable: its instance noise is drawn after the first call, as in the reference)
+        ya = self.forward(xa)
+        return ya, self.forward(xb() if callable(xb) else xb)

@@ -191,6 +191,71 @@ def test_discriminator_eval_mode_input_gradient(hip):
     assert all(p.grad is None for p in D.parameters())
 
 
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("mode", ["train", "eval_input_grad"])
+def test_discriminator_pair_equals_two_calls(hip, dt, mode):
+    """D.forward_pair(a, b) - the feature pyramid run once on both inputs, BatchNorm statistics per call - against
+    D(a), D(b) as the reference issues them (wind_field_GAN_3D.py:247-304): logits, running statistics, parameter
+    gradients (train: both calls feed one backward pass) and the input gradient of the second input (generator
+    iteration: D in eval mode, parameters frozen, first input detached).  Equal up to summation order: the batched
+    filter gradient adds the two samples inside one launch (fp32 2e-5; bf16: identical roundings, 2e-3)."""
+    import copy
+    spec = onets.DSpec(bf=8, nz=4, enable_slicing=True)
+    D1, _ = build_D(spec, dt, 23)
+    D2 = copy.deepcopy(D1)
+    D2.features.compute_dtype = D1.features.compute_dtype
+    gen = torch.Generator().manual_seed(9)
+    a = (torch.rand((2, 3, 64, 64, 4), generator=gen) * 2 - 1).to(DEV)
+    b = (torch.rand((2, 3, 64, 64, 4), generator=gen) * 2 - 1).to(DEV)
+    tol = 2e-5 if dt == torch.float32 else 2e-3
+    wgt = torch.tensor([[1.0], [-0.5]], device=DEV)
+    if mode == "train":
+        D1.train(); D2.train()
+        ya, yb = D1(a), D1(b)
+        ((ya - yb.mean()) * wgt).sum().backward()
+        pa, pb = D2.forward_pair(a, b)
+        ((pa - pb.mean()) * wgt).sum().backward()
+        assert rel_l2(pa, ya) < tol and rel_l2(pb, yb) < tol
+        for (k, p1), (_, p2) in zip(D1.named_parameters(), D2.named_parameters()):
+            assert rel_l2(p2.grad, p1.grad) < (2e-4 if dt == torch.float32 else 2e-2), k
+        for (k, v1), (_, v2) in zip(D1.state_dict().items(), D2.state_dict().items()):
+            if "running_" in k or "num_batches" in k:
+                assert rel_l2(v2.float(), v1.float()) < 1e-5, k
+    else:
+        D1.eval(); D2.eval()
+        for p in list(D1.parameters()) + list(D2.parameters()):
+            p.requires_grad = False
+        b1, b2 = b.clone().requires_grad_(True), b.clone().requires_grad_(True)
+        ya, yb = D1(a).detach(), D1(b1)
+        ((yb - ya.mean()) * wgt).sum().backward()
+        pa, pb = D2.forward_pair(a, b2)
+        ((pb - pa.detach().mean()) * wgt).sum().backward()
+        assert rel_l2(pa, ya) < tol and rel_l2(pb, yb) < tol
+        assert rel_l2(b2.grad, b1.grad) < (2e-5 if dt == torch.float32 else 2e-3)
+
+
+def test_discriminator_pair_keeps_the_order_of_random_draws(hip):
+    """Dropout3d masks and the second input's instance noise are drawn in the order of two consecutive calls
+    (first mask, noise, second mask): same seed -> same logits as D(a), D(b + noise())."""
+    spec = onets.DSpec(bf=8, nz=4, enable_slicing=True, dropout_p=0.3)
+    D, _ = build_D(spec, torch.float32, 29)
+    D.train()
+    for m in D.modules():  # (keep the running statistics out of the comparison: both runs start from the same state)
+        if isinstance(m, torch.nn.BatchNorm3d):
+            m.momentum = 0.0
+    gen = torch.Generator().manual_seed(10)
+    a = (torch.rand((2, 3, 64, 64, 4), generator=gen) * 2 - 1).to(DEV)
+    b = (torch.rand((2, 3, 64, 64, 4), generator=gen) * 2 - 1).to(DEV)
+    with torch.no_grad():
+        torch.manual_seed(77)
+        ya = D(a)
+        yb = D(b + 0.1 * torch.rand(b.shape, device=DEV))
+        torch.manual_seed(77)
+        pa, pb = D.forward_pair(a, lambda: b + 0.1 * torch.rand(b.shape, device=DEV))
+    assert rel_l2(pa, ya) < 2e-5 and rel_l2(pb, yb) < 2e-5
+    assert float((ya - D(a)).abs().max()) > 0  # (the masks do matter: another draw gives other logits)
+
+
 def test_discriminator_bf16_vs_oracle(hip):
     spec = onets.DSpec(bf=8, nz=4, enable_slicing=True)
     D, _ = build_D(spec, torch.bfloat16, 8)
