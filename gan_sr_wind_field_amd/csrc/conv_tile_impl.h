@@ -592,7 +592,9 @@ int launch_ct(CtArgs& a, hipStream_t st) {
   a.off_xs = round_up(a.off_btab + 2 * NTW * 16 * 4, 1024);
   // two activation buffers when that still leaves room for weight stages of >= 2 K-steps
   int ts_max = 0;
-  const int xb_first = getenv("WSR_CT_XBUFS") ? atoi(getenv("WSR_CT_XBUFS")) : 2;  // tuning aid
+  // (one chunk: the second activation buffer would never be filled - the LDS it frees lets a second workgroup share
+  // the CU, whose prologue and epilogue then overlap this one's main loop: terrain convs, 3-channel inputs)
+  const int xb_first = getenv("WSR_CT_XBUFS") ? atoi(getenv("WSR_CT_XBUFS")) : ((a.nchunks == 1 || (NTW == 1 && getenv("WSR_CT_N16_ONEBUF"))) ? 1 : 2);  // env: tuning aid
   for (a.xbufs = xb_first; a.xbufs >= 1; --a.xbufs) {
     a.off_ws = a.off_xs + a.xbufs * (VM ? 1 : PL) * a.P;
     const int avail = 160 * 1024 - a.off_ws;

@@ -59,6 +59,8 @@ struct WgtArgs {
   unsigned char act_nc[64], act_cc[64];
   long part_stride;             // > 0: spatial split s STORES its sums at dw + s*part_stride (no atomics, see
                                 // wsr_conv3d_wgrad_parts); 0: every split adds into dw with float atomics
+  int yl_m, yl_ox, yl_oy;       // dy is the sub-lattice (m*x + ox, m*y + oy, z) of a tensor m times as large along x and y
+                                // (parity convs of a sub-pixel up-sampling conv, wsr_conv_t.lat); m = 1: dy itself
   int prio;                     // 1: waves 4..7 at s_setprio 1 in the tile loop (tuning switch)
   int S_forced;                 // > 0: the number of spatial splits the caller was told (wsr_conv3d_wgrad_nparts)
   int plan_only;                // host side: compute the launch geometry (S) and return without launching
@@ -208,7 +210,7 @@ __global__ __launch_bounds__(512) void wgrad_tile_kernel(const WgtArgs a) {
         const int oz = v % a.TZ, qq = v / a.TZ;
         const int oy = qq % a.TY, ox = qq / a.TY;
         geo = ox | (oy << 8) | (oz << 16) | (1u << 24);
-        rel = ((ox * a.Yo + oy) * a.Zo + oz) * a.out_ctot + 8 * oct;
+        rel = ((ox * a.yl_m * (a.Yo * a.yl_m) + oy * a.yl_m) * a.Zo + oz) * a.out_ctot + 8 * oct;
       }
     }
     ygeo[k] = geo;
@@ -249,7 +251,8 @@ __global__ __launch_bounds__(512) void wgrad_tile_kernel(const WgtArgs a) {
     {  // dy image: tile voxels only
       const int hix = a.Xo - x0, hiy = a.Yo - y0, hiz = a.Zo - z0;
       const bool inner = a.TX <= hix && a.TY <= hiy && a.TZ <= hiz;
-      const long base = ((((long)b * a.Xo + x0) * a.Yo + y0) * a.Zo + z0) * a.out_ctot + a.out_off + n0;
+      const long base = ((((long)b * a.Xo * a.yl_m + x0 * a.yl_m + a.yl_ox) * (a.Yo * a.yl_m) + y0 * a.yl_m + a.yl_oy) *
+                             a.Zo + z0) * a.out_ctot + a.out_off + n0;
       const unsigned short* bp = a.dy + base;
 #pragma unroll
       for (int k = 0; k < YK; ++k) {
@@ -306,7 +309,7 @@ __global__ __launch_bounds__(512) void wgrad_tile_kernel(const WgtArgs a) {
   // (accumulator-heavy instantiations - the 5x5x5 kernels with 3 n-tiles - have no registers left for a
   // second dy set and a ring: they fetch per slot, LEAN)
   constexpr bool LEAN = SPW * TN * 4 >= 192;
-  constexpr int R = SPW % 7 == 0 ? 7 : (SPW % 4 == 0 ? 4 : 1);
+  constexpr int R = SPW % 7 == 0 ? 7 : (SPW % 4 == 0 ? 4 : (SPW % 3 == 0 ? 3 : 1));
   constexpr int D = R > 3 ? 3 : R - 1;
   struct KP { const char *xlo, *xhi, *rlo, *rhi; int slo, shi; };
   // Voxel <-> MFMA k mapping of a 32-voxel K-step.  Z16 (tile z extent a multiple of 16, every shipped
@@ -609,7 +612,7 @@ int run_tile(WgtArgs& a, int taps, int Cout, int Cin, hipStream_t st);
 int wsr_wgrad_tile_bf16(const wsr_conv_t* c, const void* x, const void* dy, float* dw, int tri_base, int tri_step,
                         long part_stride, int n_parts, int* plan, void* stream) {
   if (c->dtype != WSR_BF16 || (c->sx | c->sy | c->sz) != 1) return WSR_EUNSUPPORTED;
-  if (c->lat) return WSR_EUNSUPPORTED;
+  if (c->lat && (c->lat_phases || c->lat_mz > 1 || tri_step > 0)) return WSR_EUNSUPPORTED;  // one parity per launch
   const int taps = c->KX * c->KY * c->KZ;
   if (taps > 128) return WSR_EUNSUPPORTED;
   if (c->Cin % 8 || c->in_ctot % 8 || c->in_off % 8 || c->out_ctot % 8 || c->out_off % 8) return WSR_EUNSUPPORTED;
@@ -627,6 +630,7 @@ int wsr_wgrad_tile_bf16(const wsr_conv_t* c, const void* x, const void* dy, floa
   a.KX = c->KX; a.KY = c->KY; a.KZ = c->KZ;
   a.px = c->px; a.py = c->py; a.pz = c->pz;
   a.ups = c->upsample_xy ? 1 : 0;
+  a.yl_m = c->lat ? 2 : 1; a.yl_ox = c->lat ? c->lat_ox : 0; a.yl_oy = c->lat ? c->lat_oy : 0;
   a.tri_base = tri_base; a.tri_step = tri_step;
   a.part_stride = part_stride; a.S_forced = n_parts; a.plan_only = plan ? 1 : 0;
   hipStream_t st = as_stream(stream);
@@ -647,6 +651,11 @@ int run_tile(WgtArgs& a, int taps, int Cout, int Cin, hipStream_t st) {
     if (c->Cout <= 16) return launch_tile<1, 16, 1>(a, st);
     if (c->Cout % 48 == 0) return launch_tile<3, 16, 1>(a, st);
     return launch_tile<2, 16, 1>(a, st);
+  }
+  // <= 12 taps (the 2x2x3 parity convs of a sub-pixel up-sampling conv): 6 slots per wave = 12 taps x 4 c-tiles
+  if (taps <= 12 && c->Cout >= 64 && c->Cin >= 64) {
+    const int rc = launch_tile<4, 6, 4>(a, st);
+    if (rc != WSR_EUNSUPPORTED) return rc;
   }
   // <= 28 taps (3x3x3): 7 slots per wave = 28 taps x 2 c-tiles (32 input channels per chunk)
   if (c->Cout <= 16) return launch_tile<1, 7, 2>(a, st);

@@ -51,6 +51,8 @@ STRIDED_DGRAD = __import__("os").environ.get("WSR_STRIDED_DGRAD", "1") != "0"
 #: run the up-sampling convs (nearest x(2,2,1) + 3x3x3) in their sub-pixel form: four 2x2x3 parity convs on the
 #: un-sampled input, 4/9 of the multiply-adds (WSR_SUBPIXEL=0: gather through the up-sampling, 27 taps)
 SUBPIXEL = __import__("os").environ.get("WSR_SUBPIXEL", "1") != "0"
+#: ... and their filter gradients too (WSR_SUBPIXEL_WGRAD=0: the 27-tap gradient through the up-sampling gather)
+SUBPIXEL_WGRAD = __import__("os").environ.get("WSR_SUBPIXEL_WGRAD", "1") != "0"
 
 
 def compute_dtype_of(flag) -> torch.dtype:
@@ -662,6 +664,7 @@ class GeneratorProgram(ProgramBase):
         # master filter like hr1z; they exist only for the bf16 tile path.
         self.up_parity: List[Optional[List[ConvSite]]] = []
         self._up_wp: List[Optional[Tensor]] = []
+        self._up_dwp: List[Optional[Tensor]] = []  # parity filter gradients (folded back by wsr_subpixel_unfold)
         self._up_stamp: List[object] = []
         for u in self.ups:
             ok = (u.kernel[0], u.kernel[1]) == (3, 3) and (u.pad[0], u.pad[1]) == (1, 1) and u.stride == (1, 1, 1)
@@ -674,6 +677,7 @@ class GeneratorProgram(ProgramBase):
                 wp = None
                 self.up_parity.append(None)
             self._up_wp.append(wp)
+            self._up_dwp.append(None)
             self._up_stamp.append(None)
         self.nf = self.feature.cout
         self.gc = self.rrdbs[0][0][0][0].cout if self.rrdbs and self.rrdbs[0][0][0] else 0
@@ -781,6 +785,41 @@ class GeneratorProgram(ProgramBase):
             self.launch_probe("fwd:" + site.name, run)
         else:
             run()
+
+    def up_wgrad(self, u: int, inp: Tensor, g: Tensor, flat: Tensor, space: "GradSpace") -> None:
+        """filter gradient of up-conv u in its sub-pixel form: per parity the 2x2x3 gradient over the un-sampled
+        input and that parity's lattice of the output gradient (12 instead of 27 taps per output voxel), folded
+        back onto the 3x3x3 master filter by the adjoint of the tap sums (``wsr_subpixel_unfold``)."""
+        site, par = self.ups[u], self.up_parity[u]
+        B, xyz = inp.shape[0], tuple(inp.shape[1:4])
+        dwp = self._up_dwp[u]
+        if dwp is None or dwp.device != inp.device:
+            dwp = self._up_dwp[u] = torch.empty_like(self._up_wp[u], device=inp.device)
+        cin_p = self.cp(site.cin)
+        runs = []
+        for ph, s in enumerate(par):
+            d = ops.make_desc(ConvGeom(site.cin, site.cout, s.kernel, (1, 1, 1), s.pad), self.dt, B, xyz, inp.shape[-1],
+                              0, g.shape[-1], 0, cin=cin_p, lat=(ph >> 1, ph & 1, 0))
+            if DETERMINISTIC:
+                n = self._wgrad_nparts(("wpar", site.name, ph, B) + xyz, d)
+                parts = self._arena_take(n * site.cout * s.taps * cin_p, inp.device).view(n, site.cout, s.taps, cin_p)
+                runs.append(lambda d=d, parts=parts, n=n: ops.conv_wgrad_parts(d, inp, g, parts, n))
+                self._pending_unpack.append((parts[0], dwp[ph], 1.0, n, parts[0].numel()))
+            else:
+                dw = self._arena_take(site.cout * s.taps * cin_p, inp.device)
+                runs.append(lambda d=d, dw=dw: ops.conv_wgrad(d, inp, g, dw))
+                self._pending_unpack.append((dw.view(site.cout, s.taps, cin_p), dwp[ph], 1.0))
+
+        def run():
+            for r in runs:
+                r()
+
+        if self.launch_probe is not None:
+            self.launch_probe("wgrad:" + site.name, run)
+        else:
+            run()
+        self.flush_unpack()
+        ops.subpixel_unfold(dwp, space.view(flat, site.weight))
 
     def up_dgrad(self, u: int, g: Tensor, gin: Tensor, mask=None) -> None:
         """input gradient of up-conv u in its sub-pixel form: ``gin`` (B, X, Y, Z, nf) = sum over the four parities of
@@ -958,7 +997,10 @@ class GeneratorProgram(ProgramBase):
         for u in reversed(range(len(self.ups))):
             site, (inp, outp) = self.ups[u], saved["up_io"][u]
             ops.lrelu_bwd_(gbuf, 0, outp, 0, nf, sl)
-            self.wgrad(site, inp, 0, gbuf, 0, flat, sp, scratch)
+            if self.subpixel_active(u) and SUBPIXEL_WGRAD:
+                self.up_wgrad(u, inp, gbuf, flat, sp)
+            else:
+                self.wgrad(site, inp, 0, gbuf, 0, flat, sp, scratch)
             gin = self._empty(inp.shape, g_out)
             if self.subpixel_active(u):
                 self.up_dgrad(u, gbuf, gin)

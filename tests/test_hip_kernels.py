@@ -339,6 +339,41 @@ def test_subpixel_upconv_forward_and_dgrad(hip, shape, batched):
     assert rel_l2(from_ndhwc(dxb, 0, cin), dx_ref) < 1.5e-2
 
 
+@pytest.mark.parametrize("shape", [(2, 32, 48, 8, 16, 16), (1, 128, 128, 8, 8, 32), (1, 64, 64, 5, 6, 10)])
+def test_subpixel_upconv_filter_gradient(hip, shape):
+    """Filter gradient of nearest x(2,2,1) + 3x3x3 conv in parity form: four 2x2x3 gradients, each over the un-sampled
+    input and ITS lattice of the output gradient (deterministic split copies + ordered reduce), folded back by
+    wsr_subpixel_unfold - against autograd of the fp32 CPU conv on the same bf16-rounded operands (1e-3: fp32
+    accumulation, only the summation order differs)."""
+    o = ops()
+    B, cin, cout, X, Y, Z = shape
+    dt = torch.bfloat16
+    torch.manual_seed(13)
+    x = torch.randn(B, cin, X, Y, Z).to(dt).float()
+    gy = torch.randn(B, cout, 2 * X, 2 * Y, Z).to(dt).float()
+    w = torch.zeros(cout, cin, 3, 3, 3, requires_grad=True)
+    up = F.interpolate(x, scale_factor=(2, 2, 1), mode="nearest")
+    (dw_ref,) = torch.autograd.grad(F.conv3d(up, w, None, padding=1), w, gy)
+    xb = to_ndhwc(x, cin, 0, dt)
+    gb = to_ndhwc(gy, cout + 16, 0, dt)  # (the last up-conv's output gradient is a window of the concat buffer)
+    dwp = torch.empty(4, cout, cin, 2, 2, 3, device=DEV)
+    jobs = []
+    keep = []
+    for ph in range(4):
+        a, b = ph >> 1, ph & 1
+        d = o.make_desc(o.ConvGeom(cin, cout, (2, 2, 3), (1, 1, 1), (1 - a, 1 - b, 1)), dt, B, (X, Y, Z), cin, 0,
+                        cout + 16, 0, lat=(a, b, 0))
+        n = o.conv_wgrad_nparts(d)
+        parts = torch.full((n, cout, 12, cin), float("nan"), dtype=torch.float32, device=DEV)
+        o.conv_wgrad_parts(d, xb, gb, parts, n)
+        jobs.append((parts[0], dwp[ph], 1.0, n, parts[0].numel()))
+        keep.append(parts)
+    o.unpack_wgrad_reduce_multi(o.unpack_job_table(jobs))
+    dw = torch.empty(cout, cin, 3, 3, 3, device=DEV)
+    o.subpixel_unfold(dwp, dw)
+    assert rel_l2(dw.cpu(), dw_ref) < 1e-3
+
+
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
 def test_epilogue_residual_dropout_planar(hip, dt):
     """bias + LReLU + channel scale + alpha*v + beta*res, NDHWC and planar outputs."""

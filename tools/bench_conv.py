@@ -95,6 +95,24 @@ CASES = {
     "lr": lambda: [conv_case("lr_conv 128->128", 128, 128, (3, 3, 3), LR, what=w) for w in ("fwd", "dgrad", "wgrad")],
 }
 
+def up_parity_wgrad_case():
+    B, xyz, c = 1, (64, 64, 128), 128
+    g = torch.Generator(device=DEV).manual_seed(1)
+    x = torch.randn((B,) + xyz + (c,), device=DEV, generator=g).to(DT)
+    gy = torch.randn((B, 128, 128, 128, c + 16), device=DEV, generator=g).to(DT)
+    tot = 0.0
+    for ph in range(4):
+        a, b = ph >> 1, ph & 1
+        d = o.make_desc(o.ConvGeom(c, c, (2, 2, 3), (1, 1, 1), (1 - a, 1 - b, 1)), DT, B, xyz, c, 0, c + 16, 0, lat=(a, b, 0))
+        n = o.conv_wgrad_nparts(d)
+        parts = torch.empty((n, c, 12, c), dtype=torch.float32, device=DEV)
+        tot += timeit(lambda: o.conv_wgrad_parts(d, x, gy, parts, n))
+    flops = 2.0 * 4 * xyz[0] * xyz[1] * xyz[2] * 12 * c * c
+    print(f"{'up2 wgrad, 4 parity launches':28s} {'wgrad':12s} {tot * 1e3:9.1f} us  {flops / tot / 1e9:8.1f} TF/s")
+
+
+CASES["upw"] = up_parity_wgrad_case
+
 S10 = (32, 32, 10)  # the reference's real patch size at the trunk's resolution (C1b)
 CASES["c1b"] = lambda: [conv_case("pre 128->128 @32x32x10", 128, 128, (3, 3, 3), S10, 256, 256, 128),
                         conv_case("pre dgrad @32x32x10", 128, 128, (3, 3, 3), S10, 256, 256, 0, what="dgrad"),
