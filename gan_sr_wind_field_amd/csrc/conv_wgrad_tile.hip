@@ -310,7 +310,11 @@ __global__ __launch_bounds__(512) void wgrad_tile_kernel(const WgtArgs a) {
   // second dy set and a ring: they fetch per slot, LEAN)
   constexpr bool LEAN = SPW * TN * 4 >= 192;
   constexpr int R = SPW % 7 == 0 ? 7 : (SPW % 4 == 0 ? 4 : (SPW % 3 == 0 ? 3 : 1));
+#ifdef WSR_WG_D
+  constexpr int D = R > WSR_WG_D ? WSR_WG_D : R - 1;
+#else
   constexpr int D = R > 3 ? 3 : R - 1;
+#endif
   struct KP { const char *xlo, *xhi, *rlo, *rhi; int slo, shi; };
   // Voxel <-> MFMA k mapping of a 32-voxel K-step.  Z16 (tile z extent a multiple of 16, every shipped
   // shape): lane group G takes voxels 16*(G>>1) + 4*(G&1) + q and the same + 8 - both in ONE z column, so the

@@ -999,6 +999,32 @@ extern "C" int wsr_chan_sum(const void* x, int32_t x_ctot, int32_t x_off, int32_
   return 0;
 }
 
+static long chan_sum_grid(int C, long nvox) {
+  const int groups = C / 4, lanes = 256 / groups;
+  long grid = (nvox + (long)lanes * 16 - 1) / ((long)lanes * 16);  // >= 16 voxels per thread
+  if (grid > WSR_CHAN_SUM_ROWS) grid = WSR_CHAN_SUM_ROWS;
+  return grid < 1 ? 1 : grid;
+}
+
+extern "C" int wsr_chan_sum_rows(int32_t C, int64_t nvox) {
+  if (C <= 0 || C % 4 || C > 1024 || nvox <= 0) return 0;
+  return (int)chan_sum_grid(C, (long)nvox);
+}
+
+extern "C" int wsr_chan_sum_partials(const void* x, int32_t x_ctot, int32_t x_off, int32_t C, int64_t nvox,
+                                     float* partials, int32_t dtype, void* stream) {
+  if (!x || !partials || C <= 0 || nvox <= 0 || x_off < 0 || x_off + C > x_ctot) return WSR_EINVAL;
+  if (C % 4 || C > 1024 || x_ctot % 4 || x_off % 4) return WSR_EUNSUPPORTED;
+  const long grid = chan_sum_grid(C, (long)nvox);
+  DISPATCH_T(dtype,
+             hipLaunchKernelGGL(chan_sum_kernel<BF16>, dim3((unsigned)grid), dim3(256), 0, as_stream(stream),
+                                (const unsigned short*)x, x_ctot, x_off, C, (long)nvox, partials),
+             hipLaunchKernelGGL(chan_sum_kernel<F32>, dim3((unsigned)grid), dim3(256), 0, as_stream(stream),
+                                (const float*)x, x_ctot, x_off, C, (long)nvox, partials));
+  WSR_LAUNCH_CHECK();
+  return 0;
+}
+
 extern "C" int wsr_plane_sum(const float* src, int32_t B, int32_t C, int64_t V, float* out, float* partials, void* stream) {
   if (!src || !out || !partials || B <= 0 || C <= 0 || C > 1024 || V <= 0) return WSR_EINVAL;
   long rows = (V + 16383) / 16384;  // >= 64 elements per thread

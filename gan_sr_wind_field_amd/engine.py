@@ -1046,7 +1046,14 @@ class GeneratorProgram(ProgramBase):
                 # LFF (1x1x1, bias): out = rdb_scale * (LFF(buf) + b) + x
                 self.wgrad(lff, buf, 0, go, 0, flat, sp, scratch, scale=rdb_scale)
                 gb = sp.view(flat, lff.bias)
-                if not ops.chan_sum(go, 0, nf, gb, scale=rdb_scale):
+                rows = ops.chan_sum_rows(nf, go.numel() // go.shape[-1]) if DETERMINISTIC else 0
+                if rows:
+                    # first pass now (go is overwritten below), the sum over the partial rows rides on the ordered
+                    # reduce of the filter gradients: a job with one output row and `rows` split copies
+                    pr = self._arena_take(rows * nf, dev).view(rows, nf)
+                    ops.chan_sum_partials(go, 0, nf, pr)
+                    self._pending_unpack.append((pr[0].view(1, 1, nf), gb.view(1, nf, 1), rdb_scale, rows, nf))
+                elif not ops.chan_sum(go, 0, nf, gb, scale=rdb_scale):
                     gb.copy_(go[..., :nf].float().sum(dim=(0, 1, 2, 3)) * rdb_scale)
                 # gd[off_i : off_i+gc] is the gradient w.r.t. the LeakyReLU output of growth conv i; it is
                 # complete once the LFF and the later convs have added into it, so the kernel that makes the

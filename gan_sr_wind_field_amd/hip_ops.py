@@ -401,6 +401,23 @@ def chan_sum(x: Tensor, x_off: int, C_: int, out: Tensor, scale: float = 1.0) ->
     return True
 
 
+def chan_sum_rows(C_: int, nvox: int) -> int:
+    """partial rows the first pass of :func:`chan_sum` writes for this shape (0: shape not covered)"""
+    return int(_lib.lib().wsr_chan_sum_rows(C_, nvox))
+
+
+def chan_sum_partials(x: Tensor, x_off: int, C_: int, partials: Tensor) -> None:
+    """first pass of :func:`chan_sum` only: ``partials`` (rows, C) fp32 gets one row of sums per workgroup; the rows
+    are added later (``wsr_unpack_wgrad_reduce_multi`` job with n_parts = rows)"""
+    _need_cuda(x, partials)
+    nvox = x.numel() // x.shape[-1]
+    if partials.dtype != torch.float32 or not partials.is_contiguous() or \
+            tuple(partials.shape) != (chan_sum_rows(C_, nvox), C_):
+        raise ValueError("chan_sum_partials wants a contiguous fp32 (rows, C) buffer")
+    check(_lib.lib().wsr_chan_sum_partials(_p(x), x.shape[-1], x_off, C_, nvox, _p(partials), dtype_id(x.dtype),
+                                           _stream()), "chan_sum_partials")
+
+
 def plane_sum(src: Tensor, out: Tensor) -> Tensor:
     """``out[c] = sum_{b, voxels} src[b, c]`` for a planar fp32 (B, C, ...) tensor (fp32, overwritten)"""
     _need_cuda(src, out)

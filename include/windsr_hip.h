@@ -238,6 +238,13 @@ int wsr_chan_axpby(void* dst, int32_t d_ctot, int32_t d_off, const void* src, in
 #define WSR_CHAN_SUM_ROWS 512
 int wsr_chan_sum(const void* x, int32_t x_ctot, int32_t x_off, int32_t C, int64_t nvox, float scale, float* out,
                  float* partials, int32_t dtype, void* stream);
+/* First pass of wsr_chan_sum alone: row r of `partials` (wsr_chan_sum_rows(C, nvox) rows of C floats, caller-owned)
+ * receives the sums of workgroup r.  The rows can then be added by wsr_unpack_wgrad_reduce_multi together with the
+ * filter gradients of the same backward pass (job: Cout = 1, taps = 1, Cin = kpad = C, n_parts = rows, part_stride =
+ * C) - one launch less per bias gradient (48 per backward pass of the generator).                          */
+int wsr_chan_sum_rows(int32_t C, int64_t nvox);
+int wsr_chan_sum_partials(const void* x, int32_t x_ctot, int32_t x_off, int32_t C, int64_t nvox, float* partials,
+                          int32_t dtype, void* stream);
 /* backward of nearest x(2,2,1) up-sampling: dx[b,x,y,z,c] = sum of the 4 dy    */
 int wsr_upsample2_bwd(const void* dy, void* dx, int32_t B, int32_t Xi, int32_t Yi, int32_t Zi,
                       int32_t C, int32_t dtype, void* stream);
