@@ -382,11 +382,45 @@ void conv_tile_kernel(const CtArgs a) {
         }
         if (tsi < hi) mma_frags(wA, xA);
       } else {
+#if defined(WSR_CT_XAHEAD)
+        // wide tiles (no room for a second fragment set; the translation unit defines WSR_CT_XAHEAD): the activation
+        // fragment of m-tile i+1 is requested before the MFMAs of m-tile i - two in registers instead of the
+        // compiler's one, which it fetches AFTER issuing the previous tile's MFMAs and then waits for (ISA: "R wait
+        // 9 x MFMA" four times per K-step); WSR_CT_XAHEAD == 2: and the tap offset one K-step ahead.  Measured on the
+        // 5x5x5 144 -> 144 conv: 7.68 -> 7.46 ms (= 2), 128-wide tiles -2 % (= 1; = 2 is no better there).  NOT kept:
+        // n-tiles outer / m-tiles inner with a weight-fragment ring and the next K-step's activation fragments
+        // requested one per n-tile (no LDS round trip exposed at all): 1-3 % SLOWER than this form; reloading the
+        // weight fragments in place behind their last use: slower as well.
+        int toff = tt[lo * TPK] * RB;
+        for (int tsi = lo; tsi < hi; ++tsi) {
+          uint4 xf[2], wf[TN];
+#pragma unroll
+          for (int j = 0; j < TN; ++j) wf[j] = *reinterpret_cast<const uint4*>(wcur + (tsi * NTW + j) * 1024);
+#if WSR_CT_XAHEAD == 2
+          const int toff_n = tt[(tsi + 1) * TPK] * RB;  // (past the stage's last K-step: read, never used)
+#else
+          toff = tt[tsi * TPK] * RB;
+#endif
+          xf[0] = *reinterpret_cast<const uint4*>(xcur + hb[0] + toff);
+#pragma unroll
+          for (int i = 0; i < TM; ++i) {
+            if (i + 1 < TM) xf[(i + 1) & 1] = *reinterpret_cast<const uint4*>(xcur + hb[i + 1] + toff);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) mma_chunk<BF16>(acc[i][j], wf[j], xf[i & 1]);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+#if WSR_CT_XAHEAD == 2
+          toff = toff_n;
+#endif
+        }
+#else
         for (int tsi = lo; tsi < hi; ++tsi) {
           uint4 wf[TN], xf[TM];
           load_frags(tsi, wf, xf);
           mma_frags(wf, xf);
         }
+#endif
       }
     };
     const int mid = (STAGGER && wave >= WAVES / 2) ? ts_end / 2 : 0;  // wave-uniform

@@ -2,6 +2,7 @@
 // n-tiles).  At the trunk's resolution (32 x 32 x 128 voxels) that is one workgroup per CU in a single
 // round; the 256-voxel tiles of conv_tile_wide.hip need two rounds there, pay the prologue and epilogue
 // twice and stream every filter stage twice as often per flop.
+#define WSR_CT_XAHEAD 1  // operand requests of the K-step loop: see run_ksteps
 #include "conv_tile_impl.h"
 
 template <int TPK>

@@ -2,6 +2,7 @@
 // One translation unit per output-width family: hipcc's register allocation of one template instantiation
 // is perturbed by its co-compiled siblings (the 144-wide kernel lost 5 % when masked variants were added
 // next to it), so the hot instantiations get a compilation unit of their own.
+#define WSR_CT_XAHEAD 2  // operand requests of the K-step loop: see run_ksteps
 #include "conv_tile_impl.h"
 
 template <int TPK>
