@@ -133,10 +133,22 @@ class Discriminator_3D(nn.Module, lc.GlobalLoggingClass):
     def compute_dtype(self, dt) -> None:
         self.features.compute_dtype = engine.compute_dtype_of(dt)
 
+    def _classify(self, h: torch.Tensor) -> torch.Tensor:
+        """``self.classifier(h)``; its first layer - a few samples x 100 outputs x ~10^5 features, a weight matrix of
+        tens of MB read once - goes through the streaming row kernel (``wsr_linear_rows``) where that applies"""
+        from .. import hip_ops
+        lin = self.classifier[0]
+        z = hip_ops.linear_rows(h, lin.weight, lin.bias) if isinstance(lin, nn.Linear) else None
+        if z is None:
+            return self.classifier(h)
+        for m in list(self.classifier)[1:]:
+            z = m(z)
+        return z
+
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         h = self.dropout(self.features(x))
         h = h.reshape(h.shape[0], -1)  # logical (C, X, Y, Z) order, as in the reference (:191-192)
-        return self.classifier(h)
+        return self._classify(h)
 
     def forward_pair(self, xa: torch.Tensor, xb):
         """(D(xa), D(xb)) as two consecutive calls would give them - the reference's D(real), D(fake) of one iteration
@@ -158,5 +170,5 @@ class Discriminator_3D(nn.Module, lc.GlobalLoggingClass):
         for h, m in ((f[:b], mask_a), (f[b:], mask_b)):
             if m is not None:
                 h = h * m
-            outs.append(self.classifier(h.reshape(h.shape[0], -1)))
+            outs.append(self._classify(h.reshape(h.shape[0], -1)))
         return outs[0], outs[1]

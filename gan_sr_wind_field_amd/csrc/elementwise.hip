@@ -595,6 +595,46 @@ __global__ void zunfold_kernel(const float* __restrict__ g, typename T::elem* __
 }
 
 
+// ---- y[b][n] = bias[n] + sum_k x[b][k] * w[n][k] for a handful of rows b and a very long k ---------------
+// (the first classifier layer of the discriminator: 1..8 samples x 100 outputs x 131 072 features - a 52 MB
+// weight matrix read once; the library GEMM picks a 13-workgroup tile for this shape and streams at 0.4 TB/s).
+// One workgroup of 16 waves per output row: 64 KB of loads in flight per row, fp32 accumulation, block reduce.
+template <int BMAX>
+__global__ __launch_bounds__(1024) void linear_rows_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                           const float* __restrict__ bias, float* __restrict__ y, int B,
+                                                           int N, long K) {
+  __shared__ float sh[BMAX][16];
+  const int n = blockIdx.x;
+  const float4* __restrict__ wr = reinterpret_cast<const float4*>(w + (long)n * K);
+  float acc[BMAX];
+#pragma unroll
+  for (int b = 0; b < BMAX; ++b) acc[b] = 0.f;
+  const long K4 = K >> 2;
+  for (long i = threadIdx.x; i < K4; i += 1024) {
+    const float4 wv = wr[i];
+#pragma unroll
+    for (int b = 0; b < BMAX; ++b)
+      if (b < B) {
+        const float4 xv = reinterpret_cast<const float4*>(x + (long)b * K)[i];
+        acc[b] += wv.x * xv.x + wv.y * xv.y + wv.z * xv.z + wv.w * xv.w;
+      }
+  }
+#pragma unroll
+  for (int b = 0; b < BMAX; ++b) {
+    float a = acc[b];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) a += __shfl_xor(a, off, 64);
+    if ((threadIdx.x & 63) == 0) sh[b][threadIdx.x >> 6] = a;
+  }
+  __syncthreads();
+  if (threadIdx.x < B) {
+    float a = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) a += sh[threadIdx.x][k];  // fixed order: bit-reproducible
+    y[(long)threadIdx.x * N + n] = a + (bias ? bias[n] : 0.f);
+  }
+}
+
 // ---- per-channel sum of a planar fp32 tensor (B, C, V): the bias gradient of the last conv -----------------
 // row blockIdx.y of `part` gets the C partial sums of slice blockIdx.y; chan_sum_final_kernel adds the rows
 __global__ __launch_bounds__(256) void plane_sum_kernel(const float* __restrict__ src, int B, int C, long V,
@@ -1021,6 +1061,18 @@ extern "C" int wsr_chan_sum_partials(const void* x, int32_t x_ctot, int32_t x_of
                                 (const unsigned short*)x, x_ctot, x_off, C, (long)nvox, partials),
              hipLaunchKernelGGL(chan_sum_kernel<F32>, dim3((unsigned)grid), dim3(256), 0, as_stream(stream),
                                 (const float*)x, x_ctot, x_off, C, (long)nvox, partials));
+  WSR_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int wsr_linear_rows(const float* x, const float* w, const float* bias, float* y, int32_t B, int32_t N,
+                               int64_t K, void* stream) {
+  if (!x || !w || !y || B <= 0 || N <= 0 || K <= 0) return WSR_EINVAL;
+  if (B > 8 || (K & 3) || (((size_t)x | (size_t)w) & 15)) return WSR_EUNSUPPORTED;
+  if (B <= 2)
+    hipLaunchKernelGGL(linear_rows_kernel<2>, dim3((unsigned)N), dim3(1024), 0, as_stream(stream), x, w, bias, y, B, N, (long)K);
+  else
+    hipLaunchKernelGGL(linear_rows_kernel<8>, dim3((unsigned)N), dim3(1024), 0, as_stream(stream), x, w, bias, y, B, N, (long)K);
   WSR_LAUNCH_CHECK();
   return 0;
 }

@@ -418,6 +418,43 @@ def chan_sum_partials(x: Tensor, x_off: int, C_: int, partials: Tensor) -> None:
                                            _stream()), "chan_sum_partials")
 
 
+#: first classifier layer of the discriminator through the streaming row kernel (WSR_LINEAR_ROWS=0: library GEMM)
+LINEAR_ROWS = __import__("os").environ.get("WSR_LINEAR_ROWS", "1") != "0"
+
+
+class _LinearRows(torch.autograd.Function):
+    """``F.linear(x, w, b)`` for a few rows x and a very long reduction (``wsr_linear_rows``); backward = the
+    matrix products autograd would issue."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        y = torch.empty((x.shape[0], w.shape[0]), dtype=torch.float32, device=x.device)
+        check(_lib.lib().wsr_linear_rows(_p(x), _p(w), _p(b), _p(y), x.shape[0], w.shape[0], x.shape[1], _stream()),
+              "linear_rows")
+        ctx.save_for_backward(x, w)
+        ctx.has_bias = b is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w = ctx.saved_tensors
+        gx = g @ w if ctx.needs_input_grad[0] else None
+        gw = g.t() @ x if ctx.needs_input_grad[1] else None
+        gb = g.sum(0) if ctx.has_bias and ctx.needs_input_grad[2] else None
+        return gx, gw, gb
+
+
+def linear_rows(x: Tensor, w: Tensor, b: Optional[Tensor]) -> Optional[Tensor]:
+    """``x @ w.T + b`` through ``wsr_linear_rows`` when the shape is the one it is built for (fp32, <= 8 rows, long
+    contiguous reduction), else None (the caller uses ``F.linear``)."""
+    if not (LINEAR_ROWS and x.is_cuda and x.dtype == torch.float32 and w.dtype == torch.float32 and x.dim() == 2 and x.shape[0] <= 8
+            and x.shape[1] % 4 == 0 and x.shape[1] >= 8192 and x.is_contiguous() and w.is_contiguous()
+            and (b is None or (b.dtype == torch.float32 and b.is_contiguous()))):
+        return None
+    _need_cuda(x, w, b)
+    return _LinearRows.apply(x, w, b)
+
+
 def plane_sum(src: Tensor, out: Tensor) -> Tensor:
     """``out[c] = sum_{b, voxels} src[b, c]`` for a planar fp32 (B, C, ...) tensor (fp32, overwritten)"""
     _need_cuda(src, out)

@@ -286,6 +286,12 @@ int wsr_wind_gradient(const float* f, const float* xs, const float* ys, const fl
 int wsr_wind_gradient_bwd(const float* g, const float* xs, const float* ys, const float* zc, float* df, int32_t B,
                           int32_t X, int32_t Y, int32_t Z, void* stream);
 
+/* nn.Linear forward for a handful of rows and a very long reduction (the discriminator's first classifier layer,
+ * Discriminator_3D.py:171-175: 1..8 samples x 100 outputs x 256*4*4*z features): y (B, N) = x (B, K) w^T (N, K) +
+ * bias, fp32, one workgroup per output row streaming its weight row once -> aten::addmm.  B <= 8 and K a multiple
+ * of 4 (WSR_EUNSUPPORTED otherwise: the caller uses the library GEMM).  Bit-reproducible.                  */
+int wsr_linear_rows(const float* x, const float* w, const float* bias, float* y, int32_t B, int32_t N, int64_t K,
+                    void* stream);
 /* out[c] = sum over b, v of src[b][c][v] for a planar fp32 (B, C, V) tensor - the bias gradient of a conv whose
  * output gradient arrives planar (hr_convs.2, Generator_3D_Resnet_ESRGAN.py:105-110; aten: sum.dim_IntList).
  * Two passes through `partials` (WSR_CHAN_SUM_ROWS * C floats), no atomics.                                  */
