@@ -38,7 +38,16 @@ def pad_channels(c: int, dt: torch.dtype) -> int:
     return (c + e - 1) // e * e
 
 
+# torch.cuda.current_stream() / current_device() cost ~8 us / ~1 us of Python per call (device-index normalisation,
+# lazy-init checks, a Stream object); at ~2 000 launches per step that is most of the host time of the launch-bound
+# real-data shapes.  The raw accessors below are what they end in.
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+_raw_device = getattr(torch._C, "_cuda_getDevice", None)
+
+
 def _stream() -> C.c_void_p:
+    if _raw_stream is not None and _raw_device is not None:
+        return C.c_void_p(_raw_stream(_raw_device()))
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
@@ -56,7 +65,7 @@ def _need_cuda(*ts: Tensor) -> None:
         if not t.is_cuda:
             raise RuntimeError("windsr_hip kernels need device tensors (no CPU fallback)")
         if cur < 0:
-            cur = torch.cuda.current_device()
+            cur = _raw_device() if _raw_device is not None else torch.cuda.current_device()
         if t.device.index != cur:
             raise RuntimeError(f"windsr_hip: tensor on {t.device} but the current device is cuda:{cur} "
                                "(set torch.cuda.set_device / cfg.device for this rank)")

@@ -15,7 +15,7 @@ import bench  # noqa: E402
 
 
 class A:
-    ini, slicing, n, nz, batch, dtype = "local", False, 32, 128, 1, "bf16"
+    ini, slicing, n, nz, batch, dtype = "local", False, 32, int(os.environ.get("HP_NZ", "128")), 1, "bf16"
 
 
 def main():
@@ -23,7 +23,7 @@ def main():
     torch.cuda.set_device(dev)
     gan, cfg = bench.make_gan(A, dev, "bf16")
     from gan_sr_wind_field_amd.process_data import synthetic_batch
-    LR, HR, Z, x, y = (t.to(dev) for t in synthetic_batch(1, 32, 128, 4))
+    LR, HR, Z, x, y = (t.to(dev) for t in synthetic_batch(1, 32, A.nz, 4))
     gan.feed_xy_niter(x, y, torch.tensor(150000, device=dev), 1, 1)
 
     def step(i):
