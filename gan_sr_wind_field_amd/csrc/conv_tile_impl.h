@@ -677,7 +677,10 @@ int launch_ct(CtArgs& a, hipStream_t st) {
   a.ablate = getenv("WSR_CT_ABL") ? atoi(getenv("WSR_CT_ABL")) : 0;
   a.stamps = getenv("WSR_CT_STAMPS_PTR") ? (unsigned long long*)strtoull(getenv("WSR_CT_STAMPS_PTR"), nullptr, 0) : nullptr;
 #endif
-  a.prio = getenv("WSR_CT_PRIO") ? atoi(getenv("WSR_CT_PRIO")) : 1;  // measured: +1 % on the 144- and 128-wide tiles
+  // static priority for the younger half of the workgroup: measured again on the final kernels - +1.2 % on the
+  // 144-wide 5x5x5 tile, but -1.5 ... -4 % on every other instantiation (128-wide: 109.7 -> 106.6 us, narrow:
+  // 24.0 -> 23.5 us, 160..224-wide: 60.0 -> 58.2 us) since the operand requests moved ahead of the MFMAs
+  a.prio = getenv("WSR_CT_PRIO") ? atoi(getenv("WSR_CT_PRIO")) : (TN == 9 ? 1 : 0);
   // Few workgroups and a long reduction (the deep layers of the discriminator: 16..128 workgroups walking
   // 16..32 chunks x 27..48 taps one after the other, 50-90 us at a few per cent of the chip): split the chunks over
   // ksplit times as many workgroups; the partial sums go through the caller's workspace.
