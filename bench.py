@@ -11,6 +11,13 @@ LR (B,4,32,32,128) -> HR (B,3,128,128,128), full-size G (16 RRDB, nf 128) and th
                     [--dtype bf16|fp32] [--batch B] [--n N --nz NZ]
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
 
+``--gpus N`` with N > 1 and no torchrun environment starts the N ranks itself: the parent - before it makes any
+GPU call - runs ``python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1`` on this
+same file as a CHILD process and exits with its code (one process per GPU over RCCL; N = 1 stays in-process so
+that ``rocprofv3 -- python bench.py`` profiles the benchmark itself).  ``--dry-launch`` stops every rank after the
+rendezvous (gloo, no GPU): the CPU test of the launcher.  ``--backend gloo --one-device`` rehearses the
+N-rank step on ONE card (ranks share cuda:0; RCCL refuses duplicate devices, gloo does not).
+
 ``--config`` selects the other BASELINE.json configurations; they are recorded in
 DESIGN.md, the driver's line is always the default C3'.  Rank 0 prints ONE JSON line.
 """
@@ -120,14 +127,64 @@ def cpu_baseline(n_threads):
     return dt, pair_flops
 
 
+TRAFFIC_JSON = "profiles/r03_hbm_traffic.json"
+
+
 def recorded_traffic(key):
-    """HBM bytes per launch from the PMC passes of this round (profiles/r02_hbm_traffic.json, written from the
-    rocprofv3 --pmc summaries by tools/tuning/pmc_sum.py; gfx950 FETCH_SIZE correction applied there)."""
+    """HBM bytes per launch from the PMC passes of this round (TRAFFIC_JSON, written from the rocprofv3 --pmc
+    summaries by tools/tuning/pmc_step_sum.py; gfx950 FETCH_SIZE correction applied there).  Recorded, not
+    measured in this run: the JSON line says so (``traffic_measured_in_run: false``)."""
     try:
-        with open(os.path.join(ROOT, "profiles", "r02_hbm_traffic.json")) as f:
+        with open(os.path.join(ROOT, TRAFFIC_JSON)) as f:
             return json.load(f).get(key)
     except (OSError, ValueError):
         return None
+
+
+def free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def launch_ranks(args, argv):
+    """Start ``args.gpus`` rank processes of this file through torch.distributed.run as a CHILD of this process
+    (which has made no GPU call: a process that has initialised the GPU must never be replaced or forked into
+    ranks) and return the child's exit code."""
+    import subprocess
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(args.master_port or free_port()),
+           os.path.abspath(__file__)] + argv
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // args.gpus)))
+    return subprocess.run(cmd, env=env).returncode
+
+
+def dry_launch(args):
+    """rendezvous only (gloo, CPU): proves that ``--gpus N`` produced N ranks; rank 0 prints the JSON line"""
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE {world}"
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="gloo")
+        ones = torch.ones(1)
+        dist.all_reduce(ones)
+        ranks = dist.get_world_size()
+        assert int(ones.item()) == ranks == world
+        seen = [None] * world
+        dist.all_gather_object(seen, (rank, int(os.environ.get("LOCAL_RANK", "0"))))
+        dist.barrier()
+        dist.destroy_process_group()
+    else:
+        seen = [(0, 0)]
+    if rank == 0:
+        print(json.dumps({"dry_launch": True, "n_gpus": world, "ranks": [list(x) for x in seen]}))
 
 
 def main():
@@ -141,7 +198,19 @@ def main():
     ap.add_argument("--n", type=int, default=None, help="LR X=Y extent")
     ap.add_argument("--nz", type=int, default=None, help="vertical levels")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="nccl = RCCL over xGMI")
+    ap.add_argument("--one-device", action="store_true", help="every rank on cuda:0 (rehearsal with --backend gloo)")
+    ap.add_argument("--dry-launch", action="store_true", help="rendezvous of the N ranks only (CPU, gloo)")
+    ap.add_argument("--master-port", type=int, default=None)
+    ap.add_argument("--no-comm-timing", action="store_true", help="no HIP events around the collectives")
     args = ap.parse_args()
+    if args.gpus < 1:
+        ap.error("--gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # no torchrun environment: become the launcher BEFORE anything touches the GPU
+        sys.exit(launch_ranks(args, sys.argv[1:]))
+    if args.dry_launch:
+        return dry_launch(args)
     ini, n0, nz0, b0, dt0, kind, slicing, desc = PRESETS[args.config]
     args.ini, args.slicing = ini, slicing
     args.n = n0 if args.n is None else args.n
@@ -155,11 +224,21 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE {world}: the line would be mislabelled"
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs"
+    if args.one_device:
+        local = 0
+        os.environ["LOCAL_RANK"] = "0"
     dev = torch.device(f"cuda:{local}")
     torch.cuda.set_device(dev)
-    distributed = wdist.init_from_env("nccl")
-    assert world == args.gpus or not distributed, f"--gpus {args.gpus} but WORLD_SIZE {world}"
+    distributed = wdist.init_from_env(args.backend)
+    assert distributed == (world > 1)
+    rccl_ranks = 1
+    if distributed:  # an actual collective, not the environment: this many ranks answered
+        ones = torch.ones(1, device=dev)
+        torch.distributed.all_reduce(ones)
+        rccl_ranks = int(ones.item())
+        assert rccl_ranks == torch.distributed.get_world_size() == args.gpus
 
     gan, cfg = make_gan(args, dev, args.dtype)
     dp = wdist.attach(gan, bucket_mb=cfg.dist.bucket_mb, sync_bn=cfg.dist.sync_bn) if distributed else None
@@ -171,8 +250,11 @@ def main():
     # ---- live timing (HIP events on the launch stream, inside the timed region) of
     #   the dominant MFMA-bound kernel: the N=144 halo-tile conv (hr0 forward + its input gradient)
     #   the dominant HBM-bound kernel:  the streaming 1x1x1 conv (LFF forward, 256 -> 128)
-    probe_events = {"mfma": [], "hbm": []}
+    #   the memory-bound conv3d launches: the last conv in z-folded form - forward (5,5,1) 144 -> 15 and its input
+    #   gradient 15 -> 144 with the LeakyReLU / Dropout3d mask of the 5x5x5 conv below it in the epilogue
+    probe_events = {"mfma": [], "hbm": [], "hbm_res2": [], "conv_dgrad": [], "conv_fwd": []}
     timing_on = [False]
+    last_conv = "hr_convs.2.zfold" if gan.G.program().zfold_active() else "hr_convs.2"
 
     def probe(tag, fn):
         which = None
@@ -180,7 +262,12 @@ def main():
             if tag in ("fwd:hr_convs.0.0", "dgrad:hr_convs.0.0"):
                 which = "mfma"
             elif tag.startswith("fwd:") and tag.endswith(".LFF"):
-                which = "hbm"
+                # the last block of an RRDB also reads the RRDB shortcut (a second residual: 128 more channels)
+                which = "hbm_res2" if tag.endswith(".RDBs.2.LFF") else "hbm"
+            elif tag == "dgrad:" + last_conv:
+                which = "conv_dgrad"
+            elif tag == "fwd:" + last_conv:
+                which = "conv_fwd"
         if which is None:
             fn()
             return
@@ -215,6 +302,9 @@ def main():
         step(i)
     barrier()
     timing_on[0] = True
+    if dp is not None:
+        dp.stats.reset()
+        dp.stats.timing = not args.no_comm_timing
     t0 = time.perf_counter()
     for i in range(args.warmup, args.warmup + args.steps):
         step(i)
@@ -251,13 +341,43 @@ def main():
     k_ms, k_n = mean_ms(probe_events["mfma"])
     k_flops = 2.0 * B * sX * sX * nz * 125 * 144 * 144
     achieved = k_flops / (k_ms * 1e-3) / 1e12 if k_ms else None
-    h_ms, h_n = mean_ms(probe_events["hbm"])
-    # LFF forward: reads the 256-channel dense buffer once, writes 128 channels, reads the 128-channel residual
-    # (the block input = the first 128 channels of the same buffer: re-read, counted once more), + filter
+    # LFF forward, algorithmic bytes: the 256-channel dense buffer read once + 128 channels written +
+    # the filter.  The block's identity shortcut is the first 128 channels of that same input - the lane's own
+    # K-fragment, no second read.  Every third launch (the last block of an RRDB) also reads the RRDB
+    # shortcut: 128 more channels.  achieved = all algorithmic bytes of the timed launches / their total time.
     vox = B * n * n * nz
-    h_bytes = vox * (256 + 128 + 128) * esz + 256 * 128 * esz
+    h_b1 = vox * (256 + 128) * esz + 256 * 128 * esz
+    h_b2 = h_b1 + vox * 128 * esz
+    h1 = [a.elapsed_time(b) for a, b in probe_events["hbm"]]
+    h2 = [a.elapsed_time(b) for a, b in probe_events["hbm_res2"]]
+    h_n = len(h1) + len(h2)
+    h_ms = (sum(h1) + sum(h2)) / h_n if h_n else None
+    h_bytes = (len(h1) * h_b1 + len(h2) * h_b2) / h_n if h_n else None
     h_ach = h_bytes / (h_ms * 1e-3) / 1e9 if h_ms else None
+    # the memory-bound conv3d pair (reference Generator_3D_Resnet_ESRGAN.py:105-110, hr_convs[2]): per launch the
+    # 144-channel HR tensor (read by the forward; written by the input gradient, which also reads the saved
+    # 144-channel output of hr_convs[0] for its LeakyReLU / Dropout3d mask) + the 3-channel side as stored
+    # (z-folded: 15 planar fp32 partial sums forward, 16 bf16 channels backward) + the filter
+    V = B * sX * sX * nz
+    kz_fold = gan.G.program().hr1.kernel[2] if gan.G.program().zfold_active() else 1
+    c_hr = 144
+    cf_bytes = V * (c_hr * esz + 3 * kz_fold * 4) + 125 * c_hr * 3 * esz
+    cd_bytes = V * ((3 * kz_fold + 7) // 8 * 8 * esz + 2 * c_hr * esz) + 125 * c_hr * 3 * esz
+
+    def hbm_block(evs, nbytes, kernel):
+        ms_, n_ = mean_ms(evs)
+        ach = nbytes / (ms_ * 1e-3) / 1e9 if ms_ else None
+        return {"bound": "hbm", "kernel": kernel, "achieved": round(ach, 1) if ach else None, "peak": 8000.0,
+                "unit": "GB/s", "frac": round(ach / 8000.0, 4) if ach else None, "traffic": None,
+                "algorithmic_bytes": int(nbytes), "launches_timed": n_,
+                "avg_launch_us": round(ms_ * 1e3, 2) if ms_ else None}
+
+    conv_d = hbm_block(probe_events["conv_dgrad"], cd_bytes,
+                       "hr_convs.2 input gradient (z-folded 15 -> 144, 5x5x1, LeakyReLU+Dropout3d mask epilogue)")
+    conv_f = hbm_block(probe_events["conv_fwd"], cf_bytes, "hr_convs.2 forward (z-folded 144 -> 15, 5x5x1, planar fp32 out)")
     default_shape = args.dtype == "bf16" and n == 32 and nz == 128 and B == 1 and s == 4
+    if default_shape:
+        conv_d["traffic"], conv_f["traffic"] = recorded_traffic("hr1_dgrad"), recorded_traffic("hr1_fwd")
     out = {
         "metric": "GAN train-steps/sec (G+D fwd+bwd)" if kind == "gan" else "generator train-steps/sec (G fwd+bwd+Adam)",
         "value": round(value, 4), "unit": "train-steps/s",
@@ -267,6 +387,7 @@ def main():
         "config": {"workload": f"{desc}: LR {n}x{n}x{nz} -> HR {sX}x{sX}x{nz} (x{s}), batch {B}/GPU, "
                                f"G 16 RRDB nf128 (34.77M)" + (f", D bf32{' sliced' if slicing else ''}" if kind == "gan" else ""),
                    "preset": args.config, "global_batch": B * world, "parallelism": f"dp{world}",
+                   "rccl_ranks": rccl_ranks, "backend": args.backend if distributed else None,
                    "global_steps_per_s": round(steps_per_s, 4), "samples_per_s": round(world * B * steps_per_s, 4),
                    "step_tflop": round(step_flops / 1e12, 2),
                    "achieved_tflops_per_gpu": round(step_flops / 1e12 / (elapsed / args.steps), 1),
@@ -278,15 +399,26 @@ def main():
                      "achieved": round(achieved, 1) if achieved else None, "peak": peak, "unit": "TFLOP/s",
                      "frac": round(achieved / peak, 4) if achieved else None,
                      "traffic": recorded_traffic("hr0") if default_shape else None,
-                     "traffic_source": "profiles/r02_hbm_traffic.json (PMC passes of this round)" if default_shape else None,
+                     "traffic_source": TRAFFIC_JSON + " (PMC passes of this round)" if default_shape else None,
+                     "traffic_measured_in_run": False,
                      "launches_timed": k_n, "avg_launch_ms": round(k_ms, 3) if k_ms else None},
         "roofline_hbm": {"bound": "hbm", "kernel": "conv1x1_kernel (streaming 1x1x1 GEMM): RDB LFF 256->128 fwd + residuals",
                          "achieved": round(h_ach, 1) if h_ach else None, "peak": 8000.0, "unit": "GB/s",
                          "frac": round(h_ach / 8000.0, 4) if h_ach else None,
                          "traffic": recorded_traffic("lff_fwd") if default_shape else None,
-                         "algorithmic_bytes": h_bytes, "launches_timed": h_n,
+                         "traffic_measured_in_run": False,
+                         "algorithmic_bytes": int(h_bytes) if h_bytes else None, "launches_timed": h_n,
+                         "launches_with_second_residual": len(h2),
                          "avg_launch_us": round(h_ms * 1e3, 2) if h_ms else None},
+        # the worse of the two memory-bound conv3d launches carries the name; both are listed
+        "roofline_hbm_conv": dict(min((conv_d, conv_f), key=lambda r: r["frac"] if r["frac"] is not None else 9.0),
+                                  traffic_measured_in_run=False),
+        "roofline_hbm_convs": [conv_d, conv_f],
     }
+    if dp is not None:
+        out["comm"] = dp.stats.summary(args.steps)
+        out["comm"]["bucket_mb"] = cfg.dist.bucket_mb
+        out["comm"]["sync_bn"] = bool(cfg.dist.sync_bn)
     if world == 1 and not args.no_cpu_baseline:
         cores = min(os.cpu_count() or 1, 16)
         dt, sample_flops = cpu_baseline(cores)

@@ -157,8 +157,11 @@ class Discriminator_3D(nn.Module, lc.GlobalLoggingClass):
         the fake sample's instance noise AFTER the first call): the random draws keep the reference's order - first
         call's Dropout3d mask, ``xb()``, second call's mask; a Dropout3d mask is one Bernoulli draw per (sample,
         channel), whatever the spatial extent, so it is drawn on a (B, C, 1, 1, 1) tensor ahead of the features."""
+        if not xa.is_cuda:
+            raise RuntimeError("Discriminator_3D runs on the HIP kernels only (no CPU fallback): move the inputs "
+                               "to the MI355X device")
         b = xa.shape[0]
-        c = self.features.program().layers[-1].conv.cout if xa.is_cuda else None
+        c = self.features.program().layers[-1].conv.cout
         drop = self.training and self.dropout.p > 0
         ones = (lambda: torch.ones((b, c, 1, 1, 1), dtype=torch.float32, device=xa.device)) if drop else None
         mask_a = self.dropout(ones()) if drop else None

@@ -30,6 +30,18 @@ import torch.distributed as dist
 
 Tensor = torch.Tensor
 
+#: ledger of the attached DataParallel (the autograd functions below have no handle on it)
+_STATS: list = [None]
+
+
+def _note(kind: str, t: "Tensor") -> None:
+    if _STATS[0] is not None:
+        _STATS[0].add(kind, t)
+
+
+def _timed(kind: str, t: "Tensor"):
+    return _STATS[0].bracket(kind, t) if _STATS[0] is not None else _NULL_BRACKET
+
 
 def init_from_env(backend: Optional[str] = None) -> bool:
     """Initialise the default process group from torchrun's environment.  Returns False
@@ -56,7 +68,9 @@ class _BatchMean(torch.autograd.Function):
     def forward(ctx, t: Tensor, group):
         # equal shards per rank: the global element count is numel * world (no device round trip)
         total = t.sum().float().reshape(1)
-        dist.all_reduce(total, group=group)
+        _note("scalar", total)
+        with _timed("scalar", total):
+            dist.all_reduce(total, group=group)
         count = float(t.numel() * dist.get_world_size(group))
         ctx.group, ctx.count, ctx.shape, ctx.dtype = group, count, t.shape, t.dtype
         return (total[0] / count).to(t.dtype)
@@ -64,7 +78,9 @@ class _BatchMean(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g: Tensor):
         g = g.clone().float()
-        dist.all_reduce(g, group=ctx.group)
+        _note("scalar", g)
+        with _timed("scalar", g):
+            dist.all_reduce(g, group=ctx.group)
         # the later gradient average over ranks divides by N once more, exactly as it does
         # for every other term of the per-rank mean losses
         return (g / ctx.count).to(ctx.dtype).expand(ctx.shape), None
@@ -80,7 +96,9 @@ class _GlobalMax(torch.autograd.Function):
     @staticmethod
     def forward(ctx, t: Tensor, group):
         g = t.detach().clone()
-        dist.all_reduce(g, op=dist.ReduceOp.MAX, group=group)
+        _note("scalar", g)
+        with _timed("scalar", g):
+            dist.all_reduce(g, op=dist.ReduceOp.MAX, group=group)
         ctx.group = group
         ctx.save_for_backward(t.detach() == g)
         return g
@@ -89,8 +107,83 @@ class _GlobalMax(torch.autograd.Function):
     def backward(ctx, grad: Tensor):
         (owner,) = ctx.saved_tensors
         grad = grad.clone()
-        dist.all_reduce(grad, group=ctx.group)
+        _note("scalar", grad)
+        with _timed("scalar", grad):
+            dist.all_reduce(grad, group=ctx.group)
         return grad * owner.to(grad.dtype), None
+
+
+class CommStats:
+    """Per-process communication ledger of the data-parallel step (read by ``bench.py`` into its ``comm`` object).
+
+    ``count`` / ``bytes`` per kind of collective ("grad" = gradient buckets, "syncbn", "scalar" = RaGAN batch means,
+    physics-loss maxima and the OR-ed guard flags).  With ``timing`` on, every BLOCKING collective and every
+    ``DataParallel.wait()`` is bracketed by two HIP events on the compute stream: the elapsed time between them is
+    what the compute stream spent behind the collective - the *exposed* communication time (an asynchronous
+    gradient bucket that finished under the backward pass shows up as ~0 in ``wait``).  Events are resolved by
+    ``summary()`` after the caller has synchronised; nothing here blocks the host inside the step."""
+
+    KINDS = ("grad", "syncbn", "scalar")
+
+    def __init__(self):
+        self.timing = False
+        self.reset()
+
+    def reset(self) -> None:
+        self.count = {k: 0 for k in self.KINDS}
+        self.bytes = {k: 0 for k in self.KINDS}
+        self._events = {"wait": [], "syncbn": [], "scalar": []}
+
+    def add(self, kind: str, t: Tensor) -> None:
+        self.count[kind] += 1
+        self.bytes[kind] += t.numel() * t.element_size()
+
+    def bracket(self, kind: str, t: Tensor):
+        """context manager: HIP events around a region of the current stream (no-op unless timing a device tensor)"""
+        return _Bracket(self, kind) if (self.timing and t.is_cuda) else _NULL_BRACKET
+
+    def summary(self, steps: int) -> dict:
+        """per-step figures; call after torch.cuda.synchronize()"""
+        ms = {k: sum(a.elapsed_time(b) for a, b in v) for k, v in self._events.items()}
+        per = lambda x: round(x / max(1, steps), 3)  # noqa: E731
+        return {
+            "collectives_per_step": per(sum(self.count.values())),
+            "grad_bucket_collectives_per_step": per(self.count["grad"]),
+            "grad_mbytes_per_step": per(self.bytes["grad"] / 1e6),
+            "syncbn_collectives_per_step": per(self.count["syncbn"]),
+            "syncbn_kbytes_per_step": per(self.bytes["syncbn"] / 1e3),
+            "scalar_collectives_per_step": per(self.count["scalar"]),
+            "exposed_grad_wait_ms_per_step": per(ms["wait"]) if self.timing else None,
+            "syncbn_blocking_ms_per_step": per(ms["syncbn"]) if self.timing else None,
+            "scalar_blocking_ms_per_step": per(ms["scalar"]) if self.timing else None,
+            "timed": self.timing,
+        }
+
+
+class _Bracket:
+    def __init__(self, stats: "CommStats", kind: str):
+        self.stats, self.kind = stats, kind
+
+    def __enter__(self):
+        self.e0 = torch.cuda.Event(enable_timing=True)
+        self.e0.record()
+
+    def __exit__(self, *exc):
+        e1 = torch.cuda.Event(enable_timing=True)
+        e1.record()
+        self.stats._events[self.kind].append((self.e0, e1))
+        return False
+
+
+class _NullBracket:
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *exc):
+        return False
+
+
+_NULL_BRACKET = _NullBracket()
 
 
 class DataParallel:
@@ -106,6 +199,8 @@ class DataParallel:
         self._pending: List = []      # (work, tensor) of in-flight gradient buckets
         self._open = {}               # program id -> [flat, lo, hi] of the bucket being filled
         self.n_collectives = 0        # bookkeeping for tests / DESIGN.md numbers
+        self.stats = CommStats()
+        _STATS[0] = self.stats
 
     # ---- collectives used inside the step ----------------------------------------
     def batch_mean(self, t: Tensor) -> Tensor:
@@ -116,19 +211,25 @@ class DataParallel:
         if t.requires_grad and torch.is_grad_enabled():
             return _GlobalMax.apply(t, self.group)
         t = t.detach().clone()
-        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+        self.stats.add("scalar", t)
+        with self.stats.bracket("scalar", t):
+            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
         return t
 
     def stat_allreduce(self, t: Tensor) -> None:
-        dist.all_reduce(t, group=self.group)
+        self.stats.add("syncbn", t)
+        with self.stats.bracket("syncbn", t):
+            dist.all_reduce(t, group=self.group)
 
     def stat_allgather(self, t: Tensor) -> Tensor:
         """(world, len(t)) copies of a small vector from every rank - the one collective of a SyncBN forward"""
         out = torch.empty((self.world,) + tuple(t.shape), dtype=t.dtype, device=t.device)
-        if self._avg_native:  # nccl / RCCL
-            dist.all_gather_into_tensor(out, t.contiguous(), group=self.group)
-        else:
-            dist.all_gather(list(out.unbind(0)), t.contiguous(), group=self.group)
+        self.stats.add("syncbn", t)
+        with self.stats.bracket("syncbn", t):
+            if self._avg_native:  # nccl / RCCL
+                dist.all_gather_into_tensor(out, t.contiguous(), group=self.group)
+            else:
+                dist.all_gather(list(out.unbind(0)), t.contiguous(), group=self.group)
         return out
 
     def _avg_async(self, t: Tensor) -> None:
@@ -138,6 +239,7 @@ class DataParallel:
             work = dist.all_reduce(t, group=self.group, async_op=True)
         self._pending.append((work, t))
         self.n_collectives += 1
+        self.stats.add("grad", t)
 
     # ---- gradient buckets ------------------------------------------------------------
     def grad_ready(self, key, flat: Tensor, lo: int, hi: int) -> None:
@@ -159,9 +261,14 @@ class DataParallel:
         self.wait()
 
     def wait(self) -> None:
-        for work, t in self._pending:
-            work.wait()
-            if not self._avg_native:
+        """make the compute stream wait for every gradient bucket in flight (the host does not block on RCCL)"""
+        if not self._pending:
+            return
+        with self.stats.bracket("wait", self._pending[0][1]):
+            for work, t in self._pending:
+                work.wait()
+        if not self._avg_native:
+            for _, t in self._pending:
                 t.div_(self.world)
         self._pending.clear()
 

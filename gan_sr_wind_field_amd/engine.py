@@ -1309,42 +1309,48 @@ class DiscriminatorProgram(ProgramBase):
                 h = a
                 continue
             means, invstds, counts = [], [], []
+            if (self.stat_allgather is None) != (self.stat_allreduce is None):
+                raise RuntimeError("SyncBN needs both statistics hooks (stat_allgather for the forward pass, "
+                                   "stat_allreduce for the backward sums): set them with dist.attach()")
+            n = y[:Bg].numel() // y.shape[-1]
+            count = float(n)
+            # pass 1: sum x -> mean ; pass 2: sum (x - mean)^2 -> variance without cancellation.
+            # The per-channel steps in between are two tiny fused kernels (was ~14 torch ops per layer).
+            # Every group of the pass (D(real), D(fake)) has its own statistics; they share ONE work buffer so that
+            # a data-parallel run synchronises all groups of a layer with one collective.
+            st = torch.empty((G, 4 * C_), dtype=torch.float32, device=x.device)  # (bn_stats overwrites; rows 16-B aligned)
+            work = torch.empty((G, 2 * C_), dtype=torch.float32, device=x.device)
+            for gi in range(G):
+                yg = y[gi * Bg:(gi + 1) * Bg]
+                ops.bn_stats(yg, st[gi, :2 * C_])
+                ops.bn_mean(st[gi, :2 * C_], work[gi, :C_], count, None)
+                ops.bn_stats(yg, st[gi, 2 * C_:4 * C_], shift=work[gi, :C_])
+            if self.stat_allgather is not None:
+                # SyncBN in ONE collective per layer (all groups together): every rank contributes its local means
+                # and its local centred second moments M2 = sum (x - mean_r)^2 (both passes above are local), and
+                # the global statistics follow from the pairwise-combination rule (Chan et al.) for equal shards:
+                #   mean = avg_r mean_r ,  M2 = sum_r M2_r + n * sum_r (mean_r - mean)^2
+                # - no cancellation beyond the per-rank two-pass one.  (Was: two blocking all-reduces per group.)
+                s2 = st[:, 2 * C_:4 * C_]
+                m2_local = s2[:, C_:] - s2[:, :C_] ** 2 / count  # (sum d is ~0 but not exactly)
+                allr = self.stat_allgather(torch.cat([work[:, :C_], m2_local], dim=1))  # (world, G, 2C)
+                mean_r, m2_r = allr[..., :C_], allr[..., C_:]
+                gmean = mean_r.mean(dim=0)
+                s2[:, :C_] = 0.0
+                s2[:, C_:] = m2_r.sum(dim=0) + count * ((mean_r - gmean) ** 2).sum(dim=0)
+                work[:, :C_] = gmean
+                count = float(n) * self.stat_world
             for gi in range(G):
                 yg, ag = y[gi * Bg:(gi + 1) * Bg], a[gi * Bg:(gi + 1) * Bg]
-                n = yg.numel() // yg.shape[-1]
-                # pass 1: sum x -> mean ; pass 2: sum (x - mean)^2 -> variance without cancellation.
-                # The per-channel steps in between are two tiny fused kernels (was ~14 torch ops per layer).
-                st = torch.empty(4 * C_ + 1, dtype=torch.float32, device=x.device)  # (bn_stats overwrites)
-                s1, s2 = st[:2 * C_], st[2 * C_:4 * C_]
-                work = torch.empty(2 * C_, dtype=torch.float32, device=x.device)
-                mean, invstd = work[:C_], work[C_:]
-                ops.bn_stats(yg, s1)
-                cdev = None
-                count = float(n)
-                ops.bn_mean(s1, mean, count, cdev)
-                ops.bn_stats(yg, s2, shift=mean)
-                if self.stat_allgather is not None:
-                    # SyncBN in ONE collective per layer: every rank contributes its local mean and its local
-                    # centred second moment M2 = sum (x - mean_r)^2 (both passes above are local), and the global
-                    # statistics follow from the pairwise-combination rule (Chan et al.) for equal shard sizes:
-                    #   mean = avg_r mean_r ,  M2 = sum_r M2_r + n * sum_r (mean_r - mean)^2
-                    # - no cancellation beyond the per-rank two-pass one.  (Was: two blocking all-reduces.)
-                    m2_local = s2[C_:] - s2[:C_] ** 2 / count  # (sum d is ~0 but not exactly)
-                    allr = self.stat_allgather(torch.cat([mean, m2_local]))  # (world, 2C)
-                    mean_r, m2_r = allr[:, :C_], allr[:, C_:]
-                    gmean = mean_r.mean(dim=0)
-                    s2[:C_].zero_()
-                    s2[C_:].copy_(m2_r.sum(dim=0) + count * ((mean_r - gmean) ** 2).sum(dim=0))
-                    mean.copy_(gmean)
-                    count = float(n) * self.stat_world
+                mean, invstd = work[gi, :C_], work[gi, C_:]
                 track = bn.track_running_stats
                 mom = 0.0
                 if track:
                     with torch.no_grad():
                         bn.num_batches_tracked += 1
                     mom = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked)
-                ops.bn_finalize(s2, mean, invstd, count, bn.eps, mom, bn.running_mean if track else None,
-                                bn.running_var if track else None, cdev)
+                ops.bn_finalize(st[gi, 2 * C_:4 * C_], mean, invstd, count, bn.eps, mom,
+                                bn.running_mean if track else None, bn.running_var if track else None, None)
                 ops.bn_apply_lrelu(yg, ag, mean, invstd, bn.weight.detach(), bn.bias.detach(), l.act, sl)
                 means.append(mean)
                 invstds.append(invstd)
@@ -1387,10 +1393,13 @@ class DiscriminatorProgram(ProgramBase):
                 gy = self._empty(y_o.shape, g)
                 if r["training"]:
                     G = r["groups"]
-                    for gi in range(lo // Bg, G):
+                    g0 = lo // Bg
+                    # the two per-channel sums of every group of the pass, side by side: one collective per layer
+                    sums_all = torch.empty((G - g0, 2 * C_), dtype=torch.float32, device=dev)  # (overwritten)
+                    for gi in range(g0, G):
                         o = gi * Bg - lo
-                        gg, ag, yg, gyg = g[o:o + Bg], act_o[o:o + Bg], y_o[o:o + Bg], gy[o:o + Bg]
-                        sums = torch.empty(2 * C_, dtype=torch.float32, device=dev)  # (overwritten)
+                        gg, ag, yg = g[o:o + Bg], act_o[o:o + Bg], y_o[o:o + Bg]
+                        sums = sums_all[gi - g0]
                         ops.bn_bwd_reduce(gg, ag, yg, r["mean"][gi], r["invstd"][gi], l.act, sl, sums)
                         if need_dw:  # (every group's batch statistics are a call of their own: the gradients add)
                             if gi == 0:
@@ -1399,11 +1408,14 @@ class DiscriminatorProgram(ProgramBase):
                             else:
                                 sp.view(flat, bn.bias).add_(sums[:C_])
                                 sp.view(flat, bn.weight).add_(sums[C_:])
-                        if self.stat_allreduce is not None:
-                            sums = sums.clone()
-                            self.stat_allreduce(sums)
-                        ops.bn_bwd_apply(gg, yg, gyg, r["mean"][gi], r["invstd"][gi], bn.weight.detach(), sums,
-                                         1.0 / r["count"][gi])
+                    if self.stat_allreduce is not None:
+                        sums_all = sums_all.clone()
+                        self.stat_allreduce(sums_all)
+                    for gi in range(g0, G):
+                        o = gi * Bg - lo
+                        gg, yg, gyg = g[o:o + Bg], y_o[o:o + Bg], gy[o:o + Bg]
+                        ops.bn_bwd_apply(gg, yg, gyg, r["mean"][gi], r["invstd"][gi], bn.weight.detach(),
+                                         sums_all[gi - g0], 1.0 / r["count"][gi])
                 else:
                     mean, invstd = r["mean"][0], r["invstd"][0]
                     if l.act:

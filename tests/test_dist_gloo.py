@@ -150,3 +150,73 @@ def test_two_rank_g_iteration_equals_full_batch(tmp_path):
     np.testing.assert_allclose(r0["mean_grad"].numpy(), np.full(2, 2 * 2 * 3.0 / 4), rtol=1e-6)
     assert r0["max"].tolist() == [1.0, 0.0]
     assert r0["n_coll"] >= 2  # more than one gradient bucket was all-reduced
+
+
+def _run_bench(argv, env_extra=None, timeout=180):
+    import subprocess
+    import sys
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    env.update(env_extra or {})
+    return subprocess.run([sys.executable, os.path.join(REPO, "bench.py")] + argv, env=env, capture_output=True,
+                          text=True, timeout=timeout)
+
+
+def test_bench_launcher_starts_one_rank_per_gpu():
+    """``bench.py --gpus N`` without a torchrun environment must itself become N ranks (children of a parent that
+    never touched the GPU) - a driver that runs ``python bench.py --gpus 2`` must not get a dp1 line."""
+    import json
+    r = _run_bench(["--gpus", "2", "--dry-launch"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    out = json.loads(line)
+    assert out["dry_launch"] and out["n_gpus"] == 2
+    assert sorted(map(tuple, out["ranks"])) == [(0, 0), (1, 1)]  # (RANK, LOCAL_RANK) of the two children
+    # N = 1 stays in-process (rocprofv3 profiles the benchmark itself, not a launcher)
+    r1 = _run_bench(["--dry-launch"])
+    assert r1.returncode == 0 and json.loads(r1.stdout.splitlines()[-1])["ranks"] == [[0, 0]]
+
+
+def test_bench_refuses_a_mislabelled_world():
+    """inside a torchrun environment whose WORLD_SIZE differs from --gpus the run stops instead of printing a
+    line with the wrong n_gpus"""
+    r = _run_bench(["--gpus", "2", "--dry-launch"], {"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"})
+    assert r.returncode != 0 and "WORLD_SIZE" in r.stderr
+
+
+def _ledger_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    import torch.distributed as dist
+    from gan_sr_wind_field_amd import dist as wdist
+
+    assert wdist.init_from_env("gloo")
+    dp = wdist.DataParallel(bucket_mb=4 * 100 / 2**20)  # buckets of 100 floats
+    flat = torch.full((450,), float(rank + 1))
+    for lo in range(0, 450, 50):
+        dp.grad_ready("G", flat, lo, lo + 50)
+    dp.grad_done("G")
+    stat = dp.stat_allgather(torch.tensor([float(rank), 1.0]))
+    s = torch.ones(6)
+    dp.stat_allreduce(s)
+    m = dp.global_max(torch.tensor([float(rank)]))
+    mean = dp.batch_mean(torch.tensor([float(rank), float(rank)]))
+    torch.save(dict(flat=flat, stat=stat, s=s, m=m, mean=mean, comm=dp.stats.summary(1)),
+               os.path.join(out_dir, f"r{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_comm_ledger_counts_collectives_and_bytes(tmp_path):
+    world, port = 2, _free_port()
+    mp.spawn(_ledger_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    r = torch.load(tmp_path / "r0.pt")
+    assert torch.allclose(r["flat"], torch.full((450,), 1.5))  # averaged over the ranks
+    assert r["stat"].shape == (2, 2) and r["stat"][:, 0].tolist() == [0.0, 1.0]
+    assert r["s"].tolist() == [2.0] * 6 and float(r["m"]) == 1.0 and float(r["mean"]) == 0.5
+    c = r["comm"]
+    assert c["grad_bucket_collectives_per_step"] == 5            # 4 full buckets of 100 + the 50-float tail
+    assert abs(c["grad_mbytes_per_step"] - 450 * 4 / 1e6) < 1e-3
+    assert c["syncbn_collectives_per_step"] == 2 and c["scalar_collectives_per_step"] == 2
+    assert c["collectives_per_step"] == 9 and c["timed"] is False and c["exposed_grad_wait_ms_per_step"] is None

@@ -26,15 +26,15 @@ def _free_port():
     return port
 
 
-def _build_gan(dtype):
+def _build_gan(dtype, device_index=0):
     from gan_sr_wind_field_amd.config.config import Config
     from gan_sr_wind_field_amd.GAN_models.wind_field_GAN_3D import wind_field_GAN_3D
     from oracle import nets as onets
 
-    dev = torch.device("cuda:0")
+    dev = torch.device(f"cuda:{device_index}")
     cfg = Config(LOCAL_INI)
     cfg.is_train, cfg.is_test, cfg.is_use = True, False, False
-    cfg.gpu_id, cfg.device = 0, dev
+    cfg.gpu_id, cfg.device = device_index, dev
     cfg.compute_dtype = dtype
     cfg.generator.num_features, cfg.generator.num_RRDB, cfg.generator.RDB_growth_chan = 16, 1, 8
     cfg.generator.terrain_number_of_features = 8
@@ -67,23 +67,29 @@ def _two_iterations(gan, cfg, LR, HR, Z, x, y):
     return out
 
 
-def _worker(rank, world, port, out_dir, dtype, bucket_mb, hr_scale):
+def _worker(rank, world, port, out_dir, dtype, bucket_mb, hr_scale, backend="gloo"):
     import sys
     sys.path.insert(0, os.path.join(REPO, "tests"))
+    local = rank if backend == "nccl" else 0  # RCCL: one rank per device; gloo: both ranks on cuda:0
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
-                      LOCAL_RANK="0")
+                      LOCAL_RANK=str(local), HSA_ENABLE_IPC_MODE_LEGACY="0")
     import torch.distributed as dist
     from gan_sr_wind_field_amd import dist as wdist
     from oracle.gan import synthetic_batch
 
-    assert wdist.init_from_env("gloo")
-    gan, cfg = _build_gan(dtype)
+    torch.cuda.set_device(local)
+    assert wdist.init_from_env(backend)
+    gan, cfg = _build_gan(dtype, local)
     dp = wdist.attach(gan, bucket_mb=bucket_mb, sync_bn=True)
+    dp.stats.timing = True
     LR, HR, Z, x, y = synthetic_batch(2 * world, 16, 4, 4, seed=2001)
     HR = HR * hr_scale
     sl = slice(2 * rank, 2 * rank + 2)  # two samples per rank
     res = _two_iterations(gan, cfg, LR[sl], HR[sl], Z[sl], x, y)
     res["n_coll"] = dp.n_collectives
+    torch.cuda.synchronize()
+    res["comm"] = dp.stats.summary(1)
+    res["bn_layers"] = sum(1 for l in gan.D.features.program().layers if l.bn is not None)
     torch.save(res, os.path.join(out_dir, f"rank{rank}.pt"))
     dist.barrier()
     dist.destroy_process_group()
@@ -110,3 +116,32 @@ def test_two_rank_step_equals_full_batch_hip(hip, tmp_path, bucket_mb, hr_scale)
         assert torch.equal(r0[k], r1[k]), k  # replicas stay identical
         np.testing.assert_allclose(r0[k].numpy(), v.numpy(), rtol=5e-4, atol=2e-6, err_msg=k)
     assert r0["n_coll"] > (4 if bucket_mb < 1 else 2)  # gradient buckets of G and D + the classifier head
+    # the communication ledger bench.py prints: SyncBN costs ONE collective per BatchNorm layer and pass for BOTH
+    # inputs of the iteration (D(real) and D(fake) ride together) - forward all-gather + backward sum in the
+    # D-iteration; the G-iteration runs D in eval mode (no batch statistics)
+    comm = r0["comm"]
+    assert comm["syncbn_collectives_per_step"] == 2 * r0["bn_layers"], comm
+    assert comm["grad_bucket_collectives_per_step"] == r0["n_coll"]
+    assert comm["grad_mbytes_per_step"] > 0 and comm["scalar_collectives_per_step"] >= 2
+    assert comm["timed"] and comm["exposed_grad_wait_ms_per_step"] >= 0.0
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two MI355X devices (RCCL refuses two ranks on one)")
+def test_two_rank_step_equals_full_batch_rccl(hip, tmp_path):
+    """the same equality over backend "nccl" (= RCCL over xGMI), one rank per device: ReduceOp.AVG buckets on the
+    collective stream, all_gather_into_tensor SyncBN statistics.  Skipped on the one-GPU box."""
+    import sys
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    from oracle.gan import synthetic_batch
+
+    world, port = 2, _free_port()
+    mp.spawn(_worker, args=(world, port, str(tmp_path), "fp32", 32.0, 1.0, "nccl"), nprocs=world, join=True)
+    r0 = torch.load(tmp_path / "rank0.pt")
+    r1 = torch.load(tmp_path / "rank1.pt")
+    gan, cfg = _build_gan("fp32")
+    LR, HR, Z, x, y = synthetic_batch(2 * world, 16, 4, 4, seed=2001)
+    ref = _two_iterations(gan, cfg, LR, HR, Z, x, y)
+    for k, v in ref.items():
+        assert torch.equal(r0[k], r1[k]), k
+        np.testing.assert_allclose(r0[k].numpy(), v.numpy(), rtol=5e-4, atol=2e-6, err_msg=k)
+    assert r0["comm"]["syncbn_collectives_per_step"] == 2 * r0["bn_layers"]
