@@ -1,0 +1,692 @@
+// Memory-bound z-tapless convolutions with a thin side, bf16: a workgroup SLIDES along x.
+//
+// The last conv of the generator (reference Generator_3D_Resnet_ESRGAN.py:105-110, hr_convs[2]: 5x5x5, 144 -> 3)
+// runs z-folded as a (5,5,1) conv with 15 outputs.  Both of its passes move a 144-channel HR tensor
+// once and do little arithmetic per byte; on the generic halo-tile kernel they were bound by per-tile overheads -
+// the forward re-fetched the halo image and the whole 117 KB filter for every 512-voxel tile, in nine dependent
+// DMA phases with one workgroup per CU (524 us for 730 MB), the input gradient spent its time in 8-byte strided
+// mask loads and stores (793 us for 1.28 GB).
+//
+//   forward  (wsr_conv_slide_fwd):  y[v, n] = sum_{kx,ky,c} x[v + (kx,ky) - pad, c] * w[n, (kx,ky), c],  N <= 16
+//
+// A workgroup owns a column of the volume - TY = 16 rows x TZ = 4 levels, every x of its segment - and streams the
+// x-planes of the input (all channels, rows with their y halo) through four LDS buffers: every input byte is
+// fetched ONCE per column (y halo: 20/16), as whole 1152-byte runs (4 z-contiguous voxels x 288 B), and every
+// fragment is read from LDS once and used for the KX output planes it contributes to (input-stationary).  The
+// filter never touches LDS: the reduction (taps x channel octets) is split four ways over the waves and every wave
+// keeps the fragments of its K-steps in REGISTERS for the whole launch (KX * 6 * 4 = 120 VGPRs at 144 channels).
+// The four partial sums of an m-tile meet in LDS and are added in a fixed order (bit-reproducible).  Output:
+// planar fp32 partial sums (the z-fold pass adds the bias).
+#include <cstdlib>
+#include <type_traits>
+
+#include "common.h"
+
+namespace {
+
+__device__ __forceinline__ void cs_glds16(const void* gsrc, unsigned lds_addr) {
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(gsrc), "s"(lds_addr)
+      : "memory");
+}
+__device__ __forceinline__ void cs_dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+struct CsArgs {
+  const unsigned short* in;  // NDHWC bf16
+  const unsigned short* wf;  // tile-kernel fragment filter, TPK = 2, one n-tile: [chunk16][tap pair][lane][8]
+  float* out;                // planar fp32 (B, N, X, Y, Z)
+  const void* zero16;
+  const float* bias;         // [N] or NULL
+  int B, X, Y, Z;
+  int in_ctot, in_off;
+  int N;
+  int px, py;
+  int nty, ntz, nseg, XS;    // tiles along y and z, segments along x and their length
+  int blk;                   // 1: workgroup ids are dealt in blocks of 4 (y) x 8 (z) tiles (one XCD's share)
+  int ablate;                // WSR_CS_ABL, timing experiments only: 1 no plane DMA, 2 no MFMAs, 4 no output stores, 8 no LDS reads
+};
+
+constexpr int cs_round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+template <int KX, int KY, int OC>
+struct CsGeom {
+  static constexpr int TY = 16, TZ = 4;
+  static constexpr int PY = TY + KY - 1;          // rows of an input plane (with y halo)
+  static constexpr int VOX = PY * TZ;             // voxels of an input plane
+  static constexpr int ROWB = OC * 16;            // bytes per voxel
+  static constexpr int NP = VOX * OC;             // 16-byte pieces per plane
+  static constexpr int NU = (NP + 63) / 64;       // DMA units (64 pieces) per plane; the last one is shifted back
+  static constexpr int PLANE_B = NP * 16;
+  static constexpr int NB = 4;                    // plane buffers: one being contracted, three in flight
+  static constexpr int PAIRS = KY * OC;           // (ky, octet) pairs per kx
+  static constexpr int SK = (PAIRS + 3) / 4;      // K-steps per kx
+  static constexpr int NPW = (SK + 3) / 4;        // K-steps per kx and wave (four K groups)
+  static constexpr int NTS = (KX * KY + 1) / 2;   // tap pairs of the packed filter (TPK = 2)
+  static constexpr int SCR_B = 12 * 1024;         // partial sums of one plane: 12 (K group, m-tile) pairs x 1 KB
+  static constexpr int LDS_B = NB * PLANE_B + 2 * SCR_B;
+};
+
+template <int KX, int KY, int OC>
+__global__ __launch_bounds__(512) void conv_slide_fwd_kernel(const CsArgs a) {
+  using G = CsGeom<KX, KY, OC>;
+  constexpr int TY = G::TY, TZ = G::TZ, ROWB = G::ROWB, NP = G::NP, NU = G::NU, PLANE_B = G::PLANE_B;
+  constexpr int PAIRS = G::PAIRS, SK = G::SK, NPW = G::NPW, NTS = G::NTS, SCR_B = G::SCR_B;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int kg = wave & 3, mh = wave >> 2;  // K group, m-tile half (m-tiles 2mh, 2mh + 1)
+  const int fr = lane & 15, fg = lane >> 4;
+
+  // ---- which column --------------------------------------------------------------------------------
+  unsigned bid = (unsigned)xcd_remap(blockIdx.x, gridDim.x);
+  int ty, tz;
+  if (a.blk) {  // blocks of 4 x 8 tiles: y neighbours (shared halo rows) and z neighbours (shared output lines)
+    const unsigned within = bid & 31u;
+    unsigned r = bid >> 5;
+    const unsigned nzb = (unsigned)a.ntz >> 3, nyb = (unsigned)a.nty >> 2;
+    const unsigned zb = r % nzb; r /= nzb;
+    const unsigned yb = r % nyb; r /= nyb;
+    ty = (int)(yb * 4 + (within >> 3));
+    tz = (int)(zb * 8 + (within & 7u));
+    bid = r;
+  } else {
+    tz = (int)(bid % (unsigned)a.ntz); bid /= (unsigned)a.ntz;
+    ty = (int)(bid % (unsigned)a.nty); bid /= (unsigned)a.nty;
+  }
+  const int seg = (int)(bid % (unsigned)a.nseg);
+  const int b = (int)(bid / (unsigned)a.nseg);
+  const int y0 = ty * TY, z0 = tz * TZ;
+  const int x_begin = seg * a.XS;
+  const int nplanes = min(a.XS, a.X - x_begin);  // output planes of this workgroup (>= 1 by construction)
+
+  typedef __attribute__((address_space(3))) char* lptr_t;
+  const unsigned ring_lds = (unsigned)(unsigned long)(lptr_t)smem;
+  char* scratch = smem + G::NB * PLANE_B;
+
+  // ---- DMA geometry: the source of this lane's piece of each of the wave's units (same for every plane) ---------
+  // The planes are fetched by the waves of K groups 2 and 3; the waves of K groups 0 and 1 finalize and store the
+  // outputs.  Stores and LDS-DMA share the in-order vmcnt counter: a wave that did both waited, every plane, for the
+  // previous plane's 16-byte output stores to be acknowledged by memory before it could tell that its DMA had
+  // landed - 2.6 us per plane, three times the arithmetic.  Now no wave ever waits for a store.
+  const bool dma_wave = kg >= 2;
+  const int dw = (kg - 2) + 2 * mh;  // 0 .. 3 among the DMA waves
+  constexpr int UPW = (NU + 3) / 4;
+  int uoff[UPW];       // element offset inside an x-plane of the input, or -1 (zero page)
+  unsigned udst[UPW];  // LDS byte offset of the unit inside a plane (wave-uniform)
+#pragma unroll
+  for (int k = 0; k < UPW; ++k) {
+    const int u = dw + 4 * k;
+    int off = -1;
+    unsigned dst = 0;
+    if (dma_wave && u < NU) {
+      const int p0 = u * 64 < NP - 64 ? u * 64 : NP - 64;  // the last unit is shifted back: no partial unit
+      dst = (unsigned)p0 * 16u;
+      const int p = p0 + lane;
+      const int vox = p / OC, o = p - vox * OC;
+      const int yl = vox / TZ, zl = vox - yl * TZ;
+      const int gy = y0 - a.py + yl, gz = z0 + zl;
+      if ((unsigned)gy < (unsigned)a.Y && gz < a.Z) off = (gy * a.Z + gz) * a.in_ctot + a.in_off + o * 8;
+    }
+    uoff[k] = off;
+    udst[k] = __builtin_amdgcn_readfirstlane(dst);
+  }
+  const long plane_elems = (long)a.Y * a.Z * a.in_ctot;
+  auto plane_issue = [&](int xi, int slot) __attribute__((always_inline)) {
+    if (!dma_wave || (a.ablate & 1)) return;
+    const bool xin = (unsigned)xi < (unsigned)a.X;
+    const unsigned short* base = a.in + ((long)b * a.X + (xin ? xi : 0)) * plane_elems;
+    const unsigned dst = ring_lds + (unsigned)slot * PLANE_B;
+#pragma unroll
+    for (int k = 0; k < UPW; ++k) {
+      if (dw + 4 * k < NU) {
+        const unsigned short* src = (xin && uoff[k] >= 0) ? base + uoff[k] : reinterpret_cast<const unsigned short*>(a.zero16);
+        cs_glds16(src, dst + udst[k]);
+      }
+    }
+  };
+
+  // ---- this wave's filter fragments, in registers for the whole launch --------------------------------
+  // K-step sl (0 .. SK-1) of tap column kx contracts the four (ky, octet) pairs q = 4 sl + fg, one per lane group;
+  // consecutive pairs alternate the octet's parity, which keeps the 288-byte voxel rows conflict-free for
+  // ds_read_b128.  The wave takes the K-steps sl = 4 j + kg.
+  uint4 wreg[KX][NPW];
+  int woff[NPW];
+#pragma unroll
+  for (int j = 0; j < NPW; ++j) {
+    const int sl = 4 * j + kg;
+    const int q = 4 * sl + fg;
+    const bool ok = sl < SK && q < PAIRS;
+    const int ky = ok ? q / OC : 0, o = ok ? q - (q / OC) * OC : 0;
+    // byte offset of this lane's fragment row inside a plane: voxel (y = 4 m + fr/4 + ky, z = fr%4) = m*16 + fr + ky*TZ
+    woff[j] = (2 * mh * 16 + fr + ky * TZ) * ROWB + o * 16;
+#pragma unroll
+    for (int kx = 0; kx < KX; ++kx) {
+      uint4 w = make_uint4(0u, 0u, 0u, 0u);
+      if (ok) {
+        const int tap = kx * KY + ky;
+        const int g = ((tap & 1) << 1) | (o & 1);
+        w = *reinterpret_cast<const uint4*>(a.wf + ((size_t)((o >> 1) * NTS + (tap >> 1)) * 64 + g * 16 + fr) * 8);
+      }
+      wreg[kx][j] = w;
+    }
+  }
+  float bias4[4] = {0.f, 0.f, 0.f, 0.f};
+  if (a.bias) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      if (4 * fg + r < a.N) bias4[r] = a.bias[4 * fg + r];
+  }
+
+  // ---- schedule: input-stationary ----------------------------------------------------------------------------
+  // Input plane p feeds output planes p - kx (tap column kx).  A fragment of plane p is read from LDS ONCE and
+  // multiplied into the accumulators of all KX outputs it belongs to; an output's accumulator is complete KX planes
+  // after it was opened and the set shifts by one.  (Output-stationary - one x fragment per MFMA, every plane read
+  // KX times from a KX + 1 deep ring - saturated the LDS read path and the matrix pipe at the same time and got the
+  // sum of the two, not the maximum: 340 us with both ~45 % busy.)  LDS holds NB = 4 planes: the one being contracted
+  // and three in flight (issued three iterations before use: ~69 KB per CU on the wire).
+  constexpr int NB = G::NB;
+  const int n_in = nplanes + KX - 1;   // input planes the workgroup contracts
+  const int xin0 = x_begin - a.px;     // global x of input plane 0
+  const int nw = dma_wave ? (NU - dw + 3) / 4 : 0;  // DMA instructions this wave issues per plane (wave-uniform)
+  static_assert(2 * ((NU + 3) / 4) <= 16, "wait_landed counts at most 16 younger DMA instructions");
+  // wait until everything but the `planes_younger` most recently issued planes of this wave has landed
+  auto wait_landed = [&](int planes_younger) __attribute__((always_inline)) {
+    if (!dma_wave) return;  // (its vmcnt holds output stores only: nothing to wait for)
+    switch (planes_younger * nw) {
+      case 16: asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); break;
+      case 14: asm volatile("s_waitcnt vmcnt(14)" ::: "memory"); break;
+      case 12: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+      case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
+      case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+      case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+      case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+      case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+      case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+      case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+      case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+      case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+      default: cs_dma_wait();
+    }
+  };
+
+  // ---- prologue: planes 0 .. NB-2 are issued, plane 0 lands -----------------------------------------------------
+#pragma unroll
+  for (int q = 0; q < NB - 1; ++q)
+    if (q < n_in) plane_issue(xin0 + q, q);
+  wait_landed(min(NB - 2, n_in - 1));
+  __syncthreads();
+
+  // finalizer of m-tile m: wave (kg = m & 1, mh = m >> 1); everybody else stores its partial sums
+  const int my_m0 = 2 * mh, my_m1 = 2 * mh + 1;
+  const long out_plane = (long)a.Y * a.Z;  // voxels of one (b, n, x) plane
+  f32x4_t acc[KX][2];                      // acc[kx]: output plane p - kx, m-tiles 2 mh and 2 mh + 1
+#pragma unroll
+  for (int kx = 0; kx < KX; ++kx) acc[kx][0] = acc[kx][1] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  int slot = 0;  // p mod NB
+  for (int p = 0; p < n_in; ++p) {
+    // the buffer of plane p - 1 (all waves are past the barrier that closed it) takes plane p + NB - 1
+    {
+      int s = slot + NB - 1;
+      if (s >= NB) s -= NB;
+      if (p + NB - 1 < n_in) plane_issue(xin0 + p + NB - 1, s);
+    }
+    const char* pl = smem + slot * PLANE_B;
+    uint4 xa[NPW], xb[NPW];
+    if (!(a.ablate & 8)) {
+#pragma unroll
+      for (int j = 0; j < NPW; ++j) {
+        xa[j] = *reinterpret_cast<const uint4*>(pl + woff[j]);
+        xb[j] = *reinterpret_cast<const uint4*>(pl + woff[j] + 16 * ROWB);
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < NPW; ++j) xa[j] = xb[j] = make_uint4(p, j, p, j);
+    }
+    if (!(a.ablate & 2)) {
+#pragma unroll
+      for (int j = 0; j < NPW; ++j)
+#pragma unroll
+        for (int kx = 0; kx < KX; ++kx) {
+          mma_chunk<BF16>(acc[kx][0], wreg[kx][j], xa[j]);
+          mma_chunk<BF16>(acc[kx][1], wreg[kx][j], xb[j]);
+        }
+    } else {
+#pragma unroll
+      for (int j = 0; j < NPW; ++j) asm volatile("" ::"v"(xa[j].x), "v"(xb[j].w));
+    }
+    // ---- output plane o = p - (KX - 1) is complete: partial sums -> LDS, fixed-order sum, store -----------------
+    const int o_done = p - (KX - 1);
+    const f32x4_t acc0 = acc[KX - 1][0], acc1 = acc[KX - 1][1];
+#pragma unroll
+    for (int kx = KX - 1; kx > 0; --kx) { acc[kx][0] = acc[kx - 1][0]; acc[kx][1] = acc[kx - 1][1]; }
+    acc[0][0] = acc[0][1] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    char* scr = scratch + (p & 1) * SCR_B;
+    // layout: [m-tile 4][K group minus the finalizer's: 3][lane][16 B]; finalizer K group of m-tile m is m & 1
+    auto pslot = [&](int m, int g) __attribute__((always_inline)) {
+      const int fk = m & 1;
+      return (m * 3 + (g > fk ? g - 1 : g)) * 1024 + lane * 16;
+    };
+    const bool fin0 = kg == (my_m0 & 1), fin1 = kg == (my_m1 & 1);
+    if (o_done >= 0) {
+      if (!fin0) *reinterpret_cast<f32x4_t*>(scr + pslot(my_m0, kg)) = acc0;
+      if (!fin1) *reinterpret_cast<f32x4_t*>(scr + pslot(my_m1, kg)) = acc1;
+    }
+    // plane p + 1 has landed; the two planes issued after it stay in flight
+    wait_landed(min(NB - 2, n_in - 2 - p < 0 ? 0 : n_in - 2 - p));
+    __syncthreads();
+    if (o_done >= 0 && (fin0 || fin1)) {
+      const int m = fin0 ? my_m0 : my_m1;
+      const f32x4_t own = fin0 ? acc0 : acc1;
+      const int fk = m & 1;
+      f32x4_t sum = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {  // fixed order over the K groups
+        const f32x4_t q = g == fk ? own : *reinterpret_cast<const f32x4_t*>(scr + pslot(m, g));
+        if (g == 0) sum = q;
+        else { sum[0] += q[0]; sum[1] += q[1]; sum[2] += q[2]; sum[3] += q[3]; }
+      }
+      const int gy = y0 + 4 * m + (fr >> 2), gz = z0 + (fr & 3);
+      if (gy < a.Y && gz < a.Z) {
+        float* o = a.out + (((long)b * a.N + 4 * fg) * a.X + (x_begin + o_done)) * out_plane + (long)gy * a.Z + gz;
+        const long nstride = (long)a.X * out_plane;
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (4 * fg + r < a.N && !(a.ablate & 4)) o[r * nstride] = sum[r] + bias4[r];
+      }
+    }
+    if (++slot == NB) slot = 0;
+  }
+}
+
+template <int KX, int KY, int OC>
+int launch_slide_fwd(CsArgs& a, hipStream_t st) {
+  using G = CsGeom<KX, KY, OC>;
+  static_assert(G::LDS_B <= 160 * 1024, "ring + scratch exceed the LDS");
+  static_assert(G::NP >= 64, "plane smaller than one DMA unit");
+  auto kern = conv_slide_fwd_kernel<KX, KY, OC>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       G::LDS_B);
+    if (e != hipSuccess) return (int)e;
+    attr_done = true;
+  }
+  a.nty = (a.Y + G::TY - 1) / G::TY;
+  a.ntz = (a.Z + G::TZ - 1) / G::TZ;
+  const long cols = (long)a.B * a.nty * a.ntz;
+  // segments along x: enough workgroups to fill the chip, each at least 8 planes long (KX - 1 halo planes each)
+  int nseg = (int)((256 + cols - 1) / cols);
+  if (nseg > a.X / 8) nseg = a.X / 8;
+  if (nseg < 1) nseg = 1;
+  a.XS = (a.X + nseg - 1) / nseg;
+  a.nseg = (a.X + a.XS - 1) / a.XS;
+  a.blk = (a.nty % 4 == 0 && a.ntz % 8 == 0) ? 1 : 0;
+  static const int abl = getenv("WSR_CS_ABL") ? atoi(getenv("WSR_CS_ABL")) : 0;  // timing experiments (read once)
+  a.ablate = abl;
+  const long wg = cols * a.nseg;
+  if (wg >= (1l << 31)) return WSR_EUNSUPPORTED;
+  hipLaunchKernelGGL(kern, dim3((unsigned)wg), dim3(512), G::LDS_B, st, a);
+  WSR_LAUNCH_CHECK();
+  return 0;
+}
+
+}  // namespace
+
+// Forward of a z-tapless stride-1 conv with at most 16 outputs, planar fp32 output (see the file header).
+// WSR_EUNSUPPORTED: shape without an instantiation - the caller runs the generic halo-tile kernel.
+int wsr_conv_slide_fwd(const unsigned short* in, int in_ctot, int in_off, int C, const unsigned short* wfrag, float* out,
+                       int N, int B, int X, int Y, int Z, int KX, int KY, int px, int py, const float* bias,
+                       const void* zero16, hipStream_t st) {
+  if (C % 16 || in_ctot % 8 || in_off % 8 || N < 1 || N > 16) return WSR_EUNSUPPORTED;
+  if ((long)Y * Z * in_ctot >= (1l << 31)) return WSR_EUNSUPPORTED;  // 32-bit offsets inside an x-plane
+  if ((long)B * Y * Z < 64 || X < 8) return WSR_EUNSUPPORTED;        // tiny volumes stay on the small-tile kernels
+  CsArgs a{};
+  a.in = in; a.wf = wfrag; a.out = out; a.zero16 = zero16; a.bias = bias;
+  a.B = B; a.X = X; a.Y = Y; a.Z = Z; a.in_ctot = in_ctot; a.in_off = in_off; a.N = N; a.px = px; a.py = py;
+  if (KX == 5 && KY == 5 && C == 144) return launch_slide_fwd<5, 5, 18>(a, st);
+  if (KX == 3 && KY == 3 && C == 144) return launch_slide_fwd<3, 3, 18>(a, st);
+  return WSR_EUNSUPPORTED;
+}
+
+// ================================================================================================================
+//   input gradient (wsr_conv_slide_dgrad):  dx[v, c] = mask(h[v, c]) * scale[b, c] * sum_{kx,ky,n} dy[v + (kx,ky) - pad', n] * wT[c, (kx,ky), n]
+//
+// Short reduction (taps x 16 channels of dy), wide result (C = 144): the launch moves the C-channel HR tensor twice
+// (mask source in, gradient out) and reads a 16-channel one.  Same sliding scheme: a workgroup owns a 16 x 4 column
+// and walks x.  The dy planes are tiny (20 rows x 4 levels x 32 B) and ring through LDS eight deep; the filter
+// (transposed, tap-flipped fragments of the tile kernels) lives in REGISTERS - a wave owns 2-3 of the nine 16-channel
+// output tiles for two of the plane's four voxel tiles, all 13 K-steps (156 VGPRs).  The mask source (the saved
+// output of hr_convs[0], reference Generator_3D_Resnet_ESRGAN.py:95-104 LeakyReLU + Dropout3d) arrives by LDS-DMA two
+// planes ahead; results are staged in LDS as whole 288-byte voxel rows and leave as 16-byte stores of full rows
+// (the halo-tile kernel stored 8 bytes per lane at a 288-byte stride).  DMA is issued by waves 0-3, stores by waves
+// 4-7: no wave waits for a store to learn that its DMA has landed (see the forward kernel).
+namespace {
+
+struct CdArgs {
+  const unsigned short* dy;    // NDHWC bf16, 16 channels read at [dy_off, dy_off + 16)
+  const unsigned short* wf;    // transposed fragment filter [1 chunk][tap pair][n-tile][lane][8]
+  unsigned short* dx;          // NDHWC bf16
+  const unsigned short* mask;  // NDHWC bf16 (saved forward output), window [mask_off, mask_off + C)
+  const float* chan_scale;     // [B][C] or NULL
+  const void* zero16;
+  int B, X, Y, Z;
+  int dy_ctot, dy_off, dx_ctot, dx_off, mask_ctot, mask_off;
+  int px, py;                  // gather pads (K - 1 - pad of the forward conv)
+  float alpha, slope;
+  int nty, ntz, nseg, XS, blk;
+};
+
+template <int KX, int KY, int NT>
+struct CdGeom {
+  static constexpr int TY = 16, TZ = 4;
+  static constexpr int PY = TY + KY - 1;
+  static constexpr int DY_NP = PY * TZ * 2;                 // 16-byte pieces of a dy plane (2 per voxel)
+  static constexpr int DY_NU = (DY_NP + 63) / 64;
+  static constexpr int DY_B = DY_NP * 16;
+  static constexpr int RD = 8;                              // dy ring slots (power of two)
+  static constexpr int OC = NT * 2;                         // octets of the wide side
+  static constexpr int ROWB = OC * 16;                      // bytes of a result / mask voxel row
+  static constexpr int M_NP = TY * TZ * OC;                 // pieces of a mask / result plane
+  static constexpr int M_NU = (M_NP + 63) / 64;
+  static constexpr int M_B = M_NP * 16;
+  static constexpr int RM = 3;                              // mask ring slots
+  static constexpr int NKS = (KX * KY + 1) / 2;             // K-steps: tap pairs x 16 channels
+  static constexpr int TN = NT / 4;                         // n-tiles per wave held in registers (four N groups)
+  static constexpr int NX = NT - 4 * TN;                    // left-over n-tile (0 or 1): N group 0, filter in LDS
+  static constexpr int NU = M_NU + DY_NU;                   // DMA units per plane
+  static constexpr int OFF_DY = 0, OFF_MASK = RD * DY_B, OFF_STAGE = OFF_MASK + RM * M_B;
+  static constexpr int OFF_SC = OFF_STAGE + 2 * M_B;       // per-channel factors (NT * 16 floats)
+  static constexpr int OFF_WX = OFF_SC + NT * 16 * 4;      // filter fragments of the left-over n-tile (NKS KB)
+  static constexpr int LDS_B = OFF_WX + NX * NKS * 1024;
+};
+
+template <int KX, int KY, int NT>
+__global__ __launch_bounds__(512) void conv_slide_dgrad_kernel(const CdArgs a) {
+  using G = CdGeom<KX, KY, NT>;
+  constexpr int TY = G::TY, TZ = G::TZ, DY_NP = G::DY_NP, DY_NU = G::DY_NU, DY_B = G::DY_B, RD = G::RD, OC = G::OC;
+  constexpr int ROWB = G::ROWB, M_NP = G::M_NP, M_NU = G::M_NU, M_B = G::M_B, RM = G::RM, NKS = G::NKS, TN = G::TN;
+  constexpr int NU = G::NU, NX = G::NX;
+  static_assert(NX <= 1, "one left-over n-tile at most");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int ng = wave & 3, mh = wave >> 2;  // N group, m-tile half
+  const int fr = lane & 15, fg = lane >> 4;
+  // n-tiles of N group g: [g TN, (g + 1) TN) with the filter in registers; group 0 also takes the left-over tile
+  // NT - 1 (NT = 9: 144 channels), whose fragments it reads from LDS - three tiles of fragments per wave (156 VGPRs)
+  // left the compiler 4 registers short, and a spilled DMA base pointer is reloaded behind a vmcnt(0) every plane
+  const int nt_lo = ng * TN;
+  const bool extra = NX > 0 && ng == 0;
+
+  unsigned bid = (unsigned)xcd_remap(blockIdx.x, gridDim.x);
+  int ty, tz;
+  if (a.blk) {
+    const unsigned within = bid & 31u;
+    unsigned r = bid >> 5;
+    const unsigned nzb = (unsigned)a.ntz >> 3, nyb = (unsigned)a.nty >> 2;
+    const unsigned zb = r % nzb; r /= nzb;
+    const unsigned yb = r % nyb; r /= nyb;
+    ty = (int)(yb * 4 + (within >> 3));
+    tz = (int)(zb * 8 + (within & 7u));
+    bid = r;
+  } else {
+    tz = (int)(bid % (unsigned)a.ntz); bid /= (unsigned)a.ntz;
+    ty = (int)(bid % (unsigned)a.nty); bid /= (unsigned)a.nty;
+  }
+  const int seg = (int)(bid % (unsigned)a.nseg);
+  const int b = (int)(bid / (unsigned)a.nseg);
+  const int y0 = ty * TY, z0 = tz * TZ;
+  const int x_begin = seg * a.XS;
+  const int nplanes = min(a.XS, a.X - x_begin);
+
+  typedef __attribute__((address_space(3))) char* lptr_t;
+  const unsigned lds0 = (unsigned)(unsigned long)(lptr_t)smem;
+  char* const dyr = smem + G::OFF_DY;
+  char* const mkr = smem + G::OFF_MASK;
+  char* const stg = smem + G::OFF_STAGE;
+
+  // ---- DMA units of waves 0-3: units [0, M_NU) = mask plane, [M_NU, NU) = dy plane; result units of waves 4-7 ------
+  // (one offset table for both roles: a wave has one of them)
+  const bool dma_wave = wave < 4, st_wave = !dma_wave;
+  const int w4 = wave & 3;
+  constexpr int UPW = (NU + 3) / 4, SPW = (M_NU + 3) / 4;
+  int uoff[UPW];        // element offset inside an x-plane of the tensor the unit belongs to, or -1
+  unsigned udst[UPW];   // LDS byte offset of the unit inside its plane (wave-uniform)
+#pragma unroll
+  for (int k = 0; k < UPW; ++k) {
+    const int u = w4 + 4 * k;
+    int off = -1;
+    unsigned dst = 0;
+    if (u < M_NU) {  // a mask unit (DMA waves) or the result unit of the same voxels (store waves)
+      const int p0 = u * 64 < M_NP - 64 ? u * 64 : M_NP - 64;
+      // (a shifted last unit overlaps its predecessor: the overlap is fetched / stored twice with the same bytes)
+      dst = (unsigned)p0 * 16u;
+      const int p = p0 + lane;
+      const int vox = p / OC, o = p - vox * OC;
+      const int gy = y0 + vox / TZ, gz = z0 + vox % TZ;
+      if (gy < a.Y && gz < a.Z)
+        off = dma_wave ? (gy * a.Z + gz) * a.mask_ctot + a.mask_off + o * 8 : (gy * a.Z + gz) * a.dx_ctot + a.dx_off + o * 8;
+    } else if (dma_wave && u < NU) {
+      const int ud = u - M_NU;
+      const int p0 = ud * 64 < DY_NP - 64 ? ud * 64 : DY_NP - 64;
+      dst = (unsigned)p0 * 16u;
+      const int p = p0 + lane;
+      const int vox = p >> 1, o = p & 1;
+      const int gy = y0 - a.py + vox / TZ, gz = z0 + vox % TZ;
+      if ((unsigned)gy < (unsigned)a.Y && gz < a.Z) off = (gy * a.Z + gz) * a.dy_ctot + a.dy_off + o * 8;
+    }
+    uoff[k] = off;
+    udst[k] = __builtin_amdgcn_readfirstlane(dst);
+  }
+  const long mask_plane = (long)a.Y * a.Z * a.mask_ctot, dy_plane = (long)a.Y * a.Z * a.dy_ctot;
+  // mask plane xm (output plane index relative to x_begin) and dy plane xd (input plane index relative to
+  // x_begin - px); either may be out of range (nothing issued for a mask plane beyond the segment)
+  auto issue = [&](int xm, bool want_mask, int xd, bool want_dy) __attribute__((always_inline)) {
+    if (!dma_wave) return;
+#pragma unroll
+    for (int k = 0; k < UPW; ++k) {
+      const int u = wave + 4 * k;
+      if (u < M_NU) {
+        if (want_mask) {
+          const unsigned short* src = uoff[k] >= 0 ? a.mask + ((long)b * a.X + x_begin + xm) * mask_plane + uoff[k]
+                                                   : reinterpret_cast<const unsigned short*>(a.zero16);
+          cs_glds16(src, lds0 + G::OFF_MASK + (unsigned)(xm % RM) * M_B + udst[k]);
+        }
+      } else if (u < NU) {
+        if (want_dy) {
+          const int xi = x_begin - a.px + xd;
+          const bool xin = (unsigned)xi < (unsigned)a.X;
+          const unsigned short* src = (xin && uoff[k] >= 0) ? a.dy + ((long)b * a.X + xi) * dy_plane + uoff[k]
+                                                            : reinterpret_cast<const unsigned short*>(a.zero16);
+          cs_glds16(src, lds0 + G::OFF_DY + (unsigned)(xd & (RD - 1)) * DY_B + udst[k]);
+        }
+      }
+    }
+  };
+
+  const long dx_plane = (long)a.Y * a.Z * a.dx_ctot;
+
+  // ---- filter fragments of this wave's n-tiles, all K-steps, in registers ------------------------------------
+  uint4 wreg[NKS][TN];
+#pragma unroll
+  for (int ks = 0; ks < NKS; ++ks)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+      wreg[ks][j] = *reinterpret_cast<const uint4*>(a.wf + ((size_t)(ks * NT + nt_lo + j) * 64 + lane) * 8);
+  char* const wxl = smem + G::OFF_WX;
+  if constexpr (NX > 0) {
+    for (int idx = t; idx < NKS * 64; idx += 512)
+      *reinterpret_cast<uint4*>(wxl + idx * 16) =
+          *reinterpret_cast<const uint4*>(a.wf + ((size_t)((idx >> 6) * NT + NT - 1) * 64 + (idx & 63)) * 8);
+  }
+  // per-channel factors (Dropout3d keep factor x alpha) wait in LDS: 4 per lane and n-tile, read when needed
+  float* const scl = reinterpret_cast<float*>(smem + G::OFF_SC);
+  for (int c = t; c < NT * 16; c += 512) scl[c] = (a.chan_scale ? a.chan_scale[(long)b * (NT * 16) + c] : 1.f) * a.alpha;
+  // dy fragment of K-step ks: lane group fg holds tap 2 ks + (fg >> 1), channel octet fg & 1, voxel fr of the m-tile.
+  // Both taps of a K-step are compile-time constants, so the fragment address is the lane's base + one of two
+  // scalars (ring slot of the tap's column, row offset of the tap) picked by the lane group - no tables in registers.
+  const int lane_base = (2 * mh * 16 + fr) * 32 + (fg & 1) * 16;  // (m-tile 2 mh; the second one is + 16 voxels)
+  const bool tap_hi = (fg >> 1) != 0;
+
+  // ---- prologue ----------------------------------------------------------------------------------------------
+  const int last_dy = nplanes + KX - 2;
+#pragma unroll
+  for (int d = 0; d <= KX; ++d) issue(0, false, d, d <= last_dy);
+  issue(0, true, 0, false);
+  issue(1, nplanes > 1, 0, false);
+  cs_dma_wait();
+  __syncthreads();
+
+  const int nw_full = dma_wave ? (NU - wave + 3) / 4 : 0;  // DMA instructions per plane when both kinds are issued
+  const int nw_dy = dma_wave ? nw_full - ((M_NU - wave + 3) / 4) : 0;
+  for (int i = 0; i < nplanes; ++i) {
+    const bool want_mask = i + 2 < nplanes, want_dy = i + KX + 1 <= last_dy;
+    issue(i + 2, want_mask, i + KX + 1, want_dy);
+    // ---- contraction: 2 m-tiles x TN n-tiles, NKS K-steps -----------------------------------------------------
+    f32x4_t acc[2][TN + NX];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int j = 0; j < TN + NX; ++j) acc[m][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    constexpr int D = 2;
+    uint4 xa[D], xb[D], wx[D];
+    auto frag_addr = [&](int ks) __attribute__((always_inline)) {
+      constexpr int LAST = KX * KY - 1;  // a padded tap reads the last real one: zero weights, finite data
+      const int tA = 2 * ks < LAST ? 2 * ks : LAST, tB = 2 * ks + 1 < LAST ? 2 * ks + 1 : LAST;
+      const int cA = ((i + tA / KY) & (RD - 1)) * DY_B + (tA % KY) * TZ * 32;
+      const int cB = ((i + tB / KY) & (RD - 1)) * DY_B + (tB % KY) * TZ * 32;
+      return dyr + lane_base + (tap_hi ? cB : cA);
+    };
+    auto fetch = [&](int ks) __attribute__((always_inline)) {
+      const char* p = frag_addr(ks);
+      xa[ks % D] = *reinterpret_cast<const uint4*>(p);
+      xb[ks % D] = *reinterpret_cast<const uint4*>(p + 16 * 32);
+      if constexpr (NX > 0) {
+        if (extra) wx[ks % D] = *reinterpret_cast<const uint4*>(wxl + ks * 1024 + lane * 16);
+      }
+    };
+#pragma unroll
+    for (int ks = 0; ks < D && ks < NKS; ++ks) fetch(ks);
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) {
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        mma_chunk<BF16>(acc[0][j], wreg[ks][j], xa[ks % D]);
+        mma_chunk<BF16>(acc[1][j], wreg[ks][j], xb[ks % D]);
+      }
+      if constexpr (NX > 0) {
+        if (extra) {
+          mma_chunk<BF16>(acc[0][TN], wx[ks % D], xa[ks % D]);
+          mma_chunk<BF16>(acc[1][TN], wx[ks % D], xb[ks % D]);
+        }
+      }
+      if (ks + D < NKS) fetch(ks + D);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- mask, scale, round, stage as [voxel][ROWB] rows ---------------------------------------------------------
+    const char* mk = mkr + (i % RM) * M_B;
+    char* sg = stg + (i & 1) * M_B;
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int j = 0; j < TN + NX; ++j) {
+        if (j < TN || extra) {
+          const int nt = j < TN ? nt_lo + j : NT - 1;
+          const int ro = ((2 * mh + m) * 16 + fr) * ROWB + (nt * 16 + 4 * fg) * 2;
+          const uint2 y = *reinterpret_cast<const uint2*>(mk + ro);
+          const float4 s4 = *reinterpret_cast<const float4*>(scl + nt * 16 + 4 * fg);
+          float4 o4 = make_float4(acc[m][j][0] * s4.x, acc[m][j][1] * s4.y, acc[m][j][2] * s4.z, acc[m][j][3] * s4.w);
+          o4.x *= (short)(y.x & 0xFFFFu) > 0 ? 1.f : a.slope;  // bf16 sign test on the raw bits: y > 0
+          o4.y *= (int)y.x > 0xFFFF ? 1.f : a.slope;
+          o4.z *= (short)(y.y & 0xFFFFu) > 0 ? 1.f : a.slope;
+          o4.w *= (int)y.y > 0xFFFF ? 1.f : a.slope;
+          uint2 u;
+          u.x = (unsigned)f2bf(o4.x) | ((unsigned)f2bf(o4.y) << 16);
+          u.y = (unsigned)f2bf(o4.z) | ((unsigned)f2bf(o4.w) << 16);
+          *reinterpret_cast<uint2*>(sg + ro) = u;
+        }
+      }
+    // the DMA issued one iteration ago (mask plane i + 1, dy plane i + KX) has landed; this iteration's stays in flight
+    if (dma_wave) {
+      const int young = (want_mask ? nw_full - nw_dy : 0) + (want_dy ? nw_dy : 0);
+      switch (young) {
+        case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+        case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+        case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+        case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+        case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+        case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+        default: cs_dma_wait();
+      }
+    }
+    __syncthreads();
+    // ---- whole rows out: 16 bytes per lane, 1 KB per wave instruction ----------------------------------------------
+    if (st_wave) {
+      unsigned short* base = a.dx + ((long)b * a.X + x_begin + i) * dx_plane;
+#pragma unroll
+      for (int k = 0; k < SPW; ++k) {
+        if (w4 + 4 * k < M_NU && uoff[k] >= 0)
+          *reinterpret_cast<uint4*>(base + uoff[k]) = *reinterpret_cast<const uint4*>(sg + udst[k] + lane * 16);
+      }
+    }
+  }
+}
+
+template <int KX, int KY, int NT>
+int launch_slide_dgrad(CdArgs& a, hipStream_t st) {
+  using G = CdGeom<KX, KY, NT>;
+  static_assert(G::LDS_B <= 160 * 1024, "rings + staging exceed the LDS");
+  static_assert(G::DY_NP >= 64 && G::M_NP >= 64, "plane smaller than one DMA unit");
+  static_assert((G::NU + 3) / 4 <= 6, "the counted DMA wait covers at most six instructions per plane and wave");
+  static_assert(KX + 2 <= G::RD, "dy ring too short");
+  auto kern = conv_slide_dgrad_kernel<KX, KY, NT>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       G::LDS_B);
+    if (e != hipSuccess) return (int)e;
+    attr_done = true;
+  }
+  a.nty = (a.Y + G::TY - 1) / G::TY;
+  a.ntz = (a.Z + G::TZ - 1) / G::TZ;
+  const long cols = (long)a.B * a.nty * a.ntz;
+  int nseg = (int)((256 + cols - 1) / cols);
+  if (nseg > a.X / 8) nseg = a.X / 8;
+  if (nseg < 1) nseg = 1;
+  a.XS = (a.X + nseg - 1) / nseg;
+  a.nseg = (a.X + a.XS - 1) / a.XS;
+  a.blk = (a.nty % 4 == 0 && a.ntz % 8 == 0) ? 1 : 0;
+  const long wg = cols * a.nseg;
+  if (wg >= (1l << 31)) return WSR_EUNSUPPORTED;
+  hipLaunchKernelGGL(kern, dim3((unsigned)wg), dim3(512), G::LDS_B, st, a);
+  WSR_LAUNCH_CHECK();
+  return 0;
+}
+
+}  // namespace
+
+// Input gradient of a z-tapless stride-1 conv whose OUTPUT side has at most 16 channels, with the LeakyReLU (+
+// Dropout3d keep factor) backward of the layer below in the epilogue; C = channels of dx.  `px`, `py` are the pads of
+// the gather over dy (K - 1 - pad).  WSR_EUNSUPPORTED: no instantiation - the caller runs the halo-tile kernel.
+int wsr_conv_slide_dgrad(const unsigned short* dy, int dy_ctot, int dy_off, int red, const unsigned short* wfrag_t,
+                         unsigned short* dx, int dx_ctot, int dx_off, int C, int B, int X, int Y, int Z, int KX, int KY,
+                         int px, int py, float alpha, const wsr_lrelu_mask_t* mask, const void* zero16, hipStream_t st) {
+  if (!mask || !mask->y || mask->c0 != 0 || mask->c1 != C || red != 16) return WSR_EUNSUPPORTED;
+  if (dy_ctot % 8 || dy_off % 8 || dx_ctot % 8 || dx_off % 8 || mask->y_ctot % 8 || mask->y_off % 8) return WSR_EUNSUPPORTED;
+  if ((long)Y * Z * dx_ctot >= (1l << 31) || (long)Y * Z * mask->y_ctot >= (1l << 31)) return WSR_EUNSUPPORTED;
+  if ((long)B * Y * Z < 64 || X < 8) return WSR_EUNSUPPORTED;
+  CdArgs a{};
+  a.dy = dy; a.wf = wfrag_t; a.dx = dx; a.mask = (const unsigned short*)mask->y; a.chan_scale = mask->chan_scale;
+  a.zero16 = zero16;
+  a.B = B; a.X = X; a.Y = Y; a.Z = Z;
+  a.dy_ctot = dy_ctot; a.dy_off = dy_off; a.dx_ctot = dx_ctot; a.dx_off = dx_off;
+  a.mask_ctot = mask->y_ctot; a.mask_off = mask->y_off;
+  a.px = px; a.py = py; a.alpha = alpha; a.slope = mask->slope;
+  if (KX == 5 && KY == 5 && C == 144) return launch_slide_dgrad<5, 5, 9>(a, st);
+  if (KX == 3 && KY == 3 && C == 144) return launch_slide_dgrad<3, 3, 9>(a, st);
+  return WSR_EUNSUPPORTED;
+}

@@ -262,6 +262,21 @@ static int run_conv_tile(CtArgs& a, int red, hipStream_t st) {
   return dispatch_ct(a, tpk, st);
 }
 
+// conv_slide.hip: sliding-window kernels of the z-folded last conv
+int wsr_conv_slide_fwd(const unsigned short* in, int in_ctot, int in_off, int C, const unsigned short* wfrag, float* out,
+                       int N, int B, int X, int Y, int Z, int KX, int KY, int px, int py, const float* bias,
+                       const void* zero16, hipStream_t st);
+
+int wsr_conv_slide_dgrad(const unsigned short* dy, int dy_ctot, int dy_off, int red, const unsigned short* wfrag_t,
+                         unsigned short* dx, int dx_ctot, int dx_off, int C, int B, int X, int Y, int Z, int KX, int KY,
+                         int px, int py, float alpha, const wsr_lrelu_mask_t* mask, const void* zero16, hipStream_t st);
+
+static const void* zero_page() {
+  static void* zp = nullptr;
+  if (!zp && hipGetSymbolAddress(&zp, HIP_SYMBOL(g_zero16)) != hipSuccess) zp = nullptr;
+  return zp;
+}
+
 int wsr_conv1x1_bf16(const unsigned short* in, int in_ctot, int in_off, int red, const unsigned short* wfrag,
                      unsigned short* out, int out_ctot, int out_off, int n_out, long nvox, const float* bias,
                      const unsigned short* res, int res_ctot, int res_off, int res_c1, float alpha, float beta, int act,
@@ -319,6 +334,15 @@ extern "C" int wsr_conv3d_fwd_tile(const wsr_conv_t* c, const void* x, const voi
     if (rc != WSR_EUNSUPPORTED) return rc;
   }
   if (ep && ep->res2) return WSR_EUNSUPPORTED;  // only the streaming kernel takes a second residual
+  // thin z-tapless conv with a planar fp32 result (the z-folded last conv): sliding-window kernel
+  static const bool no_slide = getenv("WSR_NO_SLIDE") != nullptr;  // tuning / A-B switch, read once
+  if (!no_slide && c->KZ == 1 && c->Cout <= 16 && a.out_planar && !a.chan_scale && !a.res && a.act == 0 && !a.ups &&
+      !c->lat && (c->sx | c->sy | c->sz) == 1 && c->pz == 0 && a.alpha == 1.f && c->Xo == c->Xi && c->Yo == c->Yi &&
+      zero_page()) {
+    const int rc = wsr_conv_slide_fwd(a.in, a.in_ctot, a.in_off, c->Cin, a.wf, (float*)a.out, c->Cout, c->B, c->Xi, c->Yi,
+                                      c->Zi, c->KX, c->KY, c->px, c->py, a.bias, zero_page(), as_stream(stream));
+    if (rc != WSR_EUNSUPPORTED) return rc;
+  }
   return run_conv_tile(a, c->Cin, as_stream(stream));
 }
 
@@ -366,6 +390,15 @@ extern "C" int wsr_conv3d_dgrad_tile(const wsr_conv_t* c, const void* dy, const 
                                     a.out_off, a.Cout, (long)c->B * c->Xo * c->Yo * c->Zo, nullptr, a.res, a.res_ctot,
                                     a.res_off, a.res ? a.res_c1 : 0, a.alpha, a.beta, 0, 0.f, mask, nullptr, 0, 0, 0.f,
                                     as_stream(stream));
+    if (rc != WSR_EUNSUPPORTED) return rc;
+  }
+  // z-tapless conv with a thin output side and the mask of the layer below (the z-folded last conv): sliding window
+  static const bool no_slide = getenv("WSR_NO_SLIDE") != nullptr;  // tuning / A-B switch, read once
+  if (!no_slide && mask && c->KZ == 1 && c->Cout <= 16 && !accumulate && !dx_planar && !c->lat && ux == 1 && c->pz == 0 &&
+      c->Xo == c->Xi && c->Yo == c->Yi && c->Zo == c->Zi && zero_page()) {
+    const int rc = wsr_conv_slide_dgrad(a.in, a.in_ctot, a.in_off, c->Cout, a.wf, (unsigned short*)a.out, a.out_ctot,
+                                        a.out_off, c->Cin, c->B, c->Xi, c->Yi, c->Zi, c->KX, c->KY, a.px, a.py, alpha, mask,
+                                        zero_page(), as_stream(stream));
     if (rc != WSR_EUNSUPPORTED) return rc;
   }
   if (mask) {

@@ -887,3 +887,78 @@ def test_conv_tile_strided_forward_vs_cpu(hip, name, cin, cout, k, s, p, xyz, B)
     ref = F.leaky_relu(F.conv3d(x, w, bias, s, p), 0.2)
     assert tuple(ref.shape[2:]) == oxyz
     assert rel_l2(from_ndhwc(yb, 0, cout), ref) < 4e-3, name
+
+
+@pytest.mark.parametrize("name,k,xyz,B,ctot,off,bias", [
+    ("prod_5x5", (5, 5, 1), (12, 32, 16), 1, 144, 0, False),     # whole tiles, blocked workgroup order off (nty = 2)
+    ("blocked", (5, 5, 1), (8, 64, 32), 1, 144, 0, False),       # nty = 4, ntz = 8: 4 x 8 tile blocks per XCD share
+    ("ragged", (5, 5, 1), (9, 24, 10), 2, 152, 8, True),         # partial y tile, z = 10 (reference patches), window, bias
+    ("segments", (5, 5, 1), (40, 16, 4), 1, 144, 0, False),      # one column: the x axis is cut into segments
+    ("k3", (3, 3, 1), (8, 16, 8), 1, 144, 0, False),
+])
+def test_conv_slide_forward_vs_cpu(hip, name, k, xyz, B, ctot, off, bias):
+    """sliding-window kernel of the z-folded last conv (conv_slide.hip; reference Generator_3D_Resnet_ESRGAN.py:105-110
+    in the (KX, KY, 1) x 15-output form of DESIGN 4.4): planar fp32 result against an fp32 CPU conv of the same
+    bf16-rounded operands, bit-identical between two launches."""
+    o = ops()
+    dt = torch.bfloat16
+    cin, cout = 144, 15
+    gen = torch.Generator().manual_seed(77 + xyz[0])
+    x = torch.randn((B, cin) + tuple(xyz), generator=gen).bfloat16().float()
+    w = (torch.randn((cout, cin) + tuple(k), generator=gen) / math.sqrt(cin * k[0] * k[1])).bfloat16().float()
+    bv = torch.randn(cout, generator=gen) if bias else None
+    p = (k[0] // 2, k[1] // 2, 0)
+    xb = to_ndhwc(x, ctot, off, dt)
+    if off:  # canary: channels outside the window must not be read
+        xb[..., :off] = float("nan")
+    d = o.make_desc(o.ConvGeom(cin, cout, k, (1, 1, 1), p), dt, B, xyz, ctot, off, cout, 0)
+    wf = o.pack_filter_frag(packed_master(w))
+    ref = F.conv3d(x, w, bv, 1, p)
+    outs = []
+    for _ in range(2):
+        y = torch.full((B, cout) + tuple(xyz), float("nan"), dtype=torch.float32, device=DEV)
+        assert o.conv_fwd_tile(d, xb, wf, y, bias=bv.to(DEV) if bias else None, out_planar=True)
+        outs.append(y.cpu())
+    assert torch.isfinite(outs[0]).all(), name
+    assert rel_l2(outs[0], ref) < 2e-5, name  # fp32 accumulation of exactly representable products
+    assert torch.equal(outs[0], outs[1]), name
+
+
+@pytest.mark.parametrize("name,k,xyz,B,ctot,off,drop", [
+    ("prod_5x5", (5, 5, 1), (12, 32, 16), 1, 144, 0, True),
+    ("blocked", (5, 5, 1), (8, 64, 32), 1, 144, 0, False),
+    ("ragged", (5, 5, 1), (9, 24, 10), 2, 152, 8, True),
+    ("segments", (5, 5, 1), (40, 16, 4), 1, 144, 0, True),
+    ("k3", (3, 3, 1), (8, 16, 8), 1, 144, 0, False),
+])
+def test_conv_slide_input_gradient_vs_cpu(hip, name, k, xyz, B, ctot, off, drop):
+    """input gradient of the z-folded last conv on the sliding-window kernel (conv_slide.hip): 16 -> 144 channels with
+    the LeakyReLU + Dropout3d backward of hr_convs[0] (reference Generator_3D_Resnet_ESRGAN.py:95-104) in the epilogue,
+    against fp32 CPU autograd of the same bf16-rounded operands; channels outside the written window stay untouched."""
+    o = ops()
+    dt = torch.bfloat16
+    cin, cout, slope = 144, 15, 0.2
+    gen = torch.Generator().manual_seed(91 + xyz[0])
+    w = (torch.randn((cout, cin) + tuple(k), generator=gen) / math.sqrt(cout * k[0] * k[1])).bfloat16().float()
+    gy = torch.randn((B, cout) + tuple(xyz), generator=gen).bfloat16().float()
+    h = torch.randn((B, cin) + tuple(xyz), generator=gen).bfloat16().float()   # saved output of the layer below
+    keep = (torch.bernoulli(torch.full((B, cin), 0.9), generator=gen) / 0.9) if drop else None
+    p = (k[0] // 2, k[1] // 2, 0)
+    gb = to_ndhwc(gy, 16, 0, dt)
+    hb = to_ndhwc(h, ctot, off, dt)
+    dxb = torch.full((B,) + tuple(xyz) + (ctot,), 7.0, dtype=dt, device=DEV)
+    d = o.make_desc(o.ConvGeom(cin, 16, k, (1, 1, 1), p), dt, B, xyz, ctot, off, 16, 0)
+    wpad = torch.cat([w, torch.zeros((1,) + tuple(w.shape[1:]))])
+    wft = o.pack_filter_frag(packed_master(wpad), transpose=True)
+    m = (hb, off, 0, cin, slope) + ((keep.to(DEV),) if drop else ())
+    assert o.conv_dgrad_tile(d, gb, wft, dxb, mask=m)
+    xg = torch.zeros((B, cin) + tuple(xyz), requires_grad=True)
+    F.conv3d(xg, w, None, 1, p).backward(gy)
+    ref = xg.grad * torch.where(h > 0, 1.0, slope)
+    if drop:
+        ref = ref * keep[:, :, None, None, None]
+    got = from_ndhwc(dxb, off, cin)
+    assert torch.isfinite(got).all(), name
+    assert rel_l2(got, ref) < 4e-3, name  # bf16 rounding of the result
+    if off:
+        assert bool((dxb[..., :off] == 7.0).all()), name

@@ -121,6 +121,33 @@ CASES["c1b"] = lambda: [conv_case("pre 128->128 @32x32x10", 128, 128, (3, 3, 3),
                         conv_case("hr0 @128x128x10", 144, 144, (5, 5, 5), (128, 128, 10)),
                         conv_case("lr wgrad @32x32x10", 128, 128, (3, 3, 3), S10, what="wgrad")]
 
+def hr1z_case():
+    """the z-folded last conv at the benchmark's HR shape: forward 144 -> 15 (planar fp32 out) and its input
+    gradient 16 -> 144 with the LeakyReLU / Dropout3d mask of hr_convs[0] in the epilogue"""
+    B, xyz, c, n = 1, HR, 144, 15
+    g = torch.Generator(device=DEV).manual_seed(1)
+    x = torch.randn((B,) + xyz + (c,), device=DEV, generator=g).to(DT)
+    w = torch.randn((n, c, 5, 5, 1), device=DEV, generator=g) * 0.02
+    vox = xyz[0] * xyz[1] * xyz[2]
+    d = o.make_desc(o.ConvGeom(c, n, (5, 5, 1), (1, 1, 1), (2, 2, 0)), DT, B, xyz, c, 0, n, 0)
+    y = torch.empty((B, n) + xyz, dtype=torch.float32, device=DEV)
+    wf = o.pack_filter_frag(w)
+    ms = timeit(lambda: o.conv_fwd_tile(d, x, wf, y, out_planar=True))
+    nb = vox * (c * 2 + n * 4)
+    print(f"{'hr1z fwd 144->15 (5,5,1)':28s} {'fwd planar':12s} {ms * 1e3:9.1f} us  {nb / ms / 1e6:8.1f} GB/s algorithmic")
+    gy = torch.randn((B,) + xyz + (16,), device=DEV, generator=g).to(DT)
+    gy[..., 15] = 0
+    dx = torch.empty((B,) + xyz + (c,), dtype=DT, device=DEV)
+    drop = torch.ones((B, c), device=DEV)
+    dd = o.make_desc(o.ConvGeom(c, 16, (5, 5, 1), (1, 1, 1), (2, 2, 0)), DT, B, xyz, c, 0, 16, 0)
+    wft = o.pack_filter_frag(torch.cat([w, torch.zeros_like(w[:1])]), transpose=True)
+    ms = timeit(lambda: o.conv_dgrad_tile(dd, gy, wft, dx, mask=(x, 0, 0, c, 0.2, drop)))
+    nb = vox * (16 * 2 + 2 * c * 2)
+    print(f"{'hr1z dgrad 16->144 +mask':28s} {'dgrad':12s} {ms * 1e3:9.1f} us  {nb / ms / 1e6:8.1f} GB/s algorithmic")
+
+
+CASES["hr1z"] = hr1z_case
+
 if __name__ == "__main__":
     names = sys.argv[1:] or ["all"]
     if names == ["all"]:

@@ -4,7 +4,7 @@ def load(f):
     d = collections.defaultdict(lambda: collections.defaultdict(list))
     for r in csv.DictReader(open(f)):
         n = r["Kernel_Name"]
-        if "conv_tile_kernel" not in n and "wgrad_tile" not in n and "conv1x1" not in n: continue
+        if not any(k in n for k in ("conv_tile_kernel", "wgrad_tile", "conv1x1", "conv_slide")): continue
         n = n.replace("void (anonymous namespace)::", "").split("(")[0]
         key = (n, r["Grid_Size"], r["LDS_Block_Size"], r["VGPR_Count"])
         d[key][r["Counter_Name"]].append(float(r["Counter_Value"]))
