@@ -34,6 +34,31 @@ __device__ __forceinline__ void cs_glds16(const void* gsrc, unsigned lds_addr) {
 }
 __device__ __forceinline__ void cs_dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
+// LDS-DMA through a buffer descriptor: LDS[lds_addr + 16*lane] <- 16 bytes at srd.base + voff, ZEROS where voff is
+// outside [0, srd.num_records) - the halo rows and planes outside the tensor cost no address arithmetic at all (a
+// global_load_lds needs a 64-bit per-lane address and a zero-page select: ~8 vector instructions per DMA instruction,
+// and a DMA wave issues six per plane).  The descriptor words come from scalar arithmetic: s_nop 4 covers the
+// SALU-write -> VMEM-read hazard inside the statement (hipcc pads nothing inside asm).
+typedef __attribute__((ext_vector_type(4))) int cs_srd_t;
+__device__ __forceinline__ void cs_bufdma16(cs_srd_t srd, unsigned voff, unsigned lds_addr) {
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 4\n\tbuffer_load_dwordx4 %2, %1, 0 offen lds\n\ts_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "s"(srd), "v"(voff), "s"(lds_addr)
+      : "memory");
+}
+__device__ __forceinline__ cs_srd_t cs_make_srd(const void* base, unsigned bytes) {
+  const unsigned long long b = (unsigned long long)base;
+  cs_srd_t r;
+  r.x = __builtin_amdgcn_readfirstlane((int)(unsigned)b);
+  r.y = __builtin_amdgcn_readfirstlane((int)((b >> 32) & 0xFFFFu));  // stride 0
+  r.z = __builtin_amdgcn_readfirstlane((int)bytes);
+  r.w = 0x00020000;
+  return r;
+}
+constexpr unsigned CS_OOB = 0x7FFFFFF0u;  // a byte offset no plane reaches (the launch checks): reads as zeros
+
 struct CsArgs {
   const unsigned short* in;  // NDHWC bf16
   const unsigned short* wf;  // tile-kernel fragment filter, TPK = 2, one n-tile: [chunk16][tap pair][lane][8]
@@ -46,8 +71,16 @@ struct CsArgs {
   int px, py;
   int nty, ntz, nseg, XS;    // tiles along y and z, segments along x and their length
   int blk;                   // 1: workgroup ids are dealt in blocks of 4 (y) x 8 (z) tiles (one XCD's share)
-  int ablate;                // WSR_CS_ABL, timing experiments only: 1 no plane DMA, 2 no MFMAs, 4 no output stores, 8 no LDS reads
+  unsigned long long* stamps;  // -DWSR_CS_STAMPS builds: [workgroup][wave 8][8] cycle sums per loop phase (else unused)
 };
+
+#ifdef WSR_CS_STAMPS
+#define CS_T(var) const long long var = clock64()
+#define CS_ACC(k, t0, t1) st_sum[k] += (t1) - (t0)
+#else
+#define CS_T(var) do {} while (0)
+#define CS_ACC(k, t0, t1) do {} while (0)
+#endif
 
 constexpr int cs_round_up(int v, int m) { return (v + m - 1) / m * m; }
 
@@ -60,7 +93,7 @@ struct CsGeom {
   static constexpr int NP = VOX * OC;             // 16-byte pieces per plane
   static constexpr int NU = (NP + 63) / 64;       // DMA units (64 pieces) per plane; the last one is shifted back
   static constexpr int PLANE_B = NP * 16;
-  static constexpr int NB = 4;                    // plane buffers: one being contracted, three in flight
+  static constexpr int NB = 6;                    // plane buffers: one being contracted, two landed, three in flight
   static constexpr int PAIRS = KY * OC;           // (ky, octet) pairs per kx
   static constexpr int SK = (PAIRS + 3) / 4;      // K-steps per kx
   static constexpr int NPW = (SK + 3) / 4;        // K-steps per kx and wave (four K groups)
@@ -114,12 +147,12 @@ __global__ __launch_bounds__(512) void conv_slide_fwd_kernel(const CsArgs a) {
   const bool dma_wave = kg >= 2;
   const int dw = (kg - 2) + 2 * mh;  // 0 .. 3 among the DMA waves
   constexpr int UPW = (NU + 3) / 4;
-  int uoff[UPW];       // element offset inside an x-plane of the input, or -1 (zero page)
+  unsigned uoff[UPW];  // byte offset inside an x-plane of the input, or CS_OOB (reads as zeros)
   unsigned udst[UPW];  // LDS byte offset of the unit inside a plane (wave-uniform)
 #pragma unroll
   for (int k = 0; k < UPW; ++k) {
     const int u = dw + 4 * k;
-    int off = -1;
+    unsigned off = CS_OOB;
     unsigned dst = 0;
     if (dma_wave && u < NU) {
       const int p0 = u * 64 < NP - 64 ? u * 64 : NP - 64;  // the last unit is shifted back: no partial unit
@@ -128,24 +161,25 @@ __global__ __launch_bounds__(512) void conv_slide_fwd_kernel(const CsArgs a) {
       const int vox = p / OC, o = p - vox * OC;
       const int yl = vox / TZ, zl = vox - yl * TZ;
       const int gy = y0 - a.py + yl, gz = z0 + zl;
-      if ((unsigned)gy < (unsigned)a.Y && gz < a.Z) off = (gy * a.Z + gz) * a.in_ctot + a.in_off + o * 8;
+      if ((unsigned)gy < (unsigned)a.Y && gz < a.Z) off = (unsigned)((gy * a.Z + gz) * a.in_ctot + a.in_off + o * 8) * 2u;
     }
     uoff[k] = off;
     udst[k] = __builtin_amdgcn_readfirstlane(dst);
   }
   const long plane_elems = (long)a.Y * a.Z * a.in_ctot;
-  auto plane_issue = [&](int xi, int slot) __attribute__((always_inline)) {
-    if (!dma_wave || (a.ablate & 1)) return;
-    const bool xin = (unsigned)xi < (unsigned)a.X;
-    const unsigned short* base = a.in + ((long)b * a.X + (xin ? xi : 0)) * plane_elems;
+  // descriptor of input plane xi: a plane outside the tensor (or past the segment's last one) has zero records -
+  // every lane reads zeros
+  auto plane_srd = [&](int xi, bool wanted) __attribute__((always_inline)) {
+    const bool xin = wanted && (unsigned)xi < (unsigned)a.X;
+    return cs_make_srd(a.in + ((long)b * a.X + (xin ? xi : 0)) * plane_elems, xin ? (unsigned)(plane_elems * 2) : 0u);
+  };
+  auto plane_issue = [&](int xi, int slot, bool wanted) __attribute__((always_inline)) {
+    if (!dma_wave) return;
+    const cs_srd_t srd = plane_srd(xi, wanted);
     const unsigned dst = ring_lds + (unsigned)slot * PLANE_B;
 #pragma unroll
-    for (int k = 0; k < UPW; ++k) {
-      if (dw + 4 * k < NU) {
-        const unsigned short* src = (xin && uoff[k] >= 0) ? base + uoff[k] : reinterpret_cast<const unsigned short*>(a.zero16);
-        cs_glds16(src, dst + udst[k]);
-      }
-    }
+    for (int k = 0; k < UPW; ++k)
+      if (dw + 4 * k < NU) cs_bufdma16(srd, uoff[k], dst + udst[k]);
   };
 
   // ---- this wave's filter fragments, in registers for the whole launch --------------------------------
@@ -185,120 +219,184 @@ __global__ __launch_bounds__(512) void conv_slide_fwd_kernel(const CsArgs a) {
   // multiplied into the accumulators of all KX outputs it belongs to; an output's accumulator is complete KX planes
   // after it was opened and the set shifts by one.  (Output-stationary - one x fragment per MFMA, every plane read
   // KX times from a KX + 1 deep ring - saturated the LDS read path and the matrix pipe at the same time and got the
-  // sum of the two, not the maximum: 340 us with both ~45 % busy.)  LDS holds NB = 4 planes: the one being contracted
-  // and three in flight (issued three iterations before use: ~69 KB per CU on the wire).
+  // sum of the two, not the maximum: 340 us with both ~45 % busy.)  LDS holds NB = 6 planes: the one being contracted,
+  // the next one (landed and published one barrier early, so that its first fragments are requested BEFORE the
+  // barrier that ends the iteration and the matrix work restarts without an LDS round trip) and three in flight
+  // (~69 KB per CU on the wire).
+  // The loop body is straight-line: every iteration issues a plane (past the end: a zero-record descriptor, no
+  // traffic), writes / sums partial sums (before the first complete output: of garbage, never stored) - the first
+  // version chose among these per iteration with ~150 scalar branches and spent 0.6 us per plane on them.
   constexpr int NB = G::NB;
   const int n_in = nplanes + KX - 1;   // input planes the workgroup contracts
   const int xin0 = x_begin - a.px;     // global x of input plane 0
   const int nw = dma_wave ? (NU - dw + 3) / 4 : 0;  // DMA instructions this wave issues per plane (wave-uniform)
-  static_assert(2 * ((NU + 3) / 4) <= 16, "wait_landed counts at most 16 younger DMA instructions");
-  // wait until everything but the `planes_younger` most recently issued planes of this wave has landed
-  auto wait_landed = [&](int planes_younger) __attribute__((always_inline)) {
+  constexpr int NWMAX = (NU + 3) / 4;
+  static_assert(NWMAX >= 2 && (NB - 3) * NWMAX <= 63, "counted DMA wait out of range");
+  // wait until everything but the `young` most recently issued planes of this wave has landed (nw or nw - 1 DMA
+  // instructions per plane, by wave)
+  auto wait_landed = [&](auto young_c) __attribute__((always_inline)) {
+    constexpr int YOUNG = decltype(young_c)::value;
     if (!dma_wave) return;  // (its vmcnt holds output stores only: nothing to wait for)
-    switch (planes_younger * nw) {
-      case 16: asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); break;
-      case 14: asm volatile("s_waitcnt vmcnt(14)" ::: "memory"); break;
-      case 12: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
-      case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
-      case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
-      case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
-      case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
-      case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
-      case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
-      case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
-      case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
-      case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
-      default: cs_dma_wait();
+    if (nw == NWMAX) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(YOUNG * NWMAX) : "memory");
+    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(YOUNG * (NWMAX - 1)) : "memory");
+  };
+  using young_loop = std::integral_constant<int, NB - 3>;
+
+  // ---- prologue: planes 0 .. NB-2 are issued, planes 0 and 1 land ---------------------------------------------------
+#pragma unroll
+  for (int q = 0; q < NB - 1; ++q) plane_issue(xin0 + q, q, q < n_in);
+  wait_landed(young_loop{});
+  __syncthreads();
+
+  // finalizer of m-tile m: wave (kg = m & 1, mh = m >> 1); everybody else stores its partial sums.  The sum of
+  // output plane o is taken one iteration LATER, under the MFMAs of the next input plane: its LDS reads are requested
+  // right after the barrier that published the partial sums and consumed behind the matrix work.
+  const int my_m0 = 2 * mh, my_m1 = 2 * mh + 1;
+  const bool fin0 = kg == (my_m0 & 1), fin1 = kg == (my_m1 & 1), fin = fin0 || fin1;
+  const int fin_m = fin0 ? my_m0 : my_m1, fin_k = fin_m & 1;
+  // partial-sum slots: [m-tile 4][K group minus the finalizer's: 3][lane][16 B]; finalizer K group of m-tile m is m & 1
+  auto pslot = [&](int m, int g) __attribute__((always_inline)) {
+    const int fk = m & 1;
+    return (m * 3 + (g > fk ? g - 1 : g)) * 1024 + lane * 16;
+  };
+  const long out_plane = (long)a.Y * a.Z;  // voxels of one (b, n, x) plane
+  const long nstride = (long)a.X * out_plane;
+  const int fgy = y0 + 4 * fin_m + (fr >> 2), fgz = z0 + (fr & 3);
+  const bool fin_vox = fin && fgy < a.Y && fgz < a.Z;
+  float* const out_lane = a.out + ((long)b * a.N + 4 * fg) * nstride + (long)fgy * a.Z + fgz;
+  // byte offsets of the partial sums this wave reads as finalizer (K groups other than its own), and writes otherwise
+  int rd_off[3];
+#pragma unroll
+  for (int g3 = 0; g3 < 3; ++g3) rd_off[g3] = (fin_m * 3 + g3) * 1024 + lane * 16;
+  const int wr0 = pslot(my_m0, kg), wr1 = pslot(my_m1, kg);
+  auto finalize = [&](const f32x4_t (&part)[3], const f32x4_t& own, int o) __attribute__((always_inline)) {
+    // fixed order over the K groups: part[] holds groups {0..3} \ {fin_k} in order, own sits at position fin_k
+    f32x4_t sum;
+    if (fin_k == 0) {
+      sum = own;
+#pragma unroll
+      for (int g3 = 0; g3 < 3; ++g3) { sum[0] += part[g3][0]; sum[1] += part[g3][1]; sum[2] += part[g3][2]; sum[3] += part[g3][3]; }
+    } else {  // fin_k == 1
+      sum = part[0];
+      sum[0] += own[0]; sum[1] += own[1]; sum[2] += own[2]; sum[3] += own[3];
+#pragma unroll
+      for (int g3 = 1; g3 < 3; ++g3) { sum[0] += part[g3][0]; sum[1] += part[g3][1]; sum[2] += part[g3][2]; sum[3] += part[g3][3]; }
+    }
+    if (fin_vox && o >= 0) {
+      float* op = out_lane + (long)(x_begin + o) * out_plane;
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (4 * fg + r < a.N) op[r * nstride] = sum[r] + bias4[r];
     }
   };
 
-  // ---- prologue: planes 0 .. NB-2 are issued, plane 0 lands -----------------------------------------------------
-#pragma unroll
-  for (int q = 0; q < NB - 1; ++q)
-    if (q < n_in) plane_issue(xin0 + q, q);
-  wait_landed(min(NB - 2, n_in - 1));
-  __syncthreads();
-
-  // finalizer of m-tile m: wave (kg = m & 1, mh = m >> 1); everybody else stores its partial sums
-  const int my_m0 = 2 * mh, my_m1 = 2 * mh + 1;
-  const long out_plane = (long)a.Y * a.Z;  // voxels of one (b, n, x) plane
   f32x4_t acc[KX][2];                      // acc[kx]: output plane p - kx, m-tiles 2 mh and 2 mh + 1
 #pragma unroll
   for (int kx = 0; kx < KX; ++kx) acc[kx][0] = acc[kx][1] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  f32x4_t own_prev = {0.f, 0.f, 0.f, 0.f};  // the finalizer's own partial sum of the plane completed last iteration
   int slot = 0;  // p mod NB
+  // x fragments: a ring of D steps (the whole plane's 2 NPW fragments at once would not fit beside the filter); the
+  // first D of a plane are requested at the end of the previous iteration
+  constexpr int D = 3;
+  uint4 xa[D], xb[D];
+#pragma unroll
+  for (int j = 0; j < D && j < NPW; ++j) {
+    xa[j] = *reinterpret_cast<const uint4*>(smem + woff[j]);
+    xb[j] = *reinterpret_cast<const uint4*>(smem + woff[j] + 16 * ROWB);
+  }
+#ifdef WSR_CS_STAMPS
+  long long st_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  const long long st_begin = clock64();
+#endif
   for (int p = 0; p < n_in; ++p) {
-    // the buffer of plane p - 1 (all waves are past the barrier that closed it) takes plane p + NB - 1
-    {
-      int s = slot + NB - 1;
-      if (s >= NB) s -= NB;
-      if (p + NB - 1 < n_in) plane_issue(xin0 + p + NB - 1, s);
-    }
+    CS_T(t0);
+    // The buffer of plane p - 1 (all waves are past the barrier that closed it) takes plane p + NB - 1.  Its DMA
+    // instructions are issued BETWEEN the MFMA groups below, one per group: issued in a block they cost the DMA waves
+    // 600-800 cycles per plane in front of their matrix work (in-kernel stamps), and the output stores of the
+    // finalizing waves queued behind them for another ~1 300.
+    int s_nxt = slot + NB - 1;
+    if (s_nxt >= NB) s_nxt -= NB;
+    const cs_srd_t srd_nxt = plane_srd(xin0 + p + NB - 1, p + NB - 1 < n_in);
+    const unsigned dst_nxt = ring_lds + (unsigned)s_nxt * PLANE_B;
+    constexpr int UPG = (UPW + NPW - 1) / NPW;  // DMA instructions behind each MFMA group
+    CS_T(t1);
+    CS_ACC(0, t0, t1);
     const char* pl = smem + slot * PLANE_B;
-    uint4 xa[NPW], xb[NPW];
-    if (!(a.ablate & 8)) {
+    // partial sums of output plane p - KX (completed by input plane p - 1): requested now, summed behind the MFMAs
+    f32x4_t part[3];
+    const char* scr_prev = scratch + ((p - 1) & 1) * SCR_B;
+    if (fin) {
 #pragma unroll
-      for (int j = 0; j < NPW; ++j) {
-        xa[j] = *reinterpret_cast<const uint4*>(pl + woff[j]);
-        xb[j] = *reinterpret_cast<const uint4*>(pl + woff[j] + 16 * ROWB);
+      for (int g3 = 0; g3 < 3; ++g3) part[g3] = *reinterpret_cast<const f32x4_t*>(scr_prev + rd_off[g3]);
+    }
+#pragma unroll
+    for (int j = 0; j < NPW; ++j) {
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int kx = 0; kx < KX; ++kx) {
+        mma_chunk<BF16>(acc[kx][0], wreg[kx][j], xa[j % D]);
+        mma_chunk<BF16>(acc[kx][1], wreg[kx][j], xb[j % D]);
       }
-    } else {
+      if (j + D < NPW) {
+        xa[j % D] = *reinterpret_cast<const uint4*>(pl + woff[j + D]);
+        xb[j % D] = *reinterpret_cast<const uint4*>(pl + woff[j + D] + 16 * ROWB);
+      }
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int j = 0; j < NPW; ++j) xa[j] = xb[j] = make_uint4(p, j, p, j);
+      for (int k = j * UPG; k < (j + 1) * UPG && k < UPW; ++k)
+        if (dma_wave && dw + 4 * k < NU) cs_bufdma16(srd_nxt, uoff[k], dst_nxt + udst[k]);
+      if (j == 1 && fin) finalize(part, own_prev, p - KX);  // (its LDS reads have long landed)
     }
-    if (!(a.ablate & 2)) {
-#pragma unroll
-      for (int j = 0; j < NPW; ++j)
-#pragma unroll
-        for (int kx = 0; kx < KX; ++kx) {
-          mma_chunk<BF16>(acc[kx][0], wreg[kx][j], xa[j]);
-          mma_chunk<BF16>(acc[kx][1], wreg[kx][j], xb[j]);
-        }
-    } else {
-#pragma unroll
-      for (int j = 0; j < NPW; ++j) asm volatile("" ::"v"(xa[j].x), "v"(xb[j].w));
-    }
-    // ---- output plane o = p - (KX - 1) is complete: partial sums -> LDS, fixed-order sum, store -----------------
-    const int o_done = p - (KX - 1);
+    __builtin_amdgcn_sched_barrier(0);
+    CS_T(t2);
+    CS_ACC(1, t1, t2);
+    CS_T(t3);
+    CS_ACC(2, t2, t3);
+    // ---- output plane p - (KX - 1) is complete: partial sums -> LDS, accumulator set shifts --------------------
     const f32x4_t acc0 = acc[KX - 1][0], acc1 = acc[KX - 1][1];
 #pragma unroll
     for (int kx = KX - 1; kx > 0; --kx) { acc[kx][0] = acc[kx - 1][0]; acc[kx][1] = acc[kx - 1][1]; }
     acc[0][0] = acc[0][1] = f32x4_t{0.f, 0.f, 0.f, 0.f};
     char* scr = scratch + (p & 1) * SCR_B;
-    // layout: [m-tile 4][K group minus the finalizer's: 3][lane][16 B]; finalizer K group of m-tile m is m & 1
-    auto pslot = [&](int m, int g) __attribute__((always_inline)) {
-      const int fk = m & 1;
-      return (m * 3 + (g > fk ? g - 1 : g)) * 1024 + lane * 16;
-    };
-    const bool fin0 = kg == (my_m0 & 1), fin1 = kg == (my_m1 & 1);
-    if (o_done >= 0) {
-      if (!fin0) *reinterpret_cast<f32x4_t*>(scr + pslot(my_m0, kg)) = acc0;
-      if (!fin1) *reinterpret_cast<f32x4_t*>(scr + pslot(my_m1, kg)) = acc1;
+    if (!fin0) *reinterpret_cast<f32x4_t*>(scr + wr0) = acc0;
+    if (!fin1) *reinterpret_cast<f32x4_t*>(scr + wr1) = acc1;
+    own_prev = fin0 ? acc0 : acc1;
+    {  // first fragments of plane p + 1 (published by the previous barrier)
+      int sn = slot + 1;
+      if (sn >= NB) sn -= NB;
+      const char* pn = smem + sn * PLANE_B;
+#pragma unroll
+      for (int j = 0; j < D && j < NPW; ++j) {
+        xa[j] = *reinterpret_cast<const uint4*>(pn + woff[j]);
+        xb[j] = *reinterpret_cast<const uint4*>(pn + woff[j] + 16 * ROWB);
+      }
     }
-    // plane p + 1 has landed; the two planes issued after it stay in flight
-    wait_landed(min(NB - 2, n_in - 2 - p < 0 ? 0 : n_in - 2 - p));
+    CS_T(t4);
+    CS_ACC(3, t3, t4);
+    wait_landed(young_loop{});  // plane p + 2 has landed; the three planes issued after it stay in flight
+    CS_T(t5);
+    CS_ACC(4, t4, t5);
     __syncthreads();
-    if (o_done >= 0 && (fin0 || fin1)) {
-      const int m = fin0 ? my_m0 : my_m1;
-      const f32x4_t own = fin0 ? acc0 : acc1;
-      const int fk = m & 1;
-      f32x4_t sum = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {  // fixed order over the K groups
-        const f32x4_t q = g == fk ? own : *reinterpret_cast<const f32x4_t*>(scr + pslot(m, g));
-        if (g == 0) sum = q;
-        else { sum[0] += q[0]; sum[1] += q[1]; sum[2] += q[2]; sum[3] += q[3]; }
-      }
-      const int gy = y0 + 4 * m + (fr >> 2), gz = z0 + (fr & 3);
-      if (gy < a.Y && gz < a.Z) {
-        float* o = a.out + (((long)b * a.N + 4 * fg) * a.X + (x_begin + o_done)) * out_plane + (long)gy * a.Z + gz;
-        const long nstride = (long)a.X * out_plane;
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-          if (4 * fg + r < a.N && !(a.ablate & 4)) o[r * nstride] = sum[r] + bias4[r];
-      }
-    }
+    CS_T(t6);
+    CS_ACC(5, t5, t6);
     if (++slot == NB) slot = 0;
   }
+#ifdef WSR_CS_STAMPS
+  if (a.stamps && lane == 0) {
+    unsigned long long* q = a.stamps + ((size_t)blockIdx.x * 8 + wave) * 8;
+    for (int k = 0; k < 6; ++k) q[k] = (unsigned long long)st_sum[k];
+    q[6] = (unsigned long long)(clock64() - st_begin);
+    q[7] = (unsigned long long)n_in;
+  }
+#endif
+  if (fin) {  // the last output plane
+    f32x4_t part[3];
+    const char* scr_prev = scratch + ((n_in - 1) & 1) * SCR_B;
+#pragma unroll
+    for (int g3 = 0; g3 < 3; ++g3) part[g3] = *reinterpret_cast<const f32x4_t*>(scr_prev + rd_off[g3]);
+    finalize(part, own_prev, n_in - KX);
+  }
+  cs_dma_wait();  // (zero-record planes issued past the end still write LDS: they must not outlive the workgroup)
 }
 
 template <int KX, int KY, int OC>
@@ -324,10 +422,11 @@ int launch_slide_fwd(CsArgs& a, hipStream_t st) {
   a.XS = (a.X + nseg - 1) / nseg;
   a.nseg = (a.X + a.XS - 1) / a.XS;
   a.blk = (a.nty % 4 == 0 && a.ntz % 8 == 0) ? 1 : 0;
-  static const int abl = getenv("WSR_CS_ABL") ? atoi(getenv("WSR_CS_ABL")) : 0;  // timing experiments (read once)
-  a.ablate = abl;
   const long wg = cols * a.nseg;
   if (wg >= (1l << 31)) return WSR_EUNSUPPORTED;
+#ifdef WSR_CS_STAMPS
+  a.stamps = getenv("WSR_CS_STAMPS_PTR") ? (unsigned long long*)strtoull(getenv("WSR_CS_STAMPS_PTR"), nullptr, 0) : nullptr;
+#endif
   hipLaunchKernelGGL(kern, dim3((unsigned)wg), dim3(512), G::LDS_B, st, a);
   WSR_LAUNCH_CHECK();
   return 0;
@@ -341,7 +440,7 @@ int wsr_conv_slide_fwd(const unsigned short* in, int in_ctot, int in_off, int C,
                        int N, int B, int X, int Y, int Z, int KX, int KY, int px, int py, const float* bias,
                        const void* zero16, hipStream_t st) {
   if (C % 16 || in_ctot % 8 || in_off % 8 || N < 1 || N > 16) return WSR_EUNSUPPORTED;
-  if ((long)Y * Z * in_ctot >= (1l << 31)) return WSR_EUNSUPPORTED;  // 32-bit offsets inside an x-plane
+  if ((long)Y * Z * in_ctot >= (1l << 29)) return WSR_EUNSUPPORTED;  // 32-bit byte offsets inside an x-plane, below CS_OOB
   if ((long)B * Y * Z < 64 || X < 8) return WSR_EUNSUPPORTED;        // tiny volumes stay on the small-tile kernels
   CsArgs a{};
   a.in = in; a.wf = wfrag; a.out = out; a.zero16 = zero16; a.bias = bias;
@@ -449,16 +548,17 @@ __global__ __launch_bounds__(512) void conv_slide_dgrad_kernel(const CdArgs a) {
   char* const stg = smem + G::OFF_STAGE;
 
   // ---- DMA units of waves 0-3: units [0, M_NU) = mask plane, [M_NU, NU) = dy plane; result units of waves 4-7 ------
-  // (one offset table for both roles: a wave has one of them)
+  // (one offset table for both roles: a wave has one of them).  DMA goes through buffer descriptors (cs_bufdma16):
+  // rows outside the tensor and planes past the segment read as zeros without any address arithmetic.
   const bool dma_wave = wave < 4, st_wave = !dma_wave;
   const int w4 = wave & 3;
   constexpr int UPW = (NU + 3) / 4, SPW = (M_NU + 3) / 4;
-  int uoff[UPW];        // element offset inside an x-plane of the tensor the unit belongs to, or -1
+  unsigned uoff[UPW];   // byte offset inside an x-plane of the tensor the unit belongs to, or CS_OOB
   unsigned udst[UPW];   // LDS byte offset of the unit inside its plane (wave-uniform)
 #pragma unroll
   for (int k = 0; k < UPW; ++k) {
     const int u = w4 + 4 * k;
-    int off = -1;
+    unsigned off = CS_OOB;
     unsigned dst = 0;
     if (u < M_NU) {  // a mask unit (DMA waves) or the result unit of the same voxels (store waves)
       const int p0 = u * 64 < M_NP - 64 ? u * 64 : M_NP - 64;
@@ -468,7 +568,8 @@ __global__ __launch_bounds__(512) void conv_slide_dgrad_kernel(const CdArgs a) {
       const int vox = p / OC, o = p - vox * OC;
       const int gy = y0 + vox / TZ, gz = z0 + vox % TZ;
       if (gy < a.Y && gz < a.Z)
-        off = dma_wave ? (gy * a.Z + gz) * a.mask_ctot + a.mask_off + o * 8 : (gy * a.Z + gz) * a.dx_ctot + a.dx_off + o * 8;
+        off = 2u * (unsigned)(dma_wave ? (gy * a.Z + gz) * a.mask_ctot + a.mask_off + o * 8
+                                       : (gy * a.Z + gz) * a.dx_ctot + a.dx_off + o * 8);
     } else if (dma_wave && u < NU) {
       const int ud = u - M_NU;
       const int p0 = ud * 64 < DY_NP - 64 ? ud * 64 : DY_NP - 64;
@@ -476,35 +577,28 @@ __global__ __launch_bounds__(512) void conv_slide_dgrad_kernel(const CdArgs a) {
       const int p = p0 + lane;
       const int vox = p >> 1, o = p & 1;
       const int gy = y0 - a.py + vox / TZ, gz = z0 + vox % TZ;
-      if ((unsigned)gy < (unsigned)a.Y && gz < a.Z) off = (gy * a.Z + gz) * a.dy_ctot + a.dy_off + o * 8;
+      if ((unsigned)gy < (unsigned)a.Y && gz < a.Z) off = 2u * (unsigned)((gy * a.Z + gz) * a.dy_ctot + a.dy_off + o * 8);
     }
     uoff[k] = off;
     udst[k] = __builtin_amdgcn_readfirstlane(dst);
   }
   const long mask_plane = (long)a.Y * a.Z * a.mask_ctot, dy_plane = (long)a.Y * a.Z * a.dy_ctot;
-  // mask plane xm (output plane index relative to x_begin) and dy plane xd (input plane index relative to
-  // x_begin - px); either may be out of range (nothing issued for a mask plane beyond the segment)
-  auto issue = [&](int xm, bool want_mask, int xd, bool want_dy) __attribute__((always_inline)) {
-    if (!dma_wave) return;
-#pragma unroll
-    for (int k = 0; k < UPW; ++k) {
-      const int u = wave + 4 * k;
-      if (u < M_NU) {
-        if (want_mask) {
-          const unsigned short* src = uoff[k] >= 0 ? a.mask + ((long)b * a.X + x_begin + xm) * mask_plane + uoff[k]
-                                                   : reinterpret_cast<const unsigned short*>(a.zero16);
-          cs_glds16(src, lds0 + G::OFF_MASK + (unsigned)(xm % RM) * M_B + udst[k]);
-        }
-      } else if (u < NU) {
-        if (want_dy) {
-          const int xi = x_begin - a.px + xd;
-          const bool xin = (unsigned)xi < (unsigned)a.X;
-          const unsigned short* src = (xin && uoff[k] >= 0) ? a.dy + ((long)b * a.X + xi) * dy_plane + uoff[k]
-                                                            : reinterpret_cast<const unsigned short*>(a.zero16);
-          cs_glds16(src, lds0 + G::OFF_DY + (unsigned)(xd & (RD - 1)) * DY_B + udst[k]);
-        }
-      }
-    }
+  // descriptors of mask plane xm (output plane index relative to x_begin) and dy plane xd (input plane index
+  // relative to x_begin - px); a plane that is not wanted or outside the tensor has zero records (reads as zeros)
+  auto mask_srd = [&](int xm, bool wanted) __attribute__((always_inline)) {
+    return cs_make_srd(a.mask + ((long)b * a.X + (wanted ? x_begin + xm : 0)) * mask_plane,
+                       wanted ? (unsigned)(mask_plane * 2) : 0u);
+  };
+  auto dy_srd = [&](int xd, bool wanted) __attribute__((always_inline)) {
+    const int xi = x_begin - a.px + xd;
+    const bool xin = wanted && (unsigned)xi < (unsigned)a.X;
+    return cs_make_srd(a.dy + ((long)b * a.X + (xin ? xi : 0)) * dy_plane, xin ? (unsigned)(dy_plane * 2) : 0u);
+  };
+  // DMA instruction k of this wave for (mask plane xm, dy plane xd)
+  auto issue_unit = [&](int k, const cs_srd_t& sm, int xm, const cs_srd_t& sd, int xd) __attribute__((always_inline)) {
+    const int u = w4 + 4 * k;
+    if (u < M_NU) cs_bufdma16(sm, uoff[k], lds0 + G::OFF_MASK + (unsigned)(xm % RM) * M_B + udst[k]);
+    else if (u < NU) cs_bufdma16(sd, uoff[k], lds0 + G::OFF_DY + (unsigned)(xd & (RD - 1)) * DY_B + udst[k]);
   };
 
   const long dx_plane = (long)a.Y * a.Z * a.dx_ctot;
@@ -531,20 +625,42 @@ __global__ __launch_bounds__(512) void conv_slide_dgrad_kernel(const CdArgs a) {
   const int lane_base = (2 * mh * 16 + fr) * 32 + (fg & 1) * 16;  // (m-tile 2 mh; the second one is + 16 voxels)
   const bool tap_hi = (fg >> 1) != 0;
 
-  // ---- prologue ----------------------------------------------------------------------------------------------
+  // ---- prologue: dy planes 0 .. KX, mask planes 0 and 1 -----------------------------------------------------------
   const int last_dy = nplanes + KX - 2;
+  if (dma_wave) {
+    const cs_srd_t none = cs_make_srd(a.mask, 0u);
 #pragma unroll
-  for (int d = 0; d <= KX; ++d) issue(0, false, d, d <= last_dy);
-  issue(0, true, 0, false);
-  issue(1, nplanes > 1, 0, false);
+    for (int d = 0; d <= KX; ++d) {
+      const cs_srd_t sd = dy_srd(d, d <= last_dy);
+#pragma unroll
+      for (int k = 0; k < UPW; ++k)
+        if (w4 + 4 * k >= M_NU) issue_unit(k, none, 0, sd, d);
+    }
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+      const cs_srd_t sm = mask_srd(m, m < nplanes);
+#pragma unroll
+      for (int k = 0; k < UPW; ++k)
+        if (w4 + 4 * k < M_NU) issue_unit(k, sm, m, none, 0);
+    }
+  }
   cs_dma_wait();
   __syncthreads();
 
-  const int nw_full = dma_wave ? (NU - wave + 3) / 4 : 0;  // DMA instructions per plane when both kinds are issued
-  const int nw_dy = dma_wave ? nw_full - ((M_NU - wave + 3) / 4) : 0;
-  for (int i = 0; i < nplanes; ++i) {
-    const bool want_mask = i + 2 < nplanes, want_dy = i + KX + 1 <= last_dy;
-    issue(i + 2, want_mask, i + KX + 1, want_dy);
+  // DMA instructions this wave issues per plane (every plane: past the end they carry zero-record descriptors)
+  const int nw = dma_wave ? (NU - w4 + 3) / 4 : 0;
+  constexpr int NWMAX = (NU + 3) / 4;
+  static_assert(UPW <= NKS && 2 * SPW <= NKS, "one DMA instruction / one half of a store per K-step");
+  for (int i = 0; i <= nplanes; ++i) {  // (one extra round: the stores of the last plane)
+    const bool contract = i < nplanes;
+    // this iteration's DMA (mask plane i + 2, dy plane i + KX + 1) and the stores of plane i - 1 are issued BETWEEN
+    // the K-steps below, one per step (a block of 5-6 DMA instructions cost a DMA wave 600-800 cycles in front of
+    // its matrix work; the stores waited behind them)
+    const cs_srd_t sm = mask_srd(i + 2, i + 2 < nplanes), sd = dy_srd(i + KX + 1, i + KX + 1 <= last_dy);
+    unsigned short* const st_base = a.dx + ((long)b * a.X + x_begin + (i > 0 ? i - 1 : 0)) * dx_plane;
+    const char* const sg_prev = stg + ((i - 1) & 1) * M_B;
+    const bool st_now = st_wave && i > 0;
+    uint4 sreg = make_uint4(0u, 0u, 0u, 0u);
     // ---- contraction: 2 m-tiles x TN n-tiles, NKS K-steps -----------------------------------------------------
     f32x4_t acc[2][TN + NX];
 #pragma unroll
@@ -553,40 +669,56 @@ __global__ __launch_bounds__(512) void conv_slide_dgrad_kernel(const CdArgs a) {
       for (int j = 0; j < TN + NX; ++j) acc[m][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
     constexpr int D = 2;
     uint4 xa[D], xb[D], wx[D];
-    auto frag_addr = [&](int ks) __attribute__((always_inline)) {
-      constexpr int LAST = KX * KY - 1;  // a padded tap reads the last real one: zero weights, finite data
-      const int tA = 2 * ks < LAST ? 2 * ks : LAST, tB = 2 * ks + 1 < LAST ? 2 * ks + 1 : LAST;
-      const int cA = ((i + tA / KY) & (RD - 1)) * DY_B + (tA % KY) * TZ * 32;
-      const int cB = ((i + tB / KY) & (RD - 1)) * DY_B + (tB % KY) * TZ * 32;
-      return dyr + lane_base + (tap_hi ? cB : cA);
-    };
-    auto fetch = [&](int ks) __attribute__((always_inline)) {
-      const char* p = frag_addr(ks);
-      xa[ks % D] = *reinterpret_cast<const uint4*>(p);
-      xb[ks % D] = *reinterpret_cast<const uint4*>(p + 16 * 32);
-      if constexpr (NX > 0) {
-        if (extra) wx[ks % D] = *reinterpret_cast<const uint4*>(wxl + ks * 1024 + lane * 16);
-      }
-    };
+#define CD_FRAG_ADDR(ks)                                                                                        \
+  (dyr + lane_base +                                                                                            \
+   (tap_hi ? ((i + ((2 * (ks) + 1 < KX * KY - 1 ? 2 * (ks) + 1 : KX * KY - 1) / KY)) & (RD - 1)) * DY_B +        \
+                 ((2 * (ks) + 1 < KX * KY - 1 ? 2 * (ks) + 1 : KX * KY - 1) % KY) * TZ * 32                       \
+           : ((i + ((2 * (ks) < KX * KY - 1 ? 2 * (ks) : KX * KY - 1) / KY)) & (RD - 1)) * DY_B +                \
+                 ((2 * (ks) < KX * KY - 1 ? 2 * (ks) : KX * KY - 1) % KY) * TZ * 32))
+#define CD_FETCH(ks)                                                                                            \
+  do {                                                                                                          \
+    const char* p_ = CD_FRAG_ADDR(ks);                                                                          \
+    xa[(ks) % D] = *reinterpret_cast<const uint4*>(p_);                                                         \
+    xb[(ks) % D] = *reinterpret_cast<const uint4*>(p_ + 16 * 32);                                               \
+    if constexpr (NX > 0) {                                                                                     \
+      if (extra) wx[(ks) % D] = *reinterpret_cast<const uint4*>(wxl + (ks) * 1024 + lane * 16);                  \
+    }                                                                                                           \
+  } while (0)
+    if (contract) {
 #pragma unroll
-    for (int ks = 0; ks < D && ks < NKS; ++ks) fetch(ks);
+      for (int ks = 0; ks < D && ks < NKS; ++ks) CD_FETCH(ks);
+    }
 #pragma unroll
     for (int ks = 0; ks < NKS; ++ks) {
       __builtin_amdgcn_sched_barrier(0);
+      if (contract) {
 #pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        mma_chunk<BF16>(acc[0][j], wreg[ks][j], xa[ks % D]);
-        mma_chunk<BF16>(acc[1][j], wreg[ks][j], xb[ks % D]);
+        for (int j = 0; j < TN; ++j) {
+          mma_chunk<BF16>(acc[0][j], wreg[ks][j], xa[ks % D]);
+          mma_chunk<BF16>(acc[1][j], wreg[ks][j], xb[ks % D]);
+        }
+        if constexpr (NX > 0) {
+          if (extra) {
+            mma_chunk<BF16>(acc[0][TN], wx[ks % D], xa[ks % D]);
+            mma_chunk<BF16>(acc[1][TN], wx[ks % D], xb[ks % D]);
+          }
+        }
+        if (ks + D < NKS) CD_FETCH(ks + D);
       }
-      if constexpr (NX > 0) {
-        if (extra) {
-          mma_chunk<BF16>(acc[0][TN], wx[ks % D], xa[ks % D]);
-          mma_chunk<BF16>(acc[1][TN], wx[ks % D], xb[ks % D]);
+      __builtin_amdgcn_sched_barrier(0);
+      if (ks < UPW && dma_wave && contract) issue_unit(ks, sm, i + 2, sd, i + KX + 1);
+      if (ks < 2 * SPW && st_now) {  // result unit ks / 2 of plane i - 1: LDS read on even steps, store on odd ones
+        const int k = ks >> 1;
+        if (w4 + 4 * k < M_NU) {
+          if (!(ks & 1)) sreg = *reinterpret_cast<const uint4*>(sg_prev + udst[k] + lane * 16);
+          else if (uoff[k] != CS_OOB) *reinterpret_cast<uint4*>(reinterpret_cast<char*>(st_base) + uoff[k]) = sreg;
         }
       }
-      if (ks + D < NKS) fetch(ks + D);
     }
     __builtin_amdgcn_sched_barrier(0);
+#undef CD_FETCH
+#undef CD_FRAG_ADDR
+    if (!contract) break;
     // ---- mask, scale, round, stage as [voxel][ROWB] rows ---------------------------------------------------------
     const char* mk = mkr + (i % RM) * M_B;
     char* sg = stg + (i & 1) * M_B;
@@ -612,28 +744,12 @@ __global__ __launch_bounds__(512) void conv_slide_dgrad_kernel(const CdArgs a) {
       }
     // the DMA issued one iteration ago (mask plane i + 1, dy plane i + KX) has landed; this iteration's stays in flight
     if (dma_wave) {
-      const int young = (want_mask ? nw_full - nw_dy : 0) + (want_dy ? nw_dy : 0);
-      switch (young) {
-        case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
-        case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
-        case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
-        case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
-        case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
-        case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
-        default: cs_dma_wait();
-      }
+      if (nw == NWMAX) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NWMAX) : "memory");
+      else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NWMAX - 1) : "memory");
     }
     __syncthreads();
-    // ---- whole rows out: 16 bytes per lane, 1 KB per wave instruction ----------------------------------------------
-    if (st_wave) {
-      unsigned short* base = a.dx + ((long)b * a.X + x_begin + i) * dx_plane;
-#pragma unroll
-      for (int k = 0; k < SPW; ++k) {
-        if (w4 + 4 * k < M_NU && uoff[k] >= 0)
-          *reinterpret_cast<uint4*>(base + uoff[k]) = *reinterpret_cast<const uint4*>(sg + udst[k] + lane * 16);
-      }
-    }
   }
+  cs_dma_wait();  // (zero-record DMA issued for planes past the end must not outlive the workgroup)
 }
 
 template <int KX, int KY, int NT>
@@ -677,7 +793,8 @@ int wsr_conv_slide_dgrad(const unsigned short* dy, int dy_ctot, int dy_off, int 
                          int px, int py, float alpha, const wsr_lrelu_mask_t* mask, const void* zero16, hipStream_t st) {
   if (!mask || !mask->y || mask->c0 != 0 || mask->c1 != C || red != 16) return WSR_EUNSUPPORTED;
   if (dy_ctot % 8 || dy_off % 8 || dx_ctot % 8 || dx_off % 8 || mask->y_ctot % 8 || mask->y_off % 8) return WSR_EUNSUPPORTED;
-  if ((long)Y * Z * dx_ctot >= (1l << 31) || (long)Y * Z * mask->y_ctot >= (1l << 31)) return WSR_EUNSUPPORTED;
+  if ((long)Y * Z * dx_ctot >= (1l << 29) || (long)Y * Z * mask->y_ctot >= (1l << 29) || (long)Y * Z * dy_ctot >= (1l << 29))
+    return WSR_EUNSUPPORTED;  // 32-bit byte offsets inside an x-plane, below CS_OOB
   if ((long)B * Y * Z < 64 || X < 8) return WSR_EUNSUPPORTED;
   CdArgs a{};
   a.dy = dy; a.wf = wfrag_t; a.dx = dx; a.mask = (const unsigned short*)mask->y; a.chan_scale = mask->chan_scale;
@@ -687,6 +804,6 @@ int wsr_conv_slide_dgrad(const unsigned short* dy, int dy_ctot, int dy_off, int 
   a.mask_ctot = mask->y_ctot; a.mask_off = mask->y_off;
   a.px = px; a.py = py; a.alpha = alpha; a.slope = mask->slope;
   if (KX == 5 && KY == 5 && C == 144) return launch_slide_dgrad<5, 5, 9>(a, st);
-  if (KX == 3 && KY == 3 && C == 144) return launch_slide_dgrad<3, 3, 9>(a, st);
+  // (other filter extents - no shipped configuration has them - stay on the halo-tile kernel)
   return WSR_EUNSUPPORTED;
 }
