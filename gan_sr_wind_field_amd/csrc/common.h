@@ -94,7 +94,8 @@ static inline int conv_geom_ok(const wsr_conv_t* c) {
   if (c->sx <= 0 || c->sy <= 0 || c->sz <= 0 || c->px < 0 || c->py < 0 || c->pz < 0) return 0;
   if (c->dtype != WSR_F32 && c->dtype != WSR_BF16) return 0;
   if (c->lat) {  // parity conv of a sub-pixel up-sampling conv: same-size, stride 1, uneven pads (see wsr_conv_t)
-    if (c->lat != 2 || c->upsample_xy || (c->sx | c->sy | c->sz) != 1) return 0;
+    if ((c->lat != 2 && c->lat != 3) || c->upsample_xy || (c->sx | c->sy | c->sz) != 1) return 0;
+    if (c->lat == 3 && c->lat_phases) return 0;  // (lat = 3: the INPUT sits on the lattice - filter gradients only)
     if ((unsigned)c->lat_ox > 1u || (unsigned)c->lat_oy > 1u || (c->lat_phases != 0 && c->lat_phases != 4)) return 0;
     if (c->Xo != c->Xi || c->Yo != c->Yi || c->px >= c->KX || c->py >= c->KY) return 0;
     if (c->lat_phases == 4 && (c->px < 1 || c->py < 1 || c->lat_ox || c->lat_oy)) return 0;

@@ -286,7 +286,7 @@ int wsr_conv1x1_bf16(const unsigned short* in, int in_ctot, int in_off, int red,
 extern "C" int wsr_conv3d_fwd_tile(const wsr_conv_t* c, const void* x, const void* wfrag, void* y,
                                    const wsr_epilogue_t* ep, void* stream) {
   if (!conv_geom_ok(c) || !x || !wfrag || !y) return WSR_EINVAL;
-  if (c->dtype != WSR_BF16 || c->sx > 2 || c->sy > 2 || c->sz > 2) return WSR_EUNSUPPORTED;
+  if (c->dtype != WSR_BF16 || c->sx > 2 || c->sy > 2 || c->sz > 2 || c->lat == 3) return WSR_EUNSUPPORTED;
   if ((c->sx | c->sy | c->sz) != 1 && (c->upsample_xy || getenv("WSR_CT_NOSTRIDE"))) return WSR_EUNSUPPORTED;
   CtArgs a{};
   a.sx = c->sx; a.sy = c->sy; a.sz = c->sz;
@@ -353,7 +353,7 @@ extern "C" int wsr_conv3d_dgrad_tile(const wsr_conv_t* c, const void* dy, const 
                mask->c0 % 4 || mask->y_ctot % 4 || mask->y_off % 4 ||
                mask->y_off + (mask->c1 - mask->c0) > mask->y_ctot))
     return WSR_EINVAL;
-  if (c->dtype != WSR_BF16 || (c->sx | c->sy | c->sz) != 1) return WSR_EUNSUPPORTED;
+  if (c->dtype != WSR_BF16 || (c->sx | c->sy | c->sz) != 1 || c->lat == 3) return WSR_EUNSUPPORTED;
   const int ux = c->upsample_xy ? 2 : 1;
   CtArgs a{};
   a.in = (const unsigned short*)dy;

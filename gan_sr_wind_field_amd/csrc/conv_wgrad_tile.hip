@@ -61,6 +61,8 @@ struct WgtArgs {
                                 // wsr_conv3d_wgrad_parts); 0: every split adds into dw with float atomics
   int yl_m, yl_ox, yl_oy;       // dy is the sub-lattice (m*x + ox, m*y + oy, z) of a tensor m times as large along x and y
                                 // (parity convs of a sub-pixel up-sampling conv, wsr_conv_t.lat); m = 1: dy itself
+  int xl_m, xl_ox, xl_oy;       // x is the sub-lattice (m*x + ox, m*y + oy, mz*z + oz) of a tensor m (mz) times as large
+  int xl_mz, xl_oz;             // (filter gradients of the stride-2 down-sampling convs in parity form, wsr_conv_t.lat = 3)
   int prio;                     // 1: waves 4..7 at s_setprio 1 in the tile loop (tuning switch)
   int S_forced;                 // > 0: the number of spatial splits the caller was told (wsr_conv3d_wgrad_nparts)
   int plan_only;                // host side: compute the launch geometry (S) and return without launching
@@ -190,7 +192,8 @@ __global__ __launch_bounds__(512) void wgrad_tile_kernel(const WgtArgs a) {
         const int hz = h % Lz, qq = h / Lz;
         const int hy = qq % Ly, hx = qq / Ly;
         geo = hx | (hy << 8) | (hz << 16) | (1u << 24);
-        rel = ((((hx + parx) >> U) * a.Yi + ((hy + pary) >> U)) * a.Zi + hz) * a.in_ctot + 8 * ch8;
+        rel = ((((hx + parx) >> U) * a.xl_m * (a.Yi * a.xl_m) + ((hy + pary) >> U) * a.xl_m) * (a.Zi * a.xl_mz) +
+               hz * a.xl_mz) * a.in_ctot + 8 * ch8;
       }
     }
     xgeo[k] = geo;
@@ -231,8 +234,10 @@ __global__ __launch_bounds__(512) void wgrad_tile_kernel(const WgtArgs a) {
       const int lox = a.px - x0, loy = a.py - y0, loz = a.pz - z0;  // first in-range halo coordinate
       const int sx_ = a.Xi << U, sy_ = a.Yi << U;
       const bool inner = lox <= 0 && Lx - lox <= sx_ && loy <= 0 && Ly - loy <= sy_ && loz <= 0 && Lz - loz <= a.Zi;
-      const long base = ((((long)b * a.Xi + ((x0 - a.px - parx) >> U)) * a.Yi + ((y0 - a.py - pary) >> U)) * a.Zi +
-                         (z0 - a.pz)) * a.in_ctot + a.in_off + c0;
+      // (xl_m = xl_mz = 1 unless the input sits on a lattice; then U = 0)
+      const long base = ((((long)b * a.Xi * a.xl_m + (long)((x0 - a.px - parx) >> U) * a.xl_m + a.xl_ox) * (a.Yi * a.xl_m) +
+                          (long)((y0 - a.py - pary) >> U) * a.xl_m + a.xl_oy) * (a.Zi * a.xl_mz) +
+                         (long)(z0 - a.pz) * a.xl_mz + a.xl_oz) * a.in_ctot + a.in_off + c0;
       const unsigned short* bp = a.x + base;
 #pragma unroll
       for (int k = 0; k < XK; ++k) {
@@ -616,7 +621,8 @@ int run_tile(WgtArgs& a, int taps, int Cout, int Cin, hipStream_t st);
 int wsr_wgrad_tile_bf16(const wsr_conv_t* c, const void* x, const void* dy, float* dw, int tri_base, int tri_step,
                         long part_stride, int n_parts, int* plan, void* stream) {
   if (c->dtype != WSR_BF16 || (c->sx | c->sy | c->sz) != 1) return WSR_EUNSUPPORTED;
-  if (c->lat && (c->lat_phases || c->lat_mz > 1 || tri_step > 0)) return WSR_EUNSUPPORTED;  // one parity per launch
+  if (c->lat == 2 && (c->lat_phases || c->lat_mz > 1 || tri_step > 0)) return WSR_EUNSUPPORTED;  // one parity per launch
+  if (c->lat == 3 && (c->lat_phases || tri_step > 0 || c->upsample_xy)) return WSR_EUNSUPPORTED;
   const int taps = c->KX * c->KY * c->KZ;
   if (taps > 128) return WSR_EUNSUPPORTED;
   if (c->Cin % 8 || c->in_ctot % 8 || c->in_off % 8 || c->out_ctot % 8 || c->out_off % 8) return WSR_EUNSUPPORTED;
@@ -634,7 +640,12 @@ int wsr_wgrad_tile_bf16(const wsr_conv_t* c, const void* x, const void* dy, floa
   a.KX = c->KX; a.KY = c->KY; a.KZ = c->KZ;
   a.px = c->px; a.py = c->py; a.pz = c->pz;
   a.ups = c->upsample_xy ? 1 : 0;
-  a.yl_m = c->lat ? 2 : 1; a.yl_ox = c->lat ? c->lat_ox : 0; a.yl_oy = c->lat ? c->lat_oy : 0;
+  a.yl_m = c->lat == 2 ? 2 : 1; a.yl_ox = c->lat == 2 ? c->lat_ox : 0; a.yl_oy = c->lat == 2 ? c->lat_oy : 0;
+  a.xl_m = a.xl_mz = 1;
+  if (c->lat == 3) {  // x on the lattice (2x + ox, 2y + oy, mz*z + oz): Xi, Yi, Zi are the lattice's extents
+    a.xl_m = 2; a.xl_ox = c->lat_ox; a.xl_oy = c->lat_oy;
+    a.xl_mz = c->lat_mz > 1 ? c->lat_mz : 1; a.xl_oz = c->lat_oz;
+  }
   a.tri_base = tri_base; a.tri_step = tri_step;
   a.part_stride = part_stride; a.S_forced = n_parts; a.plan_only = plan ? 1 : 0;
   hipStream_t st = as_stream(stream);

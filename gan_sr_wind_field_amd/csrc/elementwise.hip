@@ -221,6 +221,26 @@ __global__ void strided_parity_filters_kernel(const float* __restrict__ w, float
   }
 }
 
+// Parity form of the FILTER gradient of a stride-(2,2,sz) (4,4,3) conv, padding 1: tap (kx, ky, kz) = (2i + a, 2j + b, .)
+// only meets input voxels of one parity, so the gradient of the taps of class (a, b, zc) is a stride-1 (2,2,KZp)
+// filter gradient over the input's sub-lattice (1 - a, 1 - b[, z class]).  This kernel moves the class gradients
+// dwp (4, n = Cout*Cin, 2, 2, KZp) to their taps of the master gradient dw (n, 4, 4, 3): every master element is
+// written by exactly one class.  sz = 1: kz = kk;  sz = 2: zc = 0 -> kz = 1, zc = 1 -> kz = 2 kk.
+__global__ void strided_parity_unfold_kernel(const float* __restrict__ dwp, float* __restrict__ dw, long n, int sz, int zc) {
+  const int KZp = sz == 1 ? 3 : (zc == 0 ? 1 : 2);
+  const long total = 4 * n * 4 * KZp;
+  for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const int kk = (int)(idx % KZp);
+    long q = idx / KZp;
+    const int j = (int)(q & 1), i = (int)((q >> 1) & 1);
+    q >>= 2;
+    const long f = q % n;
+    const int ph = (int)(q / n), a = ph >> 1, b = ph & 1;
+    const int kz = sz == 1 ? kk : (zc == 0 ? 1 : 2 * kk);
+    dw[(f * 16 + (2 * i + a) * 4 + 2 * j + b) * 3 + kz] = dwp[idx];
+  }
+}
+
 __global__ void subpixel_fold_kernel(const float* __restrict__ w, float* __restrict__ wp, long n, int KZ) {
   const long per = (long)4 * KZ;            // elements of one parity filter (2, 2, KZ)
   const long total = 4 * n * per;
@@ -838,6 +858,15 @@ extern "C" int wsr_strided_parity_filters(const float* w, float* out, int32_t Co
   const int KZp = sz == 1 ? 3 : (zc == 0 ? 1 : 2);
   hipLaunchKernelGGL(strided_parity_filters_kernel, dim3(ew_grid(16l * Cin * Cout * KZp)), dim3(EW_BLOCK), 0,
                      as_stream(stream), w, out, Cout, Cin, sz, zc);
+  WSR_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int wsr_strided_parity_unfold(const float* dwp, float* dw, int64_t n, int32_t sz, int32_t zc, void* stream) {
+  if (!dwp || !dw || n <= 0 || (sz != 1 && sz != 2) || zc < 0 || zc >= sz) return WSR_EINVAL;
+  const int KZp = sz == 1 ? 3 : (zc == 0 ? 1 : 2);
+  hipLaunchKernelGGL(strided_parity_unfold_kernel, dim3(ew_grid(16 * n * KZp)), dim3(EW_BLOCK), 0, as_stream(stream), dwp,
+                     dw, (long)n, sz, zc);
   WSR_LAUNCH_CHECK();
   return 0;
 }

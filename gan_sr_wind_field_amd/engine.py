@@ -48,6 +48,9 @@ DETERMINISTIC = __import__("os").environ.get("WSR_DETERMINISTIC", "1") != "0"
 #: input gradients of the discriminator's stride-(2,2,s) 4x4x3 convs as parity convs over dy on the tile kernels
 #: (WSR_STRIDED_DGRAD=0: generic implicit-GEMM kernel)
 STRIDED_DGRAD = __import__("os").environ.get("WSR_STRIDED_DGRAD", "1") != "0"
+#: ... and their filter gradients: four (eight) stride-1 2x2xKZ' gradients over parity sub-lattices of the input on the
+#: tile kernel (WSR_STRIDED_WGRAD=0: generic per-tap kernel, which re-reads x and dy once per tap)
+STRIDED_WGRAD = __import__("os").environ.get("WSR_STRIDED_WGRAD", "1") != "0"
 #: run the up-sampling convs (nearest x(2,2,1) + 3x3x3) in their sub-pixel form: four 2x2x3 parity convs on the
 #: un-sampled input, 4/9 of the multiply-adds (WSR_SUBPIXEL=0: gather through the up-sampling, 27 taps)
 SUBPIXEL = __import__("os").environ.get("WSR_SUBPIXEL", "1") != "0"
@@ -1188,6 +1191,7 @@ class DiscriminatorProgram(ProgramBase):
         # filters are tap selections of the master filter (wsr_strided_parity_filters), twins like the generator's.
         self.dparity: Dict[int, list] = {}
         self._dparity_stamp: Dict[int, object] = {}
+        self._dparity_grads: Dict[tuple, list] = {}  # class gradients of the parity form of the filter gradients
         for li, l in enumerate(self.layers):
             s = l.conv
             if li > 0 and s.kernel == (4, 4, 3) and s.pad == (1, 1, 1) and s.stride[:2] == (2, 2) and s.stride[2] in (1, 2) \
@@ -1204,6 +1208,53 @@ class DiscriminatorProgram(ProgramBase):
 
     def strided_dgrad_active(self, li: int) -> bool:
         return STRIDED_DGRAD and li in self.dparity and self.use_tile and self.dt == torch.bfloat16
+
+    def strided_wgrad_active(self, li: int) -> bool:
+        return STRIDED_WGRAD and li in self.dparity and self.use_tile and self.dt == torch.bfloat16 and DETERMINISTIC
+
+    def strided_wgrad(self, li: int, inp: Tensor, gy: Tensor, flat: Tensor, space: "GradSpace") -> None:
+        """filter gradient of down-sampling conv ``li`` (reference torch_blocks.py:372-521: kernel (4,4,3), stride
+        (2,2,1|2), padding 1) in parity form: tap (2i + a, 2j + b, .) only meets input voxels of one parity, so the
+        taps of class (a, b[, z class]) are a stride-1 2x2xKZ' filter gradient over a sub-lattice of ``inp`` - on the
+        LDS-tile kernel (x and dy fetched once per tile) instead of the generic per-tap kernel (once per tap: 10-23x
+        the algorithmic traffic).  The class gradients land in twins of the master gradient and are moved to their
+        taps by ``wsr_strided_parity_unfold``."""
+        s = self.layers[li].conv
+        sz = s.stride[2]
+        B, oxyz = gy.shape[0], tuple(gy.shape[1:4])
+        cin_p = self.cp(s.cin)
+        key = ("dwpar", li)
+        tw = self._dparity_grads.get(key)
+        if tw is None or tw[0][0].device != inp.device:
+            tw = [torch.empty((4, s.cout, s.cin, 2, 2, 3 if sz == 1 else (1 if zc == 0 else 2)), dtype=torch.float32,
+                              device=inp.device) for zc in range(sz)]
+            self._dparity_grads[key] = tw
+        runs = []
+        for zc in range(sz):
+            kzp = 3 if sz == 1 else (1 if zc == 0 else 2)
+            pz, mz, oz = (1, 1, 0) if sz == 1 else ((0, 2, 0) if zc == 0 else (1, 2, 1))
+            for ph in range(4):
+                a_, b_ = ph >> 1, ph & 1
+                g = ConvGeom(s.cin, s.cout, (2, 2, kzp), (1, 1, 1), (1 - a_, 1 - b_, pz))
+                d = ops.make_desc(g, self.dt, B, oxyz, inp.shape[-1], 0, gy.shape[-1], 0, cin=cin_p,
+                                  lat=(1 - a_, 1 - b_, 0, mz, oz, True))
+                n = self._wgrad_nparts(("wstr", s.name, zc, ph, B) + oxyz, d)
+                parts = self._arena_take(n * s.cout * g.taps * cin_p, inp.device).view(n, s.cout, g.taps, cin_p)
+                runs.append(lambda d=d, parts=parts, n=n: ops.conv_wgrad_parts(d, inp, gy, parts, n))
+                self._pending_unpack.append((parts[0], tw[zc][ph], 1.0, n, parts[0].numel()))
+
+        def run():
+            for r in runs:
+                r()
+
+        if self.launch_probe is not None:
+            self.launch_probe("wgrad:" + s.name, run)
+        else:
+            run()
+        self.flush_unpack()
+        dst = space.view(flat, s.weight)
+        for zc in range(sz):
+            ops.strided_parity_unfold(tw[zc], dst, sz, zc)
 
     def conv_sites(self) -> Sequence[ConvSite]:
         sites = list(self.all_sites)
@@ -1427,8 +1478,13 @@ class DiscriminatorProgram(ProgramBase):
                         sp.view(flat, bn.weight).copy_(sums[C_:])
                     ops.bn_bwd_apply(g, y_o, gy, mean, invstd, bn.weight.detach(), None, 0.0)
             inp = r["inp"][lo:]
+            lattice_ok = (li in self.dparity and tuple(inp.shape[1:3]) == (2 * gy.shape[1], 2 * gy.shape[2])
+                          and inp.shape[3] == s.stride[2] * gy.shape[3] and inp.shape[-1] == self.cp(s.cin))
             if need_dw:
-                self.wgrad(s, inp, 0, gy, 0, flat, sp, scratch)
+                if lattice_ok and self.strided_wgrad_active(li):
+                    self.strided_wgrad(li, inp, gy, flat, sp)
+                else:
+                    self.wgrad(s, inp, 0, gy, 0, flat, sp, scratch)
                 if self.grad_ready_hook is not None:
                     self.flush_unpack()
                     hi = sp.offsets[id(s.weight)][0] + (s.weight.numel() + 63) // 64 * 64
@@ -1436,8 +1492,7 @@ class DiscriminatorProgram(ProgramBase):
                     done = hi
             if li > 0:
                 gin = self._empty(inp.shape, g)
-                if self.strided_dgrad_active(li) and tuple(inp.shape[1:3]) == (2 * gy.shape[1], 2 * gy.shape[2]) \
-                        and inp.shape[3] == s.stride[2] * gy.shape[3] and inp.shape[-1] == self.cp(s.cin):
+                if self.strided_dgrad_active(li) and lattice_ok:
                     self.strided_dgrad(li, gy, gin)
                 else:
                     self.dgrad(s, gy, 0, gin, 0, tuple(inp.shape[1:4]))

@@ -116,6 +116,8 @@ def make_desc(g: ConvGeom, dt: torch.dtype, B: int, in_xyz, in_ctot: int, in_off
         d.lat, d.lat_ox, d.lat_oy, d.lat_phases = 2, lat[0], lat[1], lat[2]
         if len(lat) > 3:  # (ox, oy, phases, mz, oz): z lattice of the output as well
             d.lat_mz, d.lat_oz = lat[3], lat[4]
+        if len(lat) > 5 and lat[5]:  # (..., True): the INPUT sits on the lattice (filter gradients of strided convs)
+            d.lat = 3
     return d
 
 
@@ -497,6 +499,19 @@ def strided_parity_filters(w: Tensor, out: Tensor, sz: int, zc: int) -> Tensor:
         raise ValueError("strided_parity_filters: fp32 (Cout, Cin, 4, 4, 3) -> (4, Cin, Cout, 2, 2, KZp)")
     check(_lib.lib().wsr_strided_parity_filters(_p(w), _p(out), cout, cin, sz, zc, _stream()), "strided_parity_filters")
     return out
+
+
+def strided_parity_unfold(dwp: Tensor, dw: Tensor, sz: int, zc: int) -> Tensor:
+    """class gradients (4, Cout, Cin, 2, 2, KZp) of the parity form of a stride-(2, 2, sz) 4x4x3 conv's filter gradient
+    -> their taps of the master gradient (Cout, Cin, 4, 4, 3) (``wsr_strided_parity_unfold``)"""
+    _need_cuda(dwp, dw)
+    cout, cin = dw.shape[:2]
+    kzp = 3 if sz == 1 else (1 if zc == 0 else 2)
+    if tuple(dw.shape[2:]) != (4, 4, 3) or tuple(dwp.shape) != (4, cout, cin, 2, 2, kzp) or \
+            not (dw.is_contiguous() and dwp.is_contiguous()) or dw.dtype != torch.float32 or dwp.dtype != torch.float32:
+        raise ValueError("strided_parity_unfold: fp32 (4, Cout, Cin, 2, 2, KZp) -> (Cout, Cin, 4, 4, 3)")
+    check(_lib.lib().wsr_strided_parity_unfold(_p(dwp), _p(dw), cout * cin, sz, zc, _stream()), "strided_parity_unfold")
+    return dw
 
 
 def subpixel_fold(w: Tensor, wp: Tensor) -> Tensor:

@@ -65,7 +65,12 @@ typedef struct wsr_conv {
    * (torch_blocks.py:372-521) as forward convs over dy: input voxel (2m + a, 2n + b, s*l + c) only meets the filter
    * taps of matching parity, so each parity class is a 2x2xKZ' conv on dy that writes its own lattice of dx (filters
    * from wsr_strided_parity_filters).  lat_mz = 2 puts the output on the z lattice lat_mz*z + lat_oz as well
-   * (0 / 1: z is not strided); with lat set the conv is same-size along z too (Zo = Zi, low pad pz).     */
+   * (0 / 1: z is not strided); with lat set the conv is same-size along z too (Zo = Zi, low pad pz).
+   * lat = 3 (filter-gradient entry points only) is the mirror image for the FILTER gradient of those down-sampling
+   * convs: filter tap (2i + a, 2j + b, .) only meets input voxels of one parity, so the gradient of the taps of a
+   * class is a stride-1 2x2xKZ' filter gradient in which the INPUT x is read on the lattice (2x + lat_ox,
+   * 2y + lat_oy, lat_mz*z + lat_oz) of the stored tensor (Xi, Yi, Zi = the lattice's extents = Xo, Yo, Zo) and dy
+   * is dense; wsr_strided_parity_unfold moves the class gradients to their taps of the master gradient.     */
   int32_t lat, lat_ox, lat_oy, lat_phases;
   int32_t lat_mz, lat_oz;
 } wsr_conv_t;
@@ -265,6 +270,12 @@ int wsr_upsample2_bwd(const void* dy, void* dx, int32_t B, int32_t Xi, int32_t Y
  * Rows are the conv's INPUT channels: the result is the filter of a forward conv over dy (wsr_conv_t.lat).   */
 int wsr_strided_parity_filters(const float* w, float* out, int32_t Cout, int32_t Cin, int32_t sz, int32_t zc,
                                void* stream);
+/* Filter gradient of such a conv in parity form (wsr_conv_t.lat = 3): class (a, b) of the taps (2i + a, 2j + b) is a
+ * (2,2,KZp) stride-1 filter gradient over the input sub-lattice (1 - a, 1 - b[, z class]) with low pads (1 - a, 1 - b);
+ * sz = 1: KZp = 3, kz = kk, pad 1;  sz = 2: zc = 0: KZp = 1, kz = 1, z lattice offset 0, pad 0;  zc = 1: KZp = 2,
+ * kz = 2 kk, z lattice offset 1, pad 1.  dwp (4, n = Cout*Cin, 2, 2, KZp) fp32, class (a, b) at index 2a + b ->
+ * dw[f][2i + a][2j + b][kz] of the master gradient (n, 4, 4, 3); every element is written by exactly one class.   */
+int wsr_strided_parity_unfold(const float* dwp, float* dw, int64_t n, int32_t sz, int32_t zc, void* stream);
 int wsr_subpixel_fold(const float* w, float* wp, int64_t n, int32_t KZ, void* stream);
 int wsr_subpixel_unfold(const float* dwp, float* dw, int64_t n, int32_t KZ, void* stream);
 /* planar fp32 (B,C,X,Y,Z) <-> NDHWC `dtype` window; c_fill >= C channels are

@@ -962,3 +962,46 @@ def test_conv_slide_input_gradient_vs_cpu(hip, name, k, xyz, B, ctot, off, drop)
     assert rel_l2(got, ref) < 4e-3, name  # bf16 rounding of the result
     if off:
         assert bool((dxb[..., :off] == 7.0).all()), name
+
+
+@pytest.mark.parametrize("sz,cin,cout,xyz,B", [(1, 32, 32, (16, 16, 8), 2), (2, 64, 128, (8, 16, 12), 1),
+                                                (2, 32, 64, (12, 8, 6), 1)])
+def test_strided_filter_gradient_in_parity_form(hip, sz, cin, cout, xyz, B):
+    """filter gradient of the discriminator's down-sampling convs (reference torch_blocks.py:372-521: kernel (4,4,3),
+    stride (2,2,1|2), padding 1) as stride-1 2x2xKZ' gradients over parity sub-lattices of the input
+    (``wsr_conv_t.lat = 3`` + ``wsr_strided_parity_unfold``) against fp32 CPU autograd of the same bf16-rounded
+    operands; two runs are bit-identical (ordered reduction of the split copies)."""
+    o = ops()
+    dt = torch.bfloat16
+    gen = torch.Generator().manual_seed(3 * cin + cout + sz)
+    x = torch.randn((B, cin) + tuple(xyz), generator=gen).bfloat16().float()
+    w = torch.zeros((cout, cin, 4, 4, 3), requires_grad=True)
+    y = F.conv3d(x, w, None, (2, 2, sz), 1)
+    gy = torch.randn(y.shape, generator=gen).bfloat16().float()
+    y.backward(gy)
+    oxyz = tuple(y.shape[2:])
+    assert (2 * oxyz[0], 2 * oxyz[1], sz * oxyz[2]) == tuple(xyz)
+    xb, gb = to_ndhwc(x, cin, 0, dt), to_ndhwc(gy, cout, 0, dt)
+    outs = []
+    for _ in range(2):
+        dw = torch.full((cout, cin, 4, 4, 3), float("nan"), dtype=torch.float32, device=DEV)
+        for zc in range(sz):
+            kzp = 3 if sz == 1 else (1 if zc == 0 else 2)
+            pz, mz, oz = (1, 1, 0) if sz == 1 else ((0, 2, 0) if zc == 0 else (1, 2, 1))
+            tw = torch.full((4, cout, cin, 2, 2, kzp), float("nan"), dtype=torch.float32, device=DEV)
+            jobs, keep = [], []
+            for ph in range(4):
+                a_, b_ = ph >> 1, ph & 1
+                g = o.ConvGeom(cin, cout, (2, 2, kzp), (1, 1, 1), (1 - a_, 1 - b_, pz))
+                d = o.make_desc(g, dt, B, oxyz, cin, 0, cout, 0, lat=(1 - a_, 1 - b_, 0, mz, oz, True))
+                n = o.conv_wgrad_nparts(d)
+                parts = torch.full((n, cout, g.taps, cin), float("nan"), dtype=torch.float32, device=DEV)
+                o.conv_wgrad_parts(d, xb, gb, parts, n)
+                jobs.append((parts[0], tw[ph], 1.0, n, parts[0].numel()))
+                keep.append(parts)
+            o.unpack_wgrad_reduce_multi(o.unpack_job_table(jobs))
+            o.strided_parity_unfold(tw, dw, sz, zc)
+        outs.append(dw.cpu())
+    assert torch.isfinite(outs[0]).all()
+    assert rel_l2(outs[0], w.grad) < 2e-5  # fp32 accumulation of exactly representable products
+    assert torch.equal(outs[0], outs[1])

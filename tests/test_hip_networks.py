@@ -288,7 +288,7 @@ def test_discriminator_bf16_vs_oracle(hip):
             assert float(cos) > 0.97, (k, float(cos))
 
 
-def _gpu_gan(dtype="fp32", use_noise=False, dropout=0.0):
+def _gpu_gan(dtype="fp32", use_noise=False, dropout=0.0, feature_cost=False):
     import os
     from gan_sr_wind_field_amd.config.config import Config
     from gan_sr_wind_field_amd.GAN_models.wind_field_GAN_3D import wind_field_GAN_3D
@@ -309,6 +309,9 @@ def _gpu_gan(dtype="fp32", use_noise=False, dropout=0.0):
     cfg.training.use_instance_noise = use_noise
     cfg.training.niter = 150000
     cfg.training.d_g_train_period = 2
+    if feature_cost:
+        cfg.gan_config.use_D_feature_extractor_cost = True
+        cfg.training.feature_D_update_period = 1
     torch.manual_seed(2001)
     return wind_field_GAN_3D(cfg), cfg
 
@@ -346,6 +349,43 @@ def test_gan_train_step_trace_fp32_vs_reference(golden, hip):
             assert rel_l2(gan.G.state_dict()[k[8:]], T(g[k])) < 2e-3, k
         if k.startswith("final_D."):
             assert rel_l2(gan.D.state_dict()[k[8:]], T(g[k])) < 2e-3, k
+
+
+def test_discriminator_feature_extractor_loss(hip):
+    """``use_D_feature_extractor_cost`` (reference GAN_models/wind_field_GAN_3D.py:372-375, 577-583: a frozen deep copy
+    of D.features, MSE between its features of HR and of the generated field): the loss entry against the oracle's
+    feature pyramid on the same weights, and its gradient reaching the generator."""
+    import copy
+    import torch.nn.functional as F
+
+    outs = {}
+    for fc in (False, True):
+        gan, cfg = _gpu_gan(feature_cost=fc)
+        gs = onets.GSpec(in_channels=4, nf=16, n_rrdb=1, gc=8, tf=4, hr_kern=5, upscale=4)
+        ds = onets.DSpec(bf=4, nz=4, enable_slicing=True)
+        gan.G.load_state_dict(onets.deterministic_state(onets.g_param_shapes(gs), seed=41, scale=0.5))
+        gan.D.load_state_dict(onets.deterministic_state(onets.d_param_shapes(ds), seed=43, scale=1.0))
+        LR, HR, Z, x, y = (t.to(DEV) for t in ogan.synthetic_batch(2, 16, 4, 4, seed=2001))
+        gan.feed_xy_niter(x, y, torch.tensor(cfg.training.niter, device=DEV), 1, 2)
+        gan.G.train()
+        with torch.no_grad():
+            fake = gan.G(LR, Z).cpu()
+        mode = gan.D.features.training  # the copy inherits the mode D.features is in when it is taken
+        sd = {k: v.detach().clone().cpu() for k, v in gan.D.state_dict().items()}
+        f_hr = onets.discriminator_features(copy.deepcopy(sd), HR.cpu(), ds, mode)
+        f_sr = onets.discriminator_features(copy.deepcopy(sd), fake, ds, mode)
+        want = float(F.mse_loss(f_sr, f_hr)) * cfg.training.feature_D_loss_weight
+        gan.optimize_parameters(LR, HR, Z, 0)  # it = 0: a generator iteration
+        L = {k: float(v) for k, v in gan.get_G_train_loss_dict_ref().items()}
+        outs[fc] = (L, gan.G.state_dict()["hr_convs.2.weight"].clone())
+        if fc:
+            assert want > 0 and abs(L["feature_D"] - want) <= 2e-3 * want, (L["feature_D"], want)
+            assert gan.feature_extractor is not None and not any(p.requires_grad for p in gan.feature_extractor.parameters())
+        else:
+            assert L["feature_D"] == 0.0
+    (L0, w0), (L1, w1) = outs[False], outs[True]
+    assert abs((L1["total"] - L1["feature_D"]) - L0["total"]) <= 1e-4 * abs(L0["total"])  # the other terms are unchanged
+    assert not torch.equal(w0, w1)  # the feature loss reached the generator's update
 
 
 def test_gan_train_step_bf16_noise_dropout_runs(hip):
