@@ -85,6 +85,31 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 
 static inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 
+// ---- tuning switches ------------------------------------------------------------------------------------
+// Environment switches (WSR_*) are tuning / A-B aids.  Reading them with getenv on every launch cost 3-7 scans of
+// the environment per launch (~2 000 launches per step: milliseconds of host time on the launch-bound real-data
+// shapes).  Each call site now caches its value; wsr_reload_env() (C ABI) bumps the generation so that a process
+// that changes the environment at run time (the tests do) sees the new values.
+extern int g_wsr_env_gen;  // elementwise.hip
+#include <climits>
+#include <cstdlib>
+struct WsrEnvCache {
+  int gen = -1;
+  int val = INT_MIN;  // INT_MIN: variable not set
+};
+static inline int wsr_env_lookup(WsrEnvCache& c, const char* name) {
+  if (c.gen != g_wsr_env_gen) {
+    const char* e = getenv(name);
+    c.val = e ? atoi(e) : INT_MIN;
+    c.gen = g_wsr_env_gen;
+  }
+  return c.val;
+}
+// value of an integer switch, or INT_MIN when it is not set
+#define WSR_ENV_RAW(name) ([]() -> int { static WsrEnvCache c_; return wsr_env_lookup(c_, name); }())
+#define WSR_ENV_SET(name) (WSR_ENV_RAW(name) != INT_MIN)
+#define WSR_ENV_INT(name, dflt) (WSR_ENV_SET(name) ? WSR_ENV_RAW(name) : (dflt))
+
 static inline int conv_geom_ok(const wsr_conv_t* c) {
   if (!c) return 0;
   if (c->B <= 0 || c->Xi <= 0 || c->Yi <= 0 || c->Zi <= 0 || c->Xo <= 0 || c->Yo <= 0 || c->Zo <= 0) return 0;

@@ -182,7 +182,7 @@ int launch_c1(const C1Args& a0, hipStream_t st) {
     attr_done = true;
   }
   int grid = (a.nstrips + WAVES / NH - 1) / (WAVES / NH);
-  const int cap = getenv("WSR_C1_GRID") ? atoi(getenv("WSR_C1_GRID")) : 256;  // one workgroup per CU measured best (tuning aid)
+  const int cap = WSR_ENV_INT("WSR_C1_GRID", 256);  // one workgroup per CU measured best (tuning aid)
   if (grid > cap) grid = cap;  // the filter is staged once per workgroup
   hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(WAVES * 64), lds, st, a);
   WSR_LAUNCH_CHECK();
@@ -233,7 +233,7 @@ int wsr_conv1x1_bf16(const unsigned short* in, int in_ctot, int in_off, int red,
   if (a.bias && ((size_t)a.bias & 15)) return WSR_EUNSUPPORTED;
   if (!mask) {
     if (nt == 8 && ks == 8) {  // 256 -> 128 (LFF forward): 16-voxel strips, next strip prefetched (-18 % vs <8,2,8>)
-      if (getenv("WSR_C1_NOPF")) return launch_c1<8, 2, 8, false>(a, st);
+      if (WSR_ENV_SET("WSR_C1_NOPF")) return launch_c1<8, 2, 8, false>(a, st);
       return launch_c1<8, 1, 8, false, true>(a, st);
     }
     if (nt == 16 && ks == 4) return launch_c1<16, 1, 4, false>(a, st);  // 128 -> 256

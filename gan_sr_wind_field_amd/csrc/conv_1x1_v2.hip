@@ -204,7 +204,7 @@ int launch_c2(C2Args& a, hipStream_t st) {
     attr_done = true;
   }
   int grid = (a.nstrips + 7) / 8;
-  const int cap = getenv("WSR_C1_GRID") ? atoi(getenv("WSR_C1_GRID")) : 512;  // two resident workgroups per CU (tuning aid)
+  const int cap = WSR_ENV_INT("WSR_C1_GRID", 512);  // two resident workgroups per CU (tuning aid)
   if (grid > cap) grid = cap;
   hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), lds, st, a);
   WSR_LAUNCH_CHECK();
@@ -219,7 +219,7 @@ int wsr_conv1x1_v2_bf16(const unsigned short* in, int in_ctot, int in_off, int r
                         const unsigned short* res, int res_ctot, int res_off, int res_c1, float alpha, float beta, int act,
                         float slope, const wsr_lrelu_mask_t* mask, const unsigned short* res2, int res2_ctot, int res2_off,
                         float beta2, hipStream_t st) {
-  if (getenv("WSR_C1_V1")) return WSR_EUNSUPPORTED;  // tuning switch: the four-wave form
+  if (WSR_ENV_SET("WSR_C1_V1")) return WSR_EUNSUPPORTED;  // tuning switch: the four-wave form
   if (!((red == 256 && n_out == 128) || (red == 128 && n_out == 256))) return WSR_EUNSUPPORTED;
   // 16-byte accesses on every operand: channel windows on 8-channel boundaries
   if (in_ctot % 8 || in_off % 8 || out_ctot % 8 || out_off % 8) return WSR_EUNSUPPORTED;
@@ -242,7 +242,7 @@ int wsr_conv1x1_v2_bf16(const unsigned short* in, int in_ctot, int in_off, int r
     a.mask_slope = mask->slope;
   }
   // residual == leading channels of the input window?  (res_c1 channels of it; at most the window itself)
-  const bool rx = res && res == in && res_ctot == in_ctot && res_off == in_off && !getenv("WSR_C1_NORX") &&
+  const bool rx = res && res == in && res_ctot == in_ctot && res_off == in_off && !WSR_ENV_SET("WSR_C1_NORX") &&
                   (res_c1 >= n_out ? n_out <= red : res_c1 <= red);
   if (red == 256) {
     if (mask) return WSR_EUNSUPPORTED;

@@ -43,14 +43,14 @@ namespace {
 int dispatch_ct(CtArgs& a, int tpk, hipStream_t st) {
   const int N = a.Cout;
   if ((a.sx | a.sy | a.sz) != 1) return wsr_ct_run_strided(a, tpk, st);
-  if (const char* w4 = getenv("WSR_CT_W4")) {  // tuning switch: four-wave workgroups
+  if (WSR_ENV_SET("WSR_CT_W4")) {  // tuning switch: four-wave workgroups
     if ((long)a.B * a.Xo * a.Yo * a.Zo >= 128L * 512) {
-      const int rc = wsr_ct_run_w4(a, tpk, atoi(w4), st);
+      const int rc = wsr_ct_run_w4(a, tpk, WSR_ENV_RAW("WSR_CT_W4"), st);
       if (rc != WSR_EUNSUPPORTED) return rc;
     }
   }
   // small volumes (< 128 tiles of 512 voxels): 128-voxel tiles where an instantiation exists
-  if ((long)a.B * a.Xo * a.Yo * a.Zo < 128L * 512 && !getenv("WSR_CT_NOSMALL")) {
+  if ((long)a.B * a.Xo * a.Yo * a.Zo < 128L * 512 && !WSR_ENV_SET("WSR_CT_NOSMALL")) {
     const int rc = wsr_ct_run_small(a, tpk, st);
     if (rc != WSR_EUNSUPPORTED) return rc;
   }
@@ -60,7 +60,7 @@ int dispatch_ct(CtArgs& a, int tpk, hipStream_t st) {
   // wide tiles: the 512-voxel N = 144 instantiation is kept for the 5x5x5 144 -> 144 conv it is tuned and
   // profiled for)
   if (N == 144 && (long)a.nchunks * a.KX * a.KY * a.KZ >= 256) return wsr_ct_run_n144(a, tpk, st);
-  if (N > 64 && N <= 128 && !getenv("WSR_CT_NO_N128")) {  // (the env switch is a tuning aid)
+  if (N > 64 && N <= 128 && !WSR_ENV_SET("WSR_CT_NO_N128")) {  // (the env switch is a tuning aid)
     const int rc = wsr_ct_run_n128(a, tpk, st);
     if (rc != WSR_EUNSUPPORTED) return rc;
   }
@@ -287,7 +287,7 @@ extern "C" int wsr_conv3d_fwd_tile(const wsr_conv_t* c, const void* x, const voi
                                    const wsr_epilogue_t* ep, void* stream) {
   if (!conv_geom_ok(c) || !x || !wfrag || !y) return WSR_EINVAL;
   if (c->dtype != WSR_BF16 || c->sx > 2 || c->sy > 2 || c->sz > 2 || c->lat == 3) return WSR_EUNSUPPORTED;
-  if ((c->sx | c->sy | c->sz) != 1 && (c->upsample_xy || getenv("WSR_CT_NOSTRIDE"))) return WSR_EUNSUPPORTED;
+  if ((c->sx | c->sy | c->sz) != 1 && (c->upsample_xy || WSR_ENV_SET("WSR_CT_NOSTRIDE"))) return WSR_EUNSUPPORTED;
   CtArgs a{};
   a.sx = c->sx; a.sy = c->sy; a.sz = c->sz;
   a.in = (const unsigned short*)x;
@@ -335,7 +335,7 @@ extern "C" int wsr_conv3d_fwd_tile(const wsr_conv_t* c, const void* x, const voi
   }
   if (ep && ep->res2) return WSR_EUNSUPPORTED;  // only the streaming kernel takes a second residual
   // thin z-tapless conv with a planar fp32 result (the z-folded last conv): sliding-window kernel
-  static const bool no_slide = getenv("WSR_NO_SLIDE") != nullptr;  // tuning / A-B switch, read once
+  const bool no_slide = WSR_ENV_SET("WSR_NO_SLIDE");  // tuning / A-B switch
   if (!no_slide && c->KZ == 1 && c->Cout <= 16 && a.out_planar && !a.chan_scale && !a.res && a.act == 0 && !a.ups &&
       !c->lat && (c->sx | c->sy | c->sz) == 1 && c->pz == 0 && a.alpha == 1.f && c->Xo == c->Xi && c->Yo == c->Yi &&
       zero_page()) {
@@ -393,7 +393,7 @@ extern "C" int wsr_conv3d_dgrad_tile(const wsr_conv_t* c, const void* dy, const 
     if (rc != WSR_EUNSUPPORTED) return rc;
   }
   // z-tapless conv with a thin output side and the mask of the layer below (the z-folded last conv): sliding window
-  static const bool no_slide = getenv("WSR_NO_SLIDE") != nullptr;  // tuning / A-B switch, read once
+  const bool no_slide = WSR_ENV_SET("WSR_NO_SLIDE");  // tuning / A-B switch
   if (!no_slide && mask && c->KZ == 1 && c->Cout <= 16 && !accumulate && !dx_planar && !c->lat && ux == 1 && c->pz == 0 &&
       c->Xo == c->Xi && c->Yo == c->Yi && c->Zo == c->Zi && zero_page()) {
     const int rc = wsr_conv_slide_dgrad(a.in, a.in_ctot, a.in_off, c->Cout, a.wf, (unsigned short*)a.out, a.out_ctot,

@@ -628,12 +628,12 @@ int launch_ct(CtArgs& a, hipStream_t st) {
   int ts_max = 0;
   // (one chunk: the second activation buffer would never be filled - the LDS it frees lets a second workgroup share
   // the CU, whose prologue and epilogue then overlap this one's main loop: terrain convs, 3-channel inputs)
-  const int xb_first = getenv("WSR_CT_XBUFS") ? atoi(getenv("WSR_CT_XBUFS")) : ((a.nchunks == 1 || (NTW == 1 && getenv("WSR_CT_N16_ONEBUF"))) ? 1 : 2);  // env: tuning aid
+  const int xb_first = WSR_ENV_INT("WSR_CT_XBUFS", (a.nchunks == 1 || (NTW == 1 && WSR_ENV_SET("WSR_CT_N16_ONEBUF"))) ? 1 : 2);  // env: tuning aid
   for (a.xbufs = xb_first; a.xbufs >= 1; --a.xbufs) {
     a.off_ws = a.off_xs + a.xbufs * (VM ? 1 : PL) * a.P;
     const int avail = 160 * 1024 - a.off_ws;
     ts_max = avail / (2 * NTW * 1024);
-    const int cap_kb = getenv("WSR_WSTAGE_KB") ? atoi(getenv("WSR_WSTAGE_KB")) : 48;  // tuning aid
+    const int cap_kb = WSR_ENV_INT("WSR_WSTAGE_KB", 48);  // tuning aid
     const int cap = cap_kb / NTW > 0 ? cap_kb / NTW : 1;  // <= 48 KB per weight stage (measured: up-convs +7 %, others flat)
     if (ts_max > cap) ts_max = cap;
     // (weight stages shorter than 3 K-steps cost more in barriers than the activation prefetch saves)
@@ -674,13 +674,13 @@ int launch_ct(CtArgs& a, hipStream_t st) {
     attr_done = true;
   }
 #ifdef WSR_CT_STAMPS
-  a.ablate = getenv("WSR_CT_ABL") ? atoi(getenv("WSR_CT_ABL")) : 0;
+  a.ablate = WSR_ENV_INT("WSR_CT_ABL", 0);
   a.stamps = getenv("WSR_CT_STAMPS_PTR") ? (unsigned long long*)strtoull(getenv("WSR_CT_STAMPS_PTR"), nullptr, 0) : nullptr;
 #endif
   // static priority for the younger half of the workgroup: measured again on the final kernels - +1.2 % on the
   // 144-wide 5x5x5 tile, but -1.5 ... -4 % on every other instantiation (128-wide: 109.7 -> 106.6 us, narrow:
   // 24.0 -> 23.5 us, 160..224-wide: 60.0 -> 58.2 us) since the operand requests moved ahead of the MFMAs
-  a.prio = getenv("WSR_CT_PRIO") ? atoi(getenv("WSR_CT_PRIO")) : (TN == 9 ? 1 : 0);
+  a.prio = WSR_ENV_INT("WSR_CT_PRIO", TN == 9 ? 1 : 0);
   // Few workgroups and a long reduction (the deep layers of the discriminator: 16..128 workgroups walking
   // 16..32 chunks x 27..48 taps one after the other, 50-90 us at a few per cent of the chip): split the chunks over
   // ksplit times as many workgroups; the partial sums go through the caller's workspace.
@@ -688,7 +688,7 @@ int launch_ct(CtArgs& a, hipStream_t st) {
   a.part = nullptr;
   const int wg = a.ntiles * a.nphase * a.ngroups;
   if (a.ws && wg <= 128 && a.nchunks >= 4 && a.nphase == 1 && a.ol_m == 1 && a.ol_mz == 1 && !a.res && !a.mask_y && !a.chan_scale &&
-      !a.out_planar && a.act <= 1 && a.act_c1 == 0x7FFFFFFF && (a.Cout & 3) == 0 && a.vec_ok && !getenv("WSR_CT_NOSPLITK")) {
+      !a.out_planar && a.act <= 1 && a.act_c1 == 0x7FFFFFFF && (a.Cout & 3) == 0 && a.vec_ok && !WSR_ENV_SET("WSR_CT_NOSPLITK")) {
     int ks = 256 / wg;
     if (ks > a.nchunks / 2) ks = a.nchunks / 2;
     if (ks >= 2) {
@@ -714,7 +714,7 @@ static void pick_tile(CtArgs& a, int M) {
   else tz = 8;
   // no taps along z (the z-folded last conv, 5x5x1): a flat tile has no z halo and a smaller x-y one
   // (8x16x4: 1.9x its 512 voxels instead of 3x for 4x8x16) - these launches are bound by the halo re-reads
-  if (a.KZ == 1 && a.KX * a.KY > 1 && tz > 4 && !getenv("WSR_CT_NOFLAT")) tz = 4;
+  if (a.KZ == 1 && a.KX * a.KY > 1 && tz > 4 && !WSR_ENV_SET("WSR_CT_NOFLAT")) tz = 4;
   while (tz > M) tz >>= 1;
   const int rest = M / tz;
   int tx = 1, ty = 1;

@@ -16,7 +16,7 @@ static int run(CtArgs& a, hipStream_t st) {
       int rc;
       // few output tiles (the deep layers: 16x16x64 .. 4x4x32 voxels): narrower channel groups, more workgroups
       const long tiles = (long)a.B * ((a.Xo + a.TX - 1) / a.TX) * ((a.Yo + a.TY - 1) / a.TY) * ((a.Zo + a.TZ - 1) / a.TZ);
-      const bool few = !getenv("WSR_CT_STRIDED_WIDE") && tiles * ((N + 127) / 128) < 128;
+      const bool few = !WSR_ENV_SET("WSR_CT_STRIDED_WIDE") && tiles * ((N + 127) / 128) < 128;
       if (N <= 32 || (few && tiles * ((N + 63) / 64) < 128)) rc = launch_ct<8, 1, 2, 2, TPK>(a, st);
       else if (N <= 64 || few) rc = launch_ct<8, 1, 2, 4, TPK>(a, st);
       else rc = launch_ct<8, 1, 2, 8, TPK>(a, st);  // wider outputs: groups of 128 channels

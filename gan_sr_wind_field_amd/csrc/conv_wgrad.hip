@@ -252,6 +252,9 @@ int dispatch_wgrad(WgradArgs& a, hipStream_t st, int* plan, int n_parts) {
 int wsr_wgrad_tile_bf16(const wsr_conv_t* c, const void* x, const void* dy, float* dw, int tri_base, int tri_step,
                         long part_stride, int n_parts, int* plan, void* stream);  // conv_wgrad_tile.hip
 
+int wsr_wgrad_tile_f32(const wsr_conv_t* c, const void* x, const void* dy, float* dw, long part_stride, int n_parts,
+                       int* plan, void* stream);  // conv_wgrad_tile_f32.hip
+
 // shared body: accumulate (part_stride = 0), deterministic parts (part_stride > 0) or plan only (plan != nullptr)
 static int wgrad_any(const wsr_conv_t* c, const void* x, const void* dy, float* dw, int tri_base, int tri_step,
                      long part_stride, int n_parts, int* plan, void* stream) {
@@ -260,6 +263,10 @@ static int wgrad_any(const wsr_conv_t* c, const void* x, const void* dy, float* 
     if (rc != WSR_EUNSUPPORTED || tri_step > 0) return rc;
   }
   if (c->lat) return WSR_EUNSUPPORTED;  // parity convs of the sub-pixel form: tile kernels only
+  if (c->dtype == WSR_F32 && tri_step == 0) {  // stride-1 fp32 convs: LDS-tile kernel (all taps per workgroup)
+    const int rc = wsr_wgrad_tile_f32(c, x, dy, dw, part_stride, n_parts, plan, stream);
+    if (rc != WSR_EUNSUPPORTED) return rc;
+  }
   const int epp = c->dtype == WSR_BF16 ? 8 : 4;
   if (c->Cin % epp || c->in_ctot % epp || c->in_off % epp) return WSR_EUNSUPPORTED;
   if (c->out_ctot % epp || c->out_off % epp) return WSR_EUNSUPPORTED;

@@ -520,7 +520,7 @@ int launch_tile(WgtArgs& a, hipStream_t st) {
   int tz = a.Zo <= 16 ? a.Zo : ((a.Zo % 16 == 0 || a.Zo > 64) ? 16 : 8);
   // no taps along z (the z-folded last conv, 5x5x1): a flat tile has no z halo and a far smaller x-y one
   // (8x8x4: 2.25x its voxels; 2x4x16: 6x) - that launch is bound by the halo re-reads of its 144-channel input
-  if (a.KZ == 1 && a.KX * a.KY > 1 && tz > 4 && a.Zo % 4 == 0 && !getenv("WSR_CT_NOFLAT")) tz = 4;
+  if (a.KZ == 1 && a.KX * a.KY > 1 && tz > 4 && a.Zo % 4 == 0 && !WSR_ENV_SET("WSR_CT_NOFLAT")) tz = 4;
   static const int cand[][2] = {{8, 8}, {4, 8}, {4, 4}, {2, 4}, {2, 2}, {1, 2}, {1, 1}};
   int best = -1, best_nbuf = 0;
   for (int nbuf = 2; nbuf >= 2 && best < 0; --nbuf) {  // the kernel is written for two buffers
@@ -583,8 +583,8 @@ int launch_tile(WgtArgs& a, hipStream_t st) {
   if (S < 1) S = 1;
   if (S > a.ntiles) S = a.ntiles;
   a.S = S;
-  if (const char* ov = getenv("WSR_WGRAD_S")) {  // tuning aid
-    const int v = atoi(ov);
+  if (WSR_ENV_SET("WSR_WGRAD_S")) {  // tuning aid
+    const int v = WSR_ENV_RAW("WSR_WGRAD_S");
     if (v >= 1 && v <= a.ntiles) a.S = v;
   }
   if (a.plan_only) return 0;
@@ -600,9 +600,9 @@ int launch_tile(WgtArgs& a, hipStream_t st) {
   }
 #ifdef WSR_CT_STAMPS
   a.stamps = getenv("WSR_CT_STAMPS_PTR") ? (unsigned long long*)strtoull(getenv("WSR_CT_STAMPS_PTR"), nullptr, 0) : nullptr;
-  a.ablate = getenv("WSR_CT_ABL") ? atoi(getenv("WSR_CT_ABL")) : 0;
+  a.ablate = WSR_ENV_INT("WSR_CT_ABL", 0);
 #endif
-  a.prio = getenv("WSR_CT_PRIO") ? atoi(getenv("WSR_CT_PRIO")) : 0;
+  a.prio = WSR_ENV_INT("WSR_CT_PRIO", 0);
   hipLaunchKernelGGL(kern, dim3((unsigned)(combos * a.S)), dim3(WAVES * 64), lds, st, a);
   WSR_LAUNCH_CHECK();
   return 0;

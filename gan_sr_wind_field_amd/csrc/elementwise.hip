@@ -5,6 +5,13 @@
 #include "common.h"
 #include "stencil.h"
 
+int g_wsr_env_gen = 0;  // generation of the cached environment switches (common.h)
+
+extern "C" int wsr_reload_env(void) {
+  ++g_wsr_env_gen;
+  return 0;
+}
+
 namespace {
 
 constexpr int EW_BLOCK = 256;

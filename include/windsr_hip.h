@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define WSR_ABI_VERSION 3
+#define WSR_ABI_VERSION 4
 
 enum wsr_dtype { WSR_F32 = 0, WSR_BF16 = 1 };
 
@@ -100,6 +100,9 @@ typedef struct wsr_epilogue {
 
 int wsr_abi_version(void);
 const char* wsr_error_string(int code);
+/* The WSR_* environment switches (tuning / A-B aids, none needed for normal use) are cached per call site; a process
+ * that changes its environment at run time calls this to have them read again.  Always returns 0. */
+int wsr_reload_env(void);
 
 /* ---- convolution ------------------------------------------------------------
  * aten::conv3d forward of nn.Conv3d (torch_blocks.py:17,278; Generator_3D...py:105)

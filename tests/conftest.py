@@ -39,3 +39,20 @@ def hip():
     from gan_sr_wind_field_amd import _lib
 
     return _lib.lib()
+
+
+def reload_wsr_env():
+    """the C side caches its WSR_* tuning switches per call site: have them read again after changing os.environ"""
+    from gan_sr_wind_field_amd import _lib
+
+    _lib.lib().wsr_reload_env()
+
+
+@pytest.fixture(autouse=True)
+def _fresh_wsr_env():
+    """a test that changed a WSR_* switch (monkeypatch) must not leak the cached value into the next one"""
+    try:
+        reload_wsr_env()
+    except Exception:  # library not built: the tests that need it fail on their own
+        pass
+    yield

@@ -25,7 +25,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import REPO, rel_l2
+from conftest import reload_wsr_env, REPO, rel_l2
 from c1_case import LOSS_KEYS, c1_batch, c1_d_grads_fp64, c1_oracle_step, c1_specs, c1_states
 from oracle import gan as ogan
 from oracle import nets as onets
@@ -194,6 +194,7 @@ def test_c3_geometry_slab_generator_bf16(hip, monkeypatch):
     (WSR_CT_NOSMALL keeps this small volume off the 128-voxel variants), Z16 filter-gradient kernels.  Output
     and EVERY parameter gradient against the fp32 oracle, bounds from the bf16-storage emulation."""
     monkeypatch.setenv("WSR_CT_NOSMALL", "1")
+    reload_wsr_env()
     from test_hip_networks import build_G
 
     spec = onets.GSpec()

@@ -13,7 +13,7 @@ import pytest
 import torch
 import torch.nn.functional as F
 
-from conftest import rel_l2
+from conftest import reload_wsr_env, rel_l2
 from cases import CONV_CASES
 
 pytestmark = pytest.mark.gpu
@@ -681,6 +681,7 @@ def test_conv_tile_shapes_vs_cpu(hip, name, cin, cout, k, xyz, B, ups):
 ])
 def test_conv_tile_production_geometry(hip, monkeypatch, name, cin, cout, k, xyz, B, ups):
     monkeypatch.setenv("WSR_CT_NOSMALL", "1")
+    reload_wsr_env()
     _check_tile_conv(name, cin, cout, k, xyz, B, ups)
 
 

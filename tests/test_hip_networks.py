@@ -10,7 +10,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import rel_l2
+from conftest import reload_wsr_env, rel_l2
 from oracle import gan as ogan
 from oracle import nets as onets
 
@@ -663,8 +663,10 @@ def test_full_size_c3_discriminator_properties(hip, monkeypatch):
         assert a.shape == (1, 1) and torch.isfinite(a).all()
         assert torch.equal(a, D(x))
         monkeypatch.setenv("WSR_CT_NOSTRIDE", "1")  # strided convs back on the generic implicit GEMM
+        reload_wsr_env()
         b = D(x)
         monkeypatch.delenv("WSR_CT_NOSTRIDE")
+        reload_wsr_env()
         assert abs(float(a - b)) < 2e-2 * max(1.0, abs(float(a)))
     D.train()
     xg = x.clone().requires_grad_(True)
