@@ -182,6 +182,11 @@ def _validate(cfg, gan, dataloader_val, dataset_train, it, tb, status_logger, le
                                                 align_corners=True)).squeeze(0)
     imgs = {"HR": (uvw * HR[b]).cpu().numpy(), "SR": SR_i.cpu().numpy(), "BC": TL_i.cpu().numpy(),
             "LR": (uvw * LR_i[0, :3]).cpu().numpy()}
+    if cfg.use_tensorboard_logger:
+        # the reference's comparison / error figures of two slices (train.py:236-307); PNG files when no TensorBoard
+        # writer is installed
+        from .tools import valfigures
+        valfigures.log_validation_figures(imgs, it, tb=tb, out_dir=os.path.join(cfg.env.this_runs_folder, "images"))
     if tb is not None:
         tb.add_scalars("G_loss/validation", G_vals, it)
         tb.add_scalars("D_loss/", D_vals, it)

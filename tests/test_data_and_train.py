@@ -232,3 +232,34 @@ def test_cli_flags_match_reference():
         runmod.main(["--download"])
     with pytest.raises(NotImplementedError):
         runmod.main(["--param_search"])
+
+
+def test_validation_figures(tmp_path):
+    """the validation epoch's TensorBoard figures (reference train.py:236-307, :340-555): two slices x (comparison,
+    error) figure, tags as in the reference; PNG files when no writer is given"""
+    from gan_sr_wind_field_amd.tools import valfigures
+
+    if not valfigures.available():
+        pytest.skip("matplotlib not installed")
+    rng = np.random.default_rng(3)
+    hr = rng.normal(size=(3, 16, 16, 6)).astype(np.float32)
+    imgs = {"HR": hr, "SR": hr + 0.1 * rng.normal(size=hr.shape).astype(np.float32),
+            "BC": hr + 0.3 * rng.normal(size=hr.shape).astype(np.float32), "LR": hr[:, ::4, ::4]}
+
+    class Writer:
+        def __init__(self):
+            self.calls = []
+
+        def add_figure(self, tag, fig, it):
+            self.calls.append((tag, it, len(fig.axes)))
+
+    w = Writer()
+    tags = valfigures.log_validation_figures(imgs, 40, tb=w, rng=np.random.default_rng(0))
+    assert [c[0] for c in w.calls] == tags and len(tags) == 4 and all(c[1] == 40 for c in w.calls)
+    assert tags[0] == "im/40/wind_fields/u_field_z_index3" and tags[1] == "im/40/Error/u_field_z_index3"
+    assert tags[2].startswith("im/40/wind_fields/") and tags[3].startswith("im/40/Error/")
+    assert w.calls[0][2] == 5 and w.calls[1][2] == 12  # 4 panels + 1 colour bar; 6 panels + 6 colour bars
+    out = tmp_path / "images"
+    tags2 = valfigures.log_validation_figures(imgs, 41, out_dir=str(out), rng=np.random.default_rng(0))
+    assert len(tags2) == 4 and len(list(out.glob("*.png"))) == 4
+    assert valfigures.log_validation_figures(imgs, 42) == []  # nowhere to send them

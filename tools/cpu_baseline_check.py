@@ -6,7 +6,10 @@ local configuration at full width (C1: LR 16x16x10 -> HR 64x64x10, batch 1), G-i
 dropout and instance noise ON as shipped.  BASELINE.md section 4 asks for the restatement to land within +-20 % of
 the reference.
 
-    python tools/cpu_baseline_check.py [threads] > profiles/r02_cpu_baseline_check.txt
+    python tools/cpu_baseline_check.py [threads] [C1|C1b] > profiles/r03_cpu_baseline_check.txt
+
+``C1b`` is the reference's real patch size (LR 32x32x10 -> HR 128x128x10, D without slicing) - four times
+the generator work of C1 per pair; three timed pairs instead of five.
 """
 import os
 import sys
@@ -29,11 +32,13 @@ def one_pair(step, i):
 
 def main():
     threads = int(sys.argv[1]) if len(sys.argv) > 1 else (os.cpu_count() or 1)
+    shape = sys.argv[2] if len(sys.argv) > 2 else "C1"
+    n_lr, slicing, reps = {"C1": (16, True, 5), "C1b": (32, False, 3)}[shape]
     torch.set_num_threads(threads)
     from oracle import gan as ogan
     from oracle import nets as onets
 
-    LR, HR, Z, x, y = ogan.synthetic_batch(1, 16, 10, 4, seed=2001)
+    LR, HR, Z, x, y = ogan.synthetic_batch(1, n_lr, 10, 4, seed=2001)
     # ---- (a) the reference itself
     nc = types.ModuleType("netCDF4")
     nc.Dataset = nc.MFDataset = object
@@ -45,13 +50,14 @@ def main():
     cfg.is_train, cfg.is_test, cfg.is_use = True, False, False
     cfg.gpu_id, cfg.device = None, torch.device("cpu")
     cfg.training.niter, cfg.training.d_g_train_period = 150000, 1
+    cfg.gan_config.enable_slicing = slicing
     torch.manual_seed(2001)
     gan = ref_gan.wind_field_GAN_3D(cfg)
     gan.feed_xy_niter(x, y, torch.tensor(cfg.training.niter), 1, 1)
     ref_step = lambda it: gan.optimize_parameters(LR, HR, Z, it)  # noqa: E731
     # ---- (b) the oracle, exactly as bench.py's cpu_baseline builds it
     gs = onets.GSpec(dropout_p=0.1)
-    ds = onets.DSpec(bf=32, nz=10, enable_slicing=True, dropout_p=0.2)
+    ds = onets.DSpec(bf=32, nz=10, enable_slicing=slicing, dropout_p=0.2)
     gen = torch.Generator().manual_seed(0)
     sdG, sdD = onets.make_state(onets.g_param_shapes(gs)), onets.make_state(onets.d_param_shapes(ds))
     onets.kaiming_init_(sdG, 0.1, gen)
@@ -62,11 +68,12 @@ def main():
     # interleaved (the shared host drifts by tens of per cent over a minute), one warm-up pair each, median of 5
     one_pair(ref_step, 0), one_pair(or_step, 0)
     tr, to = [], []
-    for i in range(1, 6):
+    for i in range(1, reps + 1):
         tr.append(one_pair(ref_step, i))
         to.append(one_pair(or_step, i))
-    t_ref, t_or = sorted(tr)[2], sorted(to)[2]
+    t_ref, t_or = sorted(tr)[reps // 2], sorted(to)[reps // 2]
     ratio = t_or / t_ref
+    print(f"shape {shape}: LR {n_lr}x{n_lr}x10 -> HR {4 * n_lr}x{4 * n_lr}x10, batch 1, D {'sliced' if slicing else 'full'}")
     print(f"threads {threads}  torch {torch.__version__}  host cores {os.cpu_count()}")
     print(f"reference  wind_field_GAN_3D.optimize_parameters  G-it + D-it pair: median {t_ref:.3f} s  "
           f"(runs {' '.join(f'{v:.2f}' for v in tr)})")
