@@ -172,6 +172,7 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ part, long part_s
 
 void* g_ct_ws = nullptr;  // caller's split-reduction workspace (wsr_conv_tile_workspace)
 long g_ct_ws_bytes = 0;
+int g_ct_ws_dev = -1;     // device that was current when it was registered: launches on another device do not split
 
 }  // namespace
 
@@ -191,6 +192,8 @@ extern "C" int wsr_conv_tile_workspace(void* ws, int64_t bytes) {
   if (bytes < 0 || (ws == nullptr) != (bytes == 0)) return WSR_EINVAL;
   g_ct_ws = ws;
   g_ct_ws_bytes = (long)bytes;
+  g_ct_ws_dev = -1;
+  if (ws && hipGetDevice(&g_ct_ws_dev) != hipSuccess) g_ct_ws_dev = -1;
   return 0;
 }
 
@@ -256,8 +259,12 @@ static int run_conv_tile(CtArgs& a, int red, hipStream_t st) {
                  ? 1
                  : 0;
   if (a.act == 2 && !(a.vec_ok && (a.Cout & 3) == 0)) return WSR_EUNSUPPORTED;  // vector epilogue only
-  a.ws = g_ct_ws;
-  a.ws_bytes = g_ct_ws_bytes;
+  a.ws = nullptr;
+  a.ws_bytes = 0;
+  if (g_ct_ws) {  // the workspace is ONE buffer on ONE device: a launch on another device runs un-split
+    int dev = -1;
+    if (hipGetDevice(&dev) == hipSuccess && dev == g_ct_ws_dev) { a.ws = g_ct_ws; a.ws_bytes = g_ct_ws_bytes; }
+  }
   if (a.act_c1 != 0x7FFFFFFF && (a.act_c1 & 3)) return WSR_EINVAL;
   return dispatch_ct(a, tpk, st);
 }

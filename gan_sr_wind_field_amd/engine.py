@@ -45,6 +45,10 @@ POISON_BUFFERS = bool(int(__import__("os").environ.get("WSR_POISON_BUFFERS", "0"
 #: copy and the unpack pass adds the copies in index order - two backward passes give bit-identical gradients
 #: (WSR_DETERMINISTIC=0: one shared copy, float atomics)
 DETERMINISTIC = __import__("os").environ.get("WSR_DETERMINISTIC", "1") != "0"
+#: ... their split copies live in a persistent per-program arena of this many MB that is recycled whenever it is
+#: full: the pending copies are reduced into the master gradients (one launch) and the arena starts over.  (Round 2
+#: sized it as the sum of all copies of a backward pass: 4.2 GB at the benchmark shape, never released.)
+ARENA_MB = int(__import__("os").environ.get("WSR_ARENA_MB", "256"))
 #: input gradients of the discriminator's stride-(2,2,s) 4x4x3 convs as parity convs over dy on the tile kernels
 #: (WSR_STRIDED_DGRAD=0: generic implicit-GEMM kernel)
 STRIDED_DGRAD = __import__("os").environ.get("WSR_STRIDED_DGRAD", "1") != "0"
@@ -569,11 +573,43 @@ class ProgramBase:
             n = self._nparts[key] = ops.conv_wgrad_nparts(desc, tri_base, tri_step)
         return n
 
+    def _arena_reserve(self, n_total: int, dev) -> None:
+        """make sure the next slices of ``n_total`` floats in all fit WITHOUT a recycling flush in between (call sites
+        that take several slices first and launch their kernels afterwards: a flush in the middle would reduce copies
+        that have not been written yet)"""
+        if not DETERMINISTIC:
+            return
+        cap = max(ARENA_MB << 18, n_total + 64 * 64)
+        if self._arena is None or self._arena.device != torch.device(dev) or self._arena.numel() < cap:
+            self.flush_unpack()
+            self._arena = None
+            self._arena = torch.empty(cap, dtype=torch.float32, device=dev)
+            self._arena_off = 0
+        elif self._arena_off + n_total + 64 * 64 > self._arena.numel():
+            self.flush_unpack()
+            self._arena_off = 0
+
     def _arena_take(self, n: int, dev) -> Tensor:
+        if DETERMINISTIC:
+            # bounded, persistent arena: when the next slice does not fit, everything taken so far is reduced into the
+            # master gradients and the arena is recycled (stream order keeps the reduce ahead of the next writer).  The
+            # sequence of slices is the same every step, so the cached device job tables stay valid.
+            cap = max(ARENA_MB << 18, (n + 63) // 64 * 64)  # (floats)
+            if self._arena is None or self._arena.device != torch.device(dev) or self._arena.numel() < cap:
+                self.flush_unpack()
+                self._arena = None  # (release before growing)
+                self._arena = torch.empty(cap, dtype=torch.float32, device=dev)
+                self._arena_off = 0
+            if self._arena_off + n > self._arena.numel():
+                self.flush_unpack()
+                self._arena_off = 0
+            off = self._arena_off
+            self._arena_off = off + (n + 63) // 64 * 64
+            return self._arena[off:off + n]
         off = self._arena_off
         self._arena_need += (n + 63) // 64 * 64
         if self._arena is None or off + n > self._arena.numel():
-            return (torch.empty if DETERMINISTIC else torch.zeros)(n, dtype=torch.float32, device=dev)
+            return torch.zeros(n, dtype=torch.float32, device=dev)
         self._arena_off = off + (n + 63) // 64 * 64
         return self._arena[off:off + n]
 
@@ -587,7 +623,7 @@ class ProgramBase:
         key = tuple(j[0].data_ptr() for j in jobs) + tuple(j[1].data_ptr() for j in jobs) + tuple(j[2:] for j in jobs)
         table = self._unpack_tables.get(key)
         if table is None:
-            if len(self._unpack_tables) > 64:
+            if len(self._unpack_tables) > 512:
                 self._unpack_tables.clear()
             table = ops.unpack_job_table(jobs)
             self._unpack_tables[key] = table
@@ -600,10 +636,12 @@ class ProgramBase:
         self.flush_unpack()
         if not DETERMINISTIC:
             self._arena = None
-        elif self._arena is None or self._arena.numel() < self._arena_need:
-            dev = self._arena_dev
-            self._arena = None  # (release before growing)
-            self._arena = torch.empty(self._arena_need, dtype=torch.float32, device=dev)
+
+    def release_buffers(self) -> None:
+        """give the filter-gradient arena back (a model that leaves training for good; it is re-made on demand)"""
+        self.flush_unpack()
+        self._arena = None
+        self._unpack_tables.clear()
 
     @staticmethod
     def wgrad_scratch_elems(sites: Sequence[ConvSite], e: int) -> int:
@@ -800,9 +838,13 @@ class GeneratorProgram(ProgramBase):
             dwp = self._up_dwp[u] = torch.empty_like(self._up_wp[u], device=inp.device)
         cin_p = self.cp(site.cin)
         runs = []
+        descs = [ops.make_desc(ConvGeom(site.cin, site.cout, s.kernel, (1, 1, 1), s.pad), self.dt, B, xyz, inp.shape[-1],
+                               0, g.shape[-1], 0, cin=cin_p, lat=(ph >> 1, ph & 1, 0)) for ph, s in enumerate(par)]
+        if DETERMINISTIC:  # (the launches below are deferred: no recycling flush between the slices)
+            self._arena_reserve(sum((self._wgrad_nparts(("wpar", site.name, ph, B) + xyz, d) * site.cout * s.taps * cin_p
+                                     + 63) // 64 * 64 for ph, (s, d) in enumerate(zip(par, descs))), inp.device)
         for ph, s in enumerate(par):
-            d = ops.make_desc(ConvGeom(site.cin, site.cout, s.kernel, (1, 1, 1), s.pad), self.dt, B, xyz, inp.shape[-1],
-                              0, g.shape[-1], 0, cin=cin_p, lat=(ph >> 1, ph & 1, 0))
+            d = descs[ph]
             if DETERMINISTIC:
                 n = self._wgrad_nparts(("wpar", site.name, ph, B) + xyz, d)
                 parts = self._arena_take(n * site.cout * s.taps * cin_p, inp.device).view(n, site.cout, s.taps, cin_p)
@@ -1229,7 +1271,7 @@ class DiscriminatorProgram(ProgramBase):
             tw = [torch.empty((4, s.cout, s.cin, 2, 2, 3 if sz == 1 else (1 if zc == 0 else 2)), dtype=torch.float32,
                               device=inp.device) for zc in range(sz)]
             self._dparity_grads[key] = tw
-        runs = []
+        runs, jobs = [], []
         for zc in range(sz):
             kzp = 3 if sz == 1 else (1 if zc == 0 else 2)
             pz, mz, oz = (1, 1, 0) if sz == 1 else ((0, 2, 0) if zc == 0 else (1, 2, 1))
@@ -1238,10 +1280,13 @@ class DiscriminatorProgram(ProgramBase):
                 g = ConvGeom(s.cin, s.cout, (2, 2, kzp), (1, 1, 1), (1 - a_, 1 - b_, pz))
                 d = ops.make_desc(g, self.dt, B, oxyz, inp.shape[-1], 0, gy.shape[-1], 0, cin=cin_p,
                                   lat=(1 - a_, 1 - b_, 0, mz, oz, True))
-                n = self._wgrad_nparts(("wstr", s.name, zc, ph, B) + oxyz, d)
-                parts = self._arena_take(n * s.cout * g.taps * cin_p, inp.device).view(n, s.cout, g.taps, cin_p)
-                runs.append(lambda d=d, parts=parts, n=n: ops.conv_wgrad_parts(d, inp, gy, parts, n))
-                self._pending_unpack.append((parts[0], tw[zc][ph], 1.0, n, parts[0].numel()))
+                jobs.append((zc, ph, g, d, self._wgrad_nparts(("wstr", s.name, zc, ph, B) + oxyz, d)))
+        # (the launches are deferred: no recycling flush between the slices)
+        self._arena_reserve(sum((n * s.cout * g.taps * cin_p + 63) // 64 * 64 for _, _, g, _, n in jobs), inp.device)
+        for zc, ph, g, d, n in jobs:
+            parts = self._arena_take(n * s.cout * g.taps * cin_p, inp.device).view(n, s.cout, g.taps, cin_p)
+            runs.append(lambda d=d, parts=parts, n=n: ops.conv_wgrad_parts(d, inp, gy, parts, n))
+            self._pending_unpack.append((parts[0], tw[zc][ph], 1.0, n, parts[0].numel()))
 
         def run():
             for r in runs:
