@@ -441,6 +441,7 @@ int wsr_conv_slide_fwd(const unsigned short* in, int in_ctot, int in_off, int C,
                        const void* zero16, hipStream_t st) {
   if (C % 16 || in_ctot % 8 || in_off % 8 || N < 1 || N > 16) return WSR_EUNSUPPORTED;
   if ((long)Y * Z * in_ctot >= (1l << 29)) return WSR_EUNSUPPORTED;  // 32-bit byte offsets inside an x-plane, below CS_OOB
+  if ((long)16 * X * Y * Z >= (1l << 31)) return WSR_EUNSUPPORTED;     // 32-bit element offsets inside one item's output
   if ((long)B * Y * Z < 64 || X < 8) return WSR_EUNSUPPORTED;        // tiny volumes stay on the small-tile kernels
   CsArgs a{};
   a.in = in; a.wf = wfrag; a.out = out; a.zero16 = zero16; a.bias = bias;
@@ -491,7 +492,7 @@ struct CdGeom {
   static constexpr int M_NP = TY * TZ * OC;                 // pieces of a mask / result plane
   static constexpr int M_NU = (M_NP + 63) / 64;
   static constexpr int M_B = M_NP * 16;
-  static constexpr int RM = 3;                              // mask ring slots
+  static constexpr int RM = 4;                              // mask ring slots (power of two)
   static constexpr int NKS = (KX * KY + 1) / 2;             // K-steps: tap pairs x 16 channels
   static constexpr int TN = NT / 4;                         // n-tiles per wave held in registers (four N groups)
   static constexpr int NX = NT - 4 * TN;                    // left-over n-tile (0 or 1): N group 0, filter in LDS
@@ -514,11 +515,13 @@ __global__ __launch_bounds__(512) void conv_slide_dgrad_kernel(const CdArgs a) {
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
   const int ng = wave & 3, mh = wave >> 2;  // N group, m-tile half
   const int fr = lane & 15, fg = lane >> 4;
-  // n-tiles of N group g: [g TN, (g + 1) TN) with the filter in registers; group 0 also takes the left-over tile
-  // NT - 1 (NT = 9: 144 channels), whose fragments it reads from LDS - three tiles of fragments per wave (156 VGPRs)
-  // left the compiler 4 registers short, and a spilled DMA base pointer is reloaded behind a vmcnt(0) every plane
+  // n-tiles of N group g: [g TN, (g + 1) TN) with the filter in registers.  The left-over tile NT - 1 (NT = 9: 144
+  // channels) is shared out one voxel tile per wave to waves 0-3 - one per SIMD, so that every SIMD carries the same
+  // number of MFMAs (with both of its voxel tiles on N group 0 that group's SIMD had 1.5 x the work and set the pace) -
+  // and its filter fragments are read from LDS: three tiles of fragments per wave (156 VGPRs) left the compiler 4
+  // registers short, and a spilled DMA base pointer is reloaded behind a vmcnt(0) every plane.
   const int nt_lo = ng * TN;
-  const bool extra = NX > 0 && ng == 0;
+  const bool extra = NX > 0 && mh == 0;  // waves 0 .. 3: the left-over n-tile of voxel tile `ng`
 
   unsigned bid = (unsigned)xcd_remap(blockIdx.x, gridDim.x);
   int ty, tz;
@@ -597,8 +600,10 @@ __global__ __launch_bounds__(512) void conv_slide_dgrad_kernel(const CdArgs a) {
   // DMA instruction k of this wave for (mask plane xm, dy plane xd)
   auto issue_unit = [&](int k, const cs_srd_t& sm, int xm, const cs_srd_t& sd, int xd) __attribute__((always_inline)) {
     const int u = w4 + 4 * k;
-    if (u < M_NU) cs_bufdma16(sm, uoff[k], lds0 + G::OFF_MASK + (unsigned)(xm % RM) * M_B + udst[k]);
-    else if (u < NU) cs_bufdma16(sd, uoff[k], lds0 + G::OFF_DY + (unsigned)(xd & (RD - 1)) * DY_B + udst[k]);
+    if (u < M_NU)
+      cs_bufdma16(sm, uoff[k], __builtin_amdgcn_readfirstlane(lds0 + G::OFF_MASK + (unsigned)(xm & (RM - 1)) * M_B + udst[k]));
+    else if (u < NU)
+      cs_bufdma16(sd, uoff[k], __builtin_amdgcn_readfirstlane(lds0 + G::OFF_DY + (unsigned)(xd & (RD - 1)) * DY_B + udst[k]));
   };
 
   const long dx_plane = (long)a.Y * a.Z * a.dx_ctot;
@@ -623,6 +628,7 @@ __global__ __launch_bounds__(512) void conv_slide_dgrad_kernel(const CdArgs a) {
   // Both taps of a K-step are compile-time constants, so the fragment address is the lane's base + one of two
   // scalars (ring slot of the tap's column, row offset of the tap) picked by the lane group - no tables in registers.
   const int lane_base = (2 * mh * 16 + fr) * 32 + (fg & 1) * 16;  // (m-tile 2 mh; the second one is + 16 voxels)
+  const int lane_extra = (ng - 2 * mh) * 16 * 32;                  // (voxel tile ng of the left-over n-tile, from lane_base)
   const bool tap_hi = (fg >> 1) != 0;
 
   // ---- prologue: dy planes 0 .. KX, mask planes 0 and 1 -----------------------------------------------------------
@@ -647,28 +653,41 @@ __global__ __launch_bounds__(512) void conv_slide_dgrad_kernel(const CdArgs a) {
   cs_dma_wait();
   __syncthreads();
 
-  // DMA instructions this wave issues per plane (every plane: past the end they carry zero-record descriptors)
-  const int nw = dma_wave ? (NU - w4 + 3) / 4 : 0;
+  // ---- main loop ---------------------------------------------------------------------------------------------------
+  // Round i contracts plane i and, BETWEEN its K-steps, (a) issues the DMA of mask plane i + 2 / dy plane i + KX + 1
+  // (waves 0-3; the mask ring holds planes i - 1 .. i + 2), (b) masks, scales, rounds and stages plane i - 1 from the accumulators kept from the previous round
+  // (vector work under the MFMAs; done in a block behind them it cost a quarter of the launch), (c) stores the staged
+  // rows of plane i - 2 (waves 4-7).  The body is specialised per wave role and straight-line: the same loop with
+  // ~80 scalar branches per plane (role / first / last tests inside the unrolled K loop) spent 0.85 us per plane on
+  // them alone.  Planes past the end run with zero-record descriptors and rows that are never stored.
+  const int nw = dma_wave ? (NU - w4 + 3) / 4 : 0;  // DMA instructions this wave issues per plane
   constexpr int NWMAX = (NU + 3) / 4;
-  static_assert(UPW <= NKS && 2 * SPW <= NKS, "one DMA instruction / one half of a store per K-step");
-  for (int i = 0; i <= nplanes; ++i) {  // (one extra round: the stores of the last plane)
-    const bool contract = i < nplanes;
-    // this iteration's DMA (mask plane i + 2, dy plane i + KX + 1) and the stores of plane i - 1 are issued BETWEEN
-    // the K-steps below, one per step (a block of 5-6 DMA instructions cost a DMA wave 600-800 cycles in front of
-    // its matrix work; the stores waited behind them)
+  static_assert(UPW <= NKS && 2 * SPW <= NKS && (TN + NX) * 2 <= NKS, "one side job per K-step");
+  f32x4_t accp[2][TN + NX];  // accumulators of the plane contracted in the previous round
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int j = 0; j < TN + NX; ++j) accp[m][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  auto round = [&](int i, auto dmaw_c) __attribute__((always_inline)) {
+    constexpr bool DMAW = decltype(dmaw_c)::value;  // waves 0-3: DMA + the left-over n-tile; waves 4-7: stores
     const cs_srd_t sm = mask_srd(i + 2, i + 2 < nplanes), sd = dy_srd(i + KX + 1, i + KX + 1 <= last_dy);
-    unsigned short* const st_base = a.dx + ((long)b * a.X + x_begin + (i > 0 ? i - 1 : 0)) * dx_plane;
-    const char* const sg_prev = stg + ((i - 1) & 1) * M_B;
-    const bool st_now = st_wave && i > 0;
+    // rows staged in round i - 1 (plane i - 2) leave now
+    const int ip = i - 2;
+    char* const st_base = reinterpret_cast<char*>(a.dx + ((long)b * a.X + x_begin + (ip > 0 ? ip : 0)) * dx_plane);
+    const char* const sg_out = stg + (ip & 1) * M_B;
+    const bool st_ok = ip >= 0 && ip < nplanes;
     uint4 sreg = make_uint4(0u, 0u, 0u, 0u);
-    // ---- contraction: 2 m-tiles x TN n-tiles, NKS K-steps -----------------------------------------------------
+    // plane i - 1 is masked / staged now
+    const char* const mk = mkr + ((i - 1) & (RM - 1)) * M_B;
+    char* const sg_in = stg + ((i - 1) & 1) * M_B;
     f32x4_t acc[2][TN + NX];
 #pragma unroll
     for (int m = 0; m < 2; ++m)
 #pragma unroll
       for (int j = 0; j < TN + NX; ++j) acc[m][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
     constexpr int D = 2;
-    uint4 xa[D], xb[D], wx[D];
+    uint4 xa[D], xb[D], wx[D], xc[D];
 #define CD_FRAG_ADDR(ks)                                                                                        \
   (dyr + lane_base +                                                                                            \
    (tap_hi ? ((i + ((2 * (ks) + 1 < KX * KY - 1 ? 2 * (ks) + 1 : KX * KY - 1) / KY)) & (RD - 1)) * DY_B +        \
@@ -680,58 +699,38 @@ __global__ __launch_bounds__(512) void conv_slide_dgrad_kernel(const CdArgs a) {
     const char* p_ = CD_FRAG_ADDR(ks);                                                                          \
     xa[(ks) % D] = *reinterpret_cast<const uint4*>(p_);                                                         \
     xb[(ks) % D] = *reinterpret_cast<const uint4*>(p_ + 16 * 32);                                               \
-    if constexpr (NX > 0) {                                                                                     \
-      if (extra) wx[(ks) % D] = *reinterpret_cast<const uint4*>(wxl + (ks) * 1024 + lane * 16);                  \
+    if constexpr (NX > 0 && DMAW) {                                                                             \
+      wx[(ks) % D] = *reinterpret_cast<const uint4*>(wxl + (ks) * 1024 + lane * 16);                             \
+      xc[(ks) % D] = *reinterpret_cast<const uint4*>(p_ + lane_extra);                                           \
     }                                                                                                           \
   } while (0)
-    if (contract) {
 #pragma unroll
-      for (int ks = 0; ks < D && ks < NKS; ++ks) CD_FETCH(ks);
-    }
+    for (int ks = 0; ks < D && ks < NKS; ++ks) CD_FETCH(ks);
 #pragma unroll
     for (int ks = 0; ks < NKS; ++ks) {
       __builtin_amdgcn_sched_barrier(0);
-      if (contract) {
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {
-          mma_chunk<BF16>(acc[0][j], wreg[ks][j], xa[ks % D]);
-          mma_chunk<BF16>(acc[1][j], wreg[ks][j], xb[ks % D]);
-        }
-        if constexpr (NX > 0) {
-          if (extra) {
-            mma_chunk<BF16>(acc[0][TN], wx[ks % D], xa[ks % D]);
-            mma_chunk<BF16>(acc[1][TN], wx[ks % D], xb[ks % D]);
-          }
-        }
-        if (ks + D < NKS) CD_FETCH(ks + D);
+      for (int j = 0; j < TN; ++j) {
+        mma_chunk<BF16>(acc[0][j], wreg[ks][j], xa[ks % D]);
+        mma_chunk<BF16>(acc[1][j], wreg[ks][j], xb[ks % D]);
       }
+      if constexpr (NX > 0 && DMAW) mma_chunk<BF16>(acc[0][TN], wx[ks % D], xc[ks % D]);
+      if (ks + D < NKS) CD_FETCH(ks + D);
       __builtin_amdgcn_sched_barrier(0);
-      if (ks < UPW && dma_wave && contract) issue_unit(ks, sm, i + 2, sd, i + KX + 1);
-      if (ks < 2 * SPW && st_now) {  // result unit ks / 2 of plane i - 1: LDS read on even steps, store on odd ones
-        const int k = ks >> 1;
-        if (w4 + 4 * k < M_NU) {
-          if (!(ks & 1)) sreg = *reinterpret_cast<const uint4*>(sg_prev + udst[k] + lane * 16);
-          else if (uoff[k] != CS_OOB) *reinterpret_cast<uint4*>(reinterpret_cast<char*>(st_base) + uoff[k]) = sreg;
-        }
+      // (a) one DMA instruction
+      if constexpr (DMAW) {
+        if (ks < UPW) issue_unit(ks, sm, i + 2, sd, i + KX + 1);
       }
-    }
-    __builtin_amdgcn_sched_barrier(0);
-#undef CD_FETCH
-#undef CD_FRAG_ADDR
-    if (!contract) break;
-    // ---- mask, scale, round, stage as [voxel][ROWB] rows ---------------------------------------------------------
-    const char* mk = mkr + (i % RM) * M_B;
-    char* sg = stg + (i & 1) * M_B;
-#pragma unroll
-    for (int m = 0; m < 2; ++m)
-#pragma unroll
-      for (int j = 0; j < TN + NX; ++j) {
-        if (j < TN || extra) {
+      // (b) one (voxel tile, n-tile) of plane i - 1: mask, scale, round, stage as [voxel][ROWB] rows
+      if (ks < 2 * (TN + NX)) {
+        const int m = ks / (TN + NX), j = ks % (TN + NX);
+        if (j < TN || (NX > 0 && DMAW && m == 0)) {
           const int nt = j < TN ? nt_lo + j : NT - 1;
-          const int ro = ((2 * mh + m) * 16 + fr) * ROWB + (nt * 16 + 4 * fg) * 2;
+          const int mt = j < TN ? 2 * mh + m : ng;
+          const int ro = (mt * 16 + fr) * ROWB + (nt * 16 + 4 * fg) * 2;
           const uint2 y = *reinterpret_cast<const uint2*>(mk + ro);
           const float4 s4 = *reinterpret_cast<const float4*>(scl + nt * 16 + 4 * fg);
-          float4 o4 = make_float4(acc[m][j][0] * s4.x, acc[m][j][1] * s4.y, acc[m][j][2] * s4.z, acc[m][j][3] * s4.w);
+          float4 o4 = make_float4(accp[m][j][0] * s4.x, accp[m][j][1] * s4.y, accp[m][j][2] * s4.z, accp[m][j][3] * s4.w);
           o4.x *= (short)(y.x & 0xFFFFu) > 0 ? 1.f : a.slope;  // bf16 sign test on the raw bits: y > 0
           o4.y *= (int)y.x > 0xFFFF ? 1.f : a.slope;
           o4.z *= (short)(y.y & 0xFFFFu) > 0 ? 1.f : a.slope;
@@ -739,15 +738,39 @@ __global__ __launch_bounds__(512) void conv_slide_dgrad_kernel(const CdArgs a) {
           uint2 u;
           u.x = (unsigned)f2bf(o4.x) | ((unsigned)f2bf(o4.y) << 16);
           u.y = (unsigned)f2bf(o4.z) | ((unsigned)f2bf(o4.w) << 16);
-          *reinterpret_cast<uint2*>(sg + ro) = u;
+          *reinterpret_cast<uint2*>(sg_in + ro) = u;
         }
       }
-    // the DMA issued one iteration ago (mask plane i + 1, dy plane i + KX) has landed; this iteration's stays in flight
-    if (dma_wave) {
+      // (c) result unit ks / 2 of plane i - 2: LDS read on even steps, store on odd ones
+      if constexpr (!DMAW) {
+        if (ks < 2 * SPW) {
+          const int k = ks >> 1;
+          if (w4 + 4 * k < M_NU) {
+            if (!(ks & 1)) sreg = *reinterpret_cast<const uint4*>(sg_out + udst[k] + lane * 16);
+            else if (st_ok && uoff[k] != CS_OOB) *reinterpret_cast<uint4*>(st_base + uoff[k]) = sreg;
+          }
+        }
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#undef CD_FETCH
+#undef CD_FRAG_ADDR
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int j = 0; j < TN + NX; ++j) accp[m][j] = acc[m][j];
+    // the DMA issued one round ago has landed; this round's stays in flight
+    if constexpr (DMAW) {
       if (nw == NWMAX) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NWMAX) : "memory");
       else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NWMAX - 1) : "memory");
     }
     __syncthreads();
+  };
+  // rounds 0 .. nplanes + 1: the last two only drain the pipeline (stage the last plane, store the last two)
+  if (dma_wave) {
+    for (int i = 0; i < nplanes + 2; ++i) round(i, std::true_type{});
+  } else {
+    for (int i = 0; i < nplanes + 2; ++i) round(i, std::false_type{});
   }
   cs_dma_wait();  // (zero-record DMA issued for planes past the end must not outlive the workgroup)
 }

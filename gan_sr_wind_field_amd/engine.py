@@ -48,7 +48,7 @@ DETERMINISTIC = __import__("os").environ.get("WSR_DETERMINISTIC", "1") != "0"
 #: ... their split copies live in a persistent per-program arena of this many MB that is recycled whenever it is
 #: full: the pending copies are reduced into the master gradients (one launch) and the arena starts over.  (Round 2
 #: sized it as the sum of all copies of a backward pass: 4.2 GB at the benchmark shape, never released.)
-ARENA_MB = int(__import__("os").environ.get("WSR_ARENA_MB", "256"))
+ARENA_MB = int(__import__("os").environ.get("WSR_ARENA_MB", "1024"))
 #: input gradients of the discriminator's stride-(2,2,s) 4x4x3 convs as parity convs over dy on the tile kernels
 #: (WSR_STRIDED_DGRAD=0: generic implicit-GEMM kernel)
 STRIDED_DGRAD = __import__("os").environ.get("WSR_STRIDED_DGRAD", "1") != "0"

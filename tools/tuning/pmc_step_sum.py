@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Per-kernel HBM traffic and MFMA occupancy of one train step from the three counter passes of pmc_step.sh.
 
-    python tools/tuning/pmc_step_sum.py NAME STATS_CSV > profiles/NAME_hbm_kernels.txt   (+ profiles/r02_hbm_traffic.json)
+    python tools/tuning/pmc_step_sum.py NAME STATS_CSV > profiles/NAME_hbm_kernels.txt   (+ profiles/r03_hbm_traffic.json)
 
 Durations come from the un-instrumented ``rocprofv3 --kernel-trace --stats`` run (STATS_CSV): counter passes
 serialise dispatches and run at a lower clock.  FETCH_SIZE is doubled (gfx950 tallies 128-byte requests of wide
@@ -38,7 +38,11 @@ def main(name, stats_csv):
     v, V = 32 * 32 * 128, 128 ** 3
     algo = {
         "conv_tile_kernel<8, 1, 4, 9, 2, false, false>": 2 * V * 144 * 2 + 125 * 144 * 144 * 2,
-        "conv1x1_v2_kernel<8, 8, false, true>": v * (256 + 128 + 128) * 2 + 256 * 128 * 2,
+        # LFF forward: 256 channels in, 128 out; the block shortcut is the lane's own K fragment (no second read); every
+        # third launch (last block of an RRDB) also reads the RRDB shortcut: average over the launches
+        "conv1x1_v2_kernel<8, 8, false, true>": v * (256 + 128) * 2 + 256 * 128 * 2 + v * 128 * 2 // 3,
+        "conv_slide_fwd_kernel<5, 5, 18>": V * (144 * 2 + 15 * 4) + 125 * 144 * 3 * 2,
+        "conv_slide_dgrad_kernel<5, 5, 9>": V * (16 * 2 + 2 * 144 * 2) + 125 * 144 * 3 * 2,
         "conv1x1_v2_kernel<16, 4, true, true>": v * (128 + 128 + 256 + 32) * 2 + 256 * 128 * 2,
         "wgrad_tile_kernel<8, 1, 8, true>": v * (256 + 128) * 2,
         "wgrad_tile_kernel<3, 16, 1, true>": 2 * V * 144 * 2,
@@ -68,12 +72,13 @@ def main(name, stats_csv):
         a = f"{ab / 1e6:9.1f} {ab / (us * 1e-6) / 1e12:9.2f}" if ab else f"{'':9s} {'':9s}"
         print(f"{k[:58]:58s} {calls:6d} {us:9.1f} {f / 1e6:10.1f} {w / 1e6:10.1f} {rate:6.2f} {util:6.2f} {wait:6.2f} {a}")
     traffic = {}
-    for key, k in (("hr0", "conv_tile_kernel<8, 1, 4, 9, 2, false, false>"), ("lff_fwd", "conv1x1_v2_kernel<8, 8, false, true>")):
+    for key, k in (("hr0", "conv_tile_kernel<8, 1, 4, 9, 2, false, false>"), ("lff_fwd", "conv1x1_v2_kernel<8, 8, false, true>"),
+                   ("hr1_fwd", "conv_slide_fwd_kernel<5, 5, 18>"), ("hr1_dgrad", "conv_slide_dgrad_kernel<5, 5, 9>")):
         r = [x for x in rows if x[1] == k]
         if r:
             traffic[key] = r[0][4] + r[0][5]
     traffic["source"] = f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes '{name}', 2 x FETCH + WRITE, bytes per launch"
-    json.dump(traffic, open("profiles/r02_hbm_traffic.json", "w"), indent=1)
+    json.dump(traffic, open("profiles/r03_hbm_traffic.json", "w"), indent=1)
 
 
 if __name__ == "__main__":
