@@ -80,6 +80,12 @@ struct CtArgs {
   long part_stride;
   void* ws;
   long ws_bytes;
+  // Single activation buffer (the 5x5x5 144 -> 144 conv: no room for two): the halo image of the NEXT chunk is loaded
+  // in two parts, both under MFMAs.  The K-steps walk the taps kx-major, so the last tap column (kx = KX-1) only reads
+  // x-planes >= KX-1 of the image: from weight stage xs_stage on, planes < KX-1 (DMA units [0, xs_units)) are dead and
+  // take the next chunk; the rest is issued when the next chunk starts, whose first stage (kx = 0 only) reads planes
+  // < TX.  xs_stage < 0: off (the whole image is reloaded between chunks behind an exposed wait + barrier).
+  int xs_stage, xs_units;
   int prio;    // 1: waves of the second half of the workgroup run the main loop at s_setprio 1 (tuning switch)
   int ablate;  // -DWSR_CT_STAMPS builds, timing only: skip 1 = activation prefetch, 2 = weight prefetch, 4 = LDS reads, 8 = MFMAs
   unsigned long long* stamps;  // -DWSR_CT_STAMPS builds: [workgroup][8] clock samples of wave 0 (else unused)
@@ -323,10 +329,15 @@ void conv_tile_kernel(const CtArgs a) {
     // wave several hundred issue cycles during which it feeds no MFMAs, so the two halves of the workgroup
     // (waves w and w + WAVES/2 share a SIMD) take turns: the first half issues at the top of the phase, the
     // second half in the middle of its K-step loop, and the other wave keeps the SIMD's matrix pipe busy.
-    if (a.xbufs != 2 && st == 0 && chunk > 0) {  // single activation buffer: reload it between chunks
-      x_issue(chunk, 0, 0, HU);
-      dma_wait();
-      __syncthreads();
+    if (a.xbufs != 2) {  // single activation buffer
+      if (a.xs_stage >= 0) {  // next chunk's image in two parts, both under MFMAs (see CtArgs.xs_stage)
+        if (st == a.xs_stage && chunk + 1 < nchunks_l) x_issue(chunk + 1, 0, 0, a.xs_units);
+        if (st == 0 && chunk > 0) x_issue(chunk, 0, a.xs_units, HU);
+      } else if (st == 0 && chunk > 0) {  // reload it between chunks
+        x_issue(chunk, 0, 0, HU);
+        dma_wait();
+        __syncthreads();
+      }
     }
     auto burst = [&]() __attribute__((always_inline)) {
 #ifdef WSR_CT_STAMPS
@@ -646,6 +657,24 @@ int launch_ct(CtArgs& a, hipStream_t st) {
   a.TS = (a.nts + nph - 1) / nph;  // balanced stages
   const size_t lds = (size_t)a.off_ws + (size_t)2 * a.TS * NTW * 1024;
   if (lds > 160 * 1024) return WSR_EUNSUPPORTED;
+  a.xs_stage = -1;
+  a.xs_units = 0;
+  if (a.xbufs == 1 && a.nchunks > 1 && VM && a.KX >= 2 && a.sx == 1 && !WSR_ENV_SET("WSR_CT_NOXSPLIT")) {
+    const int Ly_ = (a.TY - 1) * a.sy + a.KY, Lz_ = (a.TZ - 1) * a.sz + a.KZ;
+    const int plane_vox = Ly_ * Lz_;                       // halo voxels of one x-plane
+    const int early_vox = (a.KX - 1) * plane_vox;          // planes [0, KX-1)
+    const int ks_last = ((a.KX - 1) * a.KY * a.KZ + TPK - 1) / TPK;  // first K-step whose taps are all in column KX-1
+    const int nst = (a.nts + a.TS - 1) / a.TS;
+    const int se = (ks_last + a.TS - 1) / a.TS;            // first weight stage made of such K-steps only
+    const int ks_kx1 = (a.KY * a.KZ) / TPK;                // first K-step that touches tap column 1
+    // conditions: the early part is whole DMA units; a stage boundary exists inside the last tap column; the first
+    // stage of a chunk stays inside tap column 0 (it runs before the late part is published) and reads only planes
+    // < TX <= KX-1 ... the late part holds planes >= KX-1, read from tap column max(1, KX-TX) on
+    if (early_vox % 32 == 0 && se < nst && a.TS <= ks_kx1 && a.TX <= a.KX - 1) {
+      a.xs_stage = se;
+      a.xs_units = early_vox / 32;
+    }
+  }
   a.tiles_x = (a.Xo + a.TX - 1) / a.TX;
   a.tiles_y = (a.Yo + a.TY - 1) / a.TY;
   a.tiles_z = (a.Zo + a.TZ - 1) / a.TZ;
