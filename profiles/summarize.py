@@ -1,12 +1,12 @@
 #!/usr/bin/env python
-"""Print the per-kernel summary of a rocprofv3 --kernel-trace --stats run (kernel_stats.csv)."""
+"""Print the per-kernel summary of a rocprofv3 --kernel-trace --stats run: summarize.py DIR|kernel_stats.csv [STEPS]."""
 import csv
 import glob
 import sys
 
 
 def main(d, steps):
-    f = glob.glob(d + "/**/*kernel_stats.csv", recursive=True)[0]
+    f = d if d.endswith(".csv") else glob.glob(d + "/**/*kernel_stats.csv", recursive=True)[0]
     rows = list(csv.DictReader(open(f)))
     tot = sum(float(r["TotalDurationNs"]) for r in rows)
     print(f"# {f}: total kernel time {tot / 1e6:.1f} ms over {steps} steps = {tot / 1e6 / steps:.1f} ms/step")
