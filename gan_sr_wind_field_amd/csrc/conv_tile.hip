@@ -103,44 +103,109 @@ __global__ void pack_frag_kernel(const float* __restrict__ w, unsigned short* __
   }
 }
 
-// one block row (blockIdx.y) per job
-__global__ void pack_frag_multi_kernel(const wsr_pack_job_t* __restrict__ jobs) {
-  const wsr_pack_job_t j = jobs[blockIdx.y];
-  const int taps = j.KX * j.KY * j.KZ;
+// One block row (blockIdx.y) per job.  An item = one (chunk, n-tile, range of <= 32 taps) of the job's sub-block: its
+// 16 rows x CK reduction channels x taps are contiguous runs of the master filter (CK * taps floats per row forward,
+// 16 * taps per reduction channel transposed); they are read coalesced into LDS and leave as whole 16-byte fragments.
+// (The first form gathered one float per 2-byte store, `taps` floats apart: 4.5x the filter bytes fetched.  Measured
+// and dropped: one flat grid over all jobs' items with the prefix sums of the item counts built per workgroup - the
+// prefix costs more than the ~60 000 mostly empty workgroups of a network's table - and the next item's loads
+// issued under the fragment writes - 228 registers, spills.)
+constexpr int PK_TRMAX = 32;
+
+struct PkGeom {
+  int taps, TPK, pls, cks, CK, nts, NT_total, chunk0, nchunks, nt0, ntl, src_rows, src_red, c_lo, TR, ntr, items;
+};
+__device__ __forceinline__ PkGeom pk_geom(const wsr_pack_job_t j) {
+  PkGeom g;
+  g.taps = j.KX * j.KY * j.KZ;
   const bool part = j.red_total > 0;  // one source of a stacked dense-block filter
   const int rows = part ? (j.transpose ? j.c_n : j.rows_total) : (j.transpose ? j.Cin : j.Cout);
   const int red = part ? j.red_total : (j.transpose ? j.Cout : j.Cin);
   const int redp = (red + 7) / 8 * 8;
-  const int TPK = taps == 1 ? (redp % 32 == 0 ? 1 : (redp % 16 == 0 ? 2 : 4)) : (redp % 16 == 0 ? 2 : 4);
-  const int PL = 4 / TPK, CK = 8 * PL;
-  const int nts = (taps + TPK - 1) / TPK, NT_total = (rows + 15) / 16;
+  g.TPK = g.taps == 1 ? (redp % 32 == 0 ? 1 : (redp % 16 == 0 ? 2 : 4)) : (redp % 16 == 0 ? 2 : 4);
+  g.pls = g.TPK == 1 ? 2 : (g.TPK == 2 ? 1 : 0);  // PL = 4 / TPK = 1 << pls channel octets per tap, CK = 8 << pls
+  g.cks = 3 + g.pls;
+  g.CK = 1 << g.cks;
+  const int tps = 2 - g.pls;                      // TPK = 1 << tps
+  g.nts = (g.taps + g.TPK - 1) >> tps;
+  g.NT_total = (rows + 15) / 16;
   // the sub-block this job writes: chunks [chunk0, chunk0 + nchunks), n-tiles [nt0, nt0 + ntl)
-  const int chunk0 = part && j.transpose ? j.red_off / CK : 0;
-  const int nchunks = part ? (j.transpose ? j.Cout / CK : (redp + CK - 1) / CK) : (redp + CK - 1) / CK;
-  const int nt0 = part && !j.transpose ? j.row_off / 16 : 0;
-  const int ntl = part && !j.transpose ? (j.Cout + 15) / 16 : NT_total;
-  const int src_rows = j.transpose ? (part ? j.c_n : j.Cin) : j.Cout;   // rows the source block has
-  const int src_red = j.transpose ? j.Cout : (part ? j.c_n : j.Cin);    // reduction channels it has
-  const int c_lo = part ? j.c_lo : 0;
-  const long total = (long)nchunks * nts * ntl * 512;
+  g.chunk0 = part && j.transpose ? j.red_off >> g.cks : 0;
+  g.nchunks = part && j.transpose ? j.Cout >> g.cks : (redp + g.CK - 1) >> g.cks;
+  g.nt0 = part && !j.transpose ? j.row_off / 16 : 0;
+  g.ntl = part && !j.transpose ? (j.Cout + 15) / 16 : g.NT_total;
+  g.src_rows = j.transpose ? (part ? j.c_n : j.Cin) : j.Cout;  // rows the source block has
+  g.src_red = j.transpose ? j.Cout : (part ? j.c_n : j.Cin);   // reduction channels it has
+  g.c_lo = part ? j.c_lo : 0;
+  // tap ranges: TR padded taps (a multiple of TPK) at a time
+  const int ptaps = g.nts << tps;
+  g.TR = ptaps < PK_TRMAX ? ptaps : PK_TRMAX;
+  g.ntr = (ptaps + g.TR - 1) / g.TR;
+  g.items = g.nchunks * g.ntl * g.ntr;
+  return g;
+}
+
+__global__ __launch_bounds__(256) void pack_frag_multi_kernel(const wsr_pack_job_t* __restrict__ jobs) {
+  __shared__ float sh[512 * 17 > 256 * (PK_TRMAX + 1) ? 512 * 17 : 256 * (PK_TRMAX + 1)];
+  const wsr_pack_job_t jrec = jobs[blockIdx.y];
+  const PkGeom g = pk_geom(jrec);
+  struct { const float* w; void* out; int transpose, Cin; } j = {jrec.w, jrec.out, jrec.transpose, jrec.Cin};  // (scalars)
+  const int taps = g.taps, TR = g.TR, pitch = TR + 1, cks = g.cks, CK = g.CK, pls = g.pls, tps = 2 - g.pls;
+  const int nrow = 16 << cks;  // LDS rows: forward i * CK + cl, transposed cl * 16 + i  (source order)
   const float* __restrict__ w = j.w;
-  unsigned short* __restrict__ out = reinterpret_cast<unsigned short*>(j.out);
-  for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
-    const int e = (int)(idx & 7);
-    const int lane = (int)((idx >> 3) & 63);
-    long q = idx >> 9;
-    const int nt = (int)(q % ntl); q /= ntl;
-    const int ts = (int)(q % nts);
-    const int chunk = (int)(q / nts);
-    const int i = lane & 15, g = lane >> 4;
-    const int tap = ts * TPK + g / PL;
-    const int c = chunk * CK + (g % PL) * 8 + e;  // reduction channel within the source block
-    const int n = nt * 16 + i;                     // row within the source block
-    float v = 0.f;
-    if (tap < taps && c < src_red && n < src_rows)
-      v = j.transpose ? w[((long)c * j.Cin + c_lo + n) * taps + (taps - 1 - tap)]
-                      : w[((long)n * j.Cin + c_lo + c) * taps + tap];
-    out[(((long)(chunk0 + chunk) * nts + ts) * NT_total + nt0 + nt) * 512 + lane * 8 + e] = f2bf(v);
+  uint4* __restrict__ out = reinterpret_cast<uint4*>(j.out);
+  const int t = threadIdx.x;
+  // (index arithmetic by shifts only: with runtime divisions the kernel was bound by them, not by memory)
+  // loads: thread (tx, ty) reads tap t0 + tx of rows ty, ty + RP, ...; one column when a range is one tap (1x1x1)
+  const int tcs = TR == 1 ? 0 : 5;
+  const int tx = t & ((1 << tcs) - 1), ty = t >> tcs, RP = 256 >> tcs;
+  for (int item = blockIdx.x; item < g.items; item += gridDim.x) {
+    const int tr = item % g.ntr;
+    const int q = item / g.ntr;
+    const int nt = q % g.ntl, chunk = q / g.ntl;
+    const int t0 = tr * TR;  // first (destination-order) tap of the range
+    const int tap = t0 + tx;
+    const bool tap_ok = tx < TR && tap < taps;
+    const long tap_src = j.transpose ? taps - 1 - tap : tap;
+    __syncthreads();
+    // (sixteen loads in flight per thread: left as a plain loop the compiler waits for every float before the next)
+    for (int r0 = ty; r0 < nrow; r0 += RP * 16) {
+      float v[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) {
+        const int r = r0 + u * RP;
+        const int i = j.transpose ? (r & 15) : r >> cks, cl = j.transpose ? (r >> 4) : r & (CK - 1);
+        const int n = nt * 16 + i, c = chunk * CK + cl;
+        v[u] = 0.f;
+        if (r < nrow && tap_ok && c < g.src_red && n < g.src_rows)
+          v[u] = j.transpose ? w[((long)c * j.Cin + g.c_lo + n) * taps + tap_src]
+                             : w[((long)n * j.Cin + g.c_lo + c) * taps + tap_src];
+      }
+#pragma unroll
+      for (int u = 0; u < 16; ++u) {
+        const int r = r0 + u * RP;
+        if (r < nrow && tx < TR) sh[r * pitch + tx] = v[u];
+      }
+    }
+    __syncthreads();
+    const int ts0 = t0 >> tps, tsn = min(TR >> tps, g.nts - ts0);
+    for (int idx = t; idx < tsn * 64; idx += 256) {
+      const int lane = idx & 63, tsl = idx >> 6;
+      const int i = lane & 15, gq = lane >> 4;
+      const int tt = (tsl << tps) + (gq >> pls), clb = (gq & ((1 << pls) - 1)) * 8;
+      float f[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int r = j.transpose ? (clb + e) * 16 + i : (i << cks) + clb + e;
+        f[e] = sh[r * pitch + tt];
+      }
+      uint4 u;
+      u.x = (unsigned)f2bf(f[0]) | ((unsigned)f2bf(f[1]) << 16);
+      u.y = (unsigned)f2bf(f[2]) | ((unsigned)f2bf(f[3]) << 16);
+      u.z = (unsigned)f2bf(f[4]) | ((unsigned)f2bf(f[5]) << 16);
+      u.w = (unsigned)f2bf(f[6]) | ((unsigned)f2bf(f[7]) << 16);
+      out[(((long)(g.chunk0 + chunk) * g.nts + ts0 + tsl) * g.NT_total + g.nt0 + nt) * 64 + lane] = u;
+    }
   }
 }
 
@@ -199,7 +264,10 @@ extern "C" int wsr_conv_tile_workspace(void* ws, int64_t bytes) {
 
 extern "C" int wsr_pack_filter_frag_multi(const wsr_pack_job_t* jobs_dev, int32_t n_jobs, void* stream) {
   if (!jobs_dev || n_jobs <= 0 || n_jobs > 65535) return WSR_EINVAL;
-  hipLaunchKernelGGL(pack_frag_multi_kernel, dim3(64, (unsigned)n_jobs), dim3(256), 0, as_stream(stream), jobs_dev);
+  // workgroups per job: a generator's table is ~1 000 jobs of mostly 16-28 items (empty workgroups cost dispatch time),
+  // a discriminator's 43 jobs of up to 512 (measured: 16 / 32 / 128 workgroups per job win at 940 / 398 / 43 jobs)
+  const int gx = WSR_ENV_INT("WSR_PK_GRID", n_jobs >= 512 ? 16 : (n_jobs >= 128 ? 32 : 128));
+  hipLaunchKernelGGL(pack_frag_multi_kernel, dim3((unsigned)gx, (unsigned)n_jobs), dim3(256), 0, as_stream(stream), jobs_dev);
   WSR_LAUNCH_CHECK();
   return 0;
 }

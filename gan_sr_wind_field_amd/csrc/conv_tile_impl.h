@@ -330,7 +330,9 @@ void conv_tile_kernel(const CtArgs a) {
     // (waves w and w + WAVES/2 share a SIMD) take turns: the first half issues at the top of the phase, the
     // second half in the middle of its K-step loop, and the other wave keeps the SIMD's matrix pipe busy.
     if (a.xbufs != 2) {  // single activation buffer
-      if (a.xs_stage >= 0) {  // next chunk's image in two parts, both under MFMAs (see CtArgs.xs_stage)
+      // (compiled into the 144-wide instantiation only: with the two extra copies of the issue loop in every
+      // instantiation the 32-wide launches of the dense blocks went from 26.8 to 30.7 us)
+      if (TN == 9 && a.xs_stage >= 0) {  // next chunk's image in two parts, both under MFMAs (see CtArgs.xs_stage)
         if (st == a.xs_stage && chunk + 1 < nchunks_l) x_issue(chunk + 1, 0, 0, a.xs_units);
         if (st == 0 && chunk > 0) x_issue(chunk, 0, a.xs_units, HU);
       } else if (st == 0 && chunk > 0) {  // reload it between chunks
@@ -659,7 +661,7 @@ int launch_ct(CtArgs& a, hipStream_t st) {
   if (lds > 160 * 1024) return WSR_EUNSUPPORTED;
   a.xs_stage = -1;
   a.xs_units = 0;
-  if (a.xbufs == 1 && a.nchunks > 1 && VM && a.KX >= 2 && a.sx == 1 && !WSR_ENV_SET("WSR_CT_NOXSPLIT")) {
+  if (TN == 9 && a.xbufs == 1 && a.nchunks > 1 && VM && a.KX >= 2 && a.sx == 1 && !WSR_ENV_SET("WSR_CT_NOXSPLIT")) {
     const int Ly_ = (a.TY - 1) * a.sy + a.KY, Lz_ = (a.TZ - 1) * a.sz + a.KZ;
     const int plane_vox = Ly_ * Lz_;                       // halo voxels of one x-plane
     const int early_vox = (a.KX - 1) * plane_vox;          // planes [0, KX-1)

@@ -77,37 +77,48 @@ __global__ void unpack_wgrad_multi_kernel(const wsr_unpack_job_t* __restrict__ j
 // layout in one pass.  One workgroup per (job, output channel n, 64 input channels): the packed rows
 // [tap][c0 .. c0+63] of every part are read coalesced, summed, transposed through LDS and written as the
 // contiguous run dst[n][c0 .. c0+63][taps].
-__global__ __launch_bounds__(256) void unpack_reduce_multi_kernel(const wsr_unpack_job_t* __restrict__ jobs) {
+__global__ __launch_bounds__(512) void unpack_reduce_multi_kernel(const wsr_unpack_job_t* __restrict__ jobs) {
   __shared__ float sh[64][129];  // [c][tap], taps <= 128
   const wsr_unpack_job_t j = jobs[blockIdx.y];
   const int cchunks = (j.Cin + 63) / 64;
-  const int c4 = (threadIdx.x & 15) * 4, tl = threadIdx.x >> 4;  // 16 lanes x float4 = 64 channels, 16 taps at a time
+  // 16 lanes x float4 = 64 channels, 32 taps at a time (a 3x3x3 filter: one pass); a thread's chain is
+  // ceil(n_parts / 16) dependent round trips - at 8 in flight and 16 taps per pass the 64-copy jobs were latency-bound
+  const int c4 = (threadIdx.x & 15) * 4, tl = threadIdx.x >> 4;
   const int nparts = j.n_parts > 0 ? j.n_parts : 1;
   const bool vec = (j.kpad & 3) == 0 && (j.part_stride & 3) == 0 && (((size_t)j.src) & 15) == 0;
   for (int item = blockIdx.x; item < j.Cout * cchunks; item += gridDim.x) {
     const int n = item / cchunks, c0 = (item - n * cchunks) * 64;
     const int cw = min(64, j.Cin - c0);
     __syncthreads();
-    for (int tap = tl; tap < j.taps; tap += 16) {
+    for (int tap = tl; tap < j.taps; tap += 32) {
       const float* p = j.src + ((long)n * j.taps + tap) * j.kpad + c0 + c4;
       float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
       if (vec && c0 + c4 + 4 <= j.kpad) {  // (the row is kpad long: reading past Cin inside it is harmless)
-        // eight copies in flight per thread (the copies are megabytes apart: every load is an HBM round trip), added
-        // in index order
+        // sixteen copies in flight per thread (the copies are megabytes apart: every load is an HBM round trip),
+        // added in index order
         int s = 0;
-        for (; s + 8 <= nparts; s += 8) {
+        for (; s + 16 <= nparts; s += 16) {
+          float4 v[16];
+#pragma unroll
+          for (int u = 0; u < 16; ++u) v[u] = *reinterpret_cast<const float4*>(p + (long)(s + u) * j.part_stride);
+#pragma unroll
+          for (int u = 0; u < 16; ++u) { a.x += v[u].x; a.y += v[u].y; a.z += v[u].z; a.w += v[u].w; }
+        }
+        if (s + 8 <= nparts) {
           float4 v[8];
 #pragma unroll
           for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const float4*>(p + (long)(s + u) * j.part_stride);
 #pragma unroll
           for (int u = 0; u < 8; ++u) { a.x += v[u].x; a.y += v[u].y; a.z += v[u].z; a.w += v[u].w; }
+          s += 8;
         }
-        for (; s + 4 <= nparts; s += 4) {
+        if (s + 4 <= nparts) {
           float4 v[4];
 #pragma unroll
           for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const float4*>(p + (long)(s + u) * j.part_stride);
 #pragma unroll
           for (int u = 0; u < 4; ++u) { a.x += v[u].x; a.y += v[u].y; a.z += v[u].z; a.w += v[u].w; }
+          s += 4;
         }
         for (; s < nparts; ++s) {
           const float4 v = *reinterpret_cast<const float4*>(p + (long)s * j.part_stride);
@@ -126,7 +137,7 @@ __global__ __launch_bounds__(256) void unpack_reduce_multi_kernel(const wsr_unpa
     }
     __syncthreads();
     float* d = j.dst + ((long)n * j.Cin + c0) * j.taps;
-    for (int idx = threadIdx.x; idx < cw * j.taps; idx += 256) {
+    for (int idx = threadIdx.x; idx < cw * j.taps; idx += 512) {
       const int c = idx / j.taps, tap = idx - c * j.taps;
       const float v = j.scale * sh[c][tap];
       d[idx] = j.accumulate ? d[idx] + v : v;
@@ -807,7 +818,7 @@ extern "C" int wsr_unpack_wgrad_multi(const wsr_unpack_job_t* jobs_dev, int32_t 
 
 extern "C" int wsr_unpack_wgrad_reduce_multi(const wsr_unpack_job_t* jobs_dev, int32_t n_jobs, void* stream) {
   if (!jobs_dev || n_jobs <= 0 || n_jobs > 65535) return WSR_EINVAL;
-  hipLaunchKernelGGL(unpack_reduce_multi_kernel, dim3(128, (unsigned)n_jobs), dim3(256), 0, as_stream(stream), jobs_dev);
+  hipLaunchKernelGGL(unpack_reduce_multi_kernel, dim3(128, (unsigned)n_jobs), dim3(512), 0, as_stream(stream), jobs_dev);
   WSR_LAUNCH_CHECK();
   return 0;
 }

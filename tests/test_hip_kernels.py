@@ -1006,3 +1006,43 @@ def test_strided_filter_gradient_in_parity_form(hip, sz, cin, cout, xyz, B):
     assert torch.isfinite(outs[0]).all()
     assert rel_l2(outs[0], w.grad) < 2e-5  # fp32 accumulation of exactly representable products
     assert torch.equal(outs[0], outs[1])
+
+
+@pytest.mark.parametrize("shape", [(32, 128, 3, 3, 3), (128, 256, 1, 1, 1), (256, 128, 1, 1, 1), (144, 144, 5, 5, 5),
+                                   (3, 144, 5, 5, 1), (32, 3, 3, 3, 3), (64, 40, 4, 4, 3), (20, 24, 3, 3, 1)])
+def test_filter_fragments_of_a_job_table_equal_the_single_filter_pack(hip, shape):
+    """wsr_pack_filter_frag_multi (LDS-staged, one launch per network) writes bit for bit what wsr_pack_filter_frag
+    (one gather kernel per filter) writes - forward and transposed (input-gradient) fragment order."""
+    o = ops()
+    gen = torch.Generator().manual_seed(sum(shape))
+    w = torch.randn(shape, generator=gen).to(DEV)
+    jobs, want = [], []
+    for tr in (False, True):
+        want.append(o.pack_filter_frag(w, transpose=tr))
+        out = torch.full_like(want[-1], float("nan"))
+        jobs.append((w, out, tr))
+    o.pack_filter_frag_multi(o.pack_job_table(jobs))
+    torch.cuda.synchronize()
+    for (_, out, tr), ref in zip(jobs, want):
+        assert torch.equal(out.view(torch.int16), ref.view(torch.int16)), f"transpose={tr}"
+
+
+@pytest.mark.parametrize("transpose", [False, True])
+def test_stacked_filter_parts_equal_the_pack_of_the_stacked_filter(hip, transpose):
+    """The stacked filter of a dense block (reference torch_blocks.py:256-267: conv i reads channels [0, nf + i*gc))
+    assembled from its source convs by red_total > 0 jobs == the plain pack of the concatenated virtual filter."""
+    o = ops()
+    gen = torch.Generator().manual_seed(77 + int(transpose))
+    c_lo, c_n = 32, 48
+    srcs = [torch.randn((co, ci, 3, 3, 3), generator=gen).to(DEV) for co, ci in ((32, 96), (16, 128), (32, 160))]
+    virt = torch.cat([w[:, c_lo:c_lo + c_n] for w in srcs], 0).contiguous()  # (80, 48, 3, 3, 3)
+    ref = o.pack_filter_frag(virt, transpose=transpose)
+    out = torch.full_like(ref, float("nan"))
+    jobs, off, tot = [], 0, virt.shape[0]
+    for w in srcs:
+        jobs.append((w, out, transpose, c_lo, c_n, off, tot, 0, c_n) if transpose else
+                    (w, out, transpose, c_lo, c_n, 0, c_n, off, tot))
+        off += w.shape[0]
+    o.pack_filter_frag_multi(o.pack_job_table(jobs))
+    torch.cuda.synchronize()
+    assert torch.equal(out.view(torch.int16), ref.view(torch.int16))

@@ -18,6 +18,7 @@ if __name__ == "__main__":
             os.environ.pop(var, None)
         else:
             os.environ[var] = v
+        bench_conv.o._lib.lib().wsr_reload_env()  # (the switches are cached per call site)
         print(f"---- {var}={v or '(unset)'}", flush=True)
         for c in cases:
             bench_conv.CASES[c]()
