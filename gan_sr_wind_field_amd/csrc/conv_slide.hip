@@ -74,7 +74,7 @@ struct CsArgs {
   unsigned long long* stamps;  // -DWSR_CS_STAMPS builds: [workgroup][wave 8][8] cycle sums per loop phase (else unused)
 };
 
-#ifdef WSR_CS_STAMPS
+#if defined(WSR_CS_STAMPS) && WSR_CS_STAMPS != 2
 #define CS_T(var) const long long var = clock64()
 #define CS_ACC(k, t0, t1) st_sum[k] += (t1) - (t0)
 #else
@@ -112,6 +112,9 @@ __global__ __launch_bounds__(512) void conv_slide_fwd_kernel(const CsArgs a) {
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
   const int kg = wave & 3, mh = wave >> 2;  // K group, m-tile half (m-tiles 2mh, 2mh + 1)
   const int fr = lane & 15, fg = lane >> 4;
+#ifdef WSR_CS_STAMPS
+  const long long st_wall0 = wall_clock64();  // (100 MHz)
+#endif
 
   // ---- which column --------------------------------------------------------------------------------
   unsigned bid = (unsigned)xcd_remap(blockIdx.x, gridDim.x);
@@ -306,62 +309,96 @@ __global__ __launch_bounds__(512) void conv_slide_fwd_kernel(const CsArgs a) {
   }
 #ifdef WSR_CS_STAMPS
   long long st_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  const long long st_wall1 = wall_clock64();
   const long long st_begin = clock64();
 #endif
+  // The iteration's one barrier sits in the MIDDLE of the plane's matrix work (after MB of its NPW MFMA groups): a wave
+  // that arrives early waits while its SIMD partner still issues MFMAs, and the serial part of a plane - partial sums
+  // to LDS, first fragments of the next plane, the wait for the landed DMA - runs under the partner's MFMAs instead of
+  // with an empty pipe (at the end of the plane it cost ~550 of 2 750 cycles per plane).  What the barrier orders:
+  //  * partial sums written at the end of iteration p-1  ->  summed by the finalizers after the barrier of iteration p;
+  //  * every wave is done with plane p-1  ->  its buffer takes plane p + NB - 1 (DMA issued behind the later groups);
+  //  * plane p+1 has landed (counted wait of the DMA waves in front of the barrier)  ->  its first fragments are
+  //    requested at the end of iteration p.
+  constexpr int MB = 2;
+  static_assert(NPW > MB + 1, "the groups behind the barrier carry the DMA issue and the finalizer");
+  constexpr int UPG = (UPW + (NPW - MB) - 1) / (NPW - MB);  // DMA instructions behind each MFMA group after the barrier
   for (int p = 0; p < n_in; ++p) {
     CS_T(t0);
-    // The buffer of plane p - 1 (all waves are past the barrier that closed it) takes plane p + NB - 1.  Its DMA
-    // instructions are issued BETWEEN the MFMA groups below, one per group: issued in a block they cost the DMA waves
-    // 600-800 cycles per plane in front of their matrix work (in-kernel stamps), and the output stores of the
-    // finalizing waves queued behind them for another ~1 300.
     int s_nxt = slot + NB - 1;
     if (s_nxt >= NB) s_nxt -= NB;
     const cs_srd_t srd_nxt = plane_srd(xin0 + p + NB - 1, p + NB - 1 < n_in);
     const unsigned dst_nxt = ring_lds + (unsigned)s_nxt * PLANE_B;
-    constexpr int UPG = (UPW + NPW - 1) / NPW;  // DMA instructions behind each MFMA group
     CS_T(t1);
     CS_ACC(0, t0, t1);
     const char* pl = smem + slot * PLANE_B;
-    // partial sums of output plane p - KX (completed by input plane p - 1): requested now, summed behind the MFMAs
     f32x4_t part[3];
     const char* scr_prev = scratch + ((p - 1) & 1) * SCR_B;
-    if (fin) {
-#pragma unroll
-      for (int g3 = 0; g3 < 3; ++g3) part[g3] = *reinterpret_cast<const f32x4_t*>(scr_prev + rd_off[g3]);
-    }
 #pragma unroll
     for (int j = 0; j < NPW; ++j) {
-      __builtin_amdgcn_sched_barrier(0);
+      if (j == MB) {
+        wait_landed(young_loop{});  // plane p + 1 has landed; the three planes issued after it stay in flight
+        __syncthreads();
+        // partial sums of output plane p - KX (completed by input plane p - 1): requested now, summed behind the MFMAs
+        if (fin) {
 #pragma unroll
-      for (int kx = 0; kx < KX; ++kx) {
-        mma_chunk<BF16>(acc[kx][0], wreg[kx][j], xa[j % D]);
-        mma_chunk<BF16>(acc[kx][1], wreg[kx][j], xb[j % D]);
+          for (int g3 = 0; g3 < 3; ++g3) part[g3] = *reinterpret_cast<const f32x4_t*>(scr_prev + rd_off[g3]);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#ifdef WSR_CS_ABL_NOMFMA
+      if (a.N > 1000)  // (tuning build: the matrix work is skipped, everything else runs)
+#endif
+      if (j == 0) {
+        // The accumulator set SHIFTS here, for free: the first MFMA of output plane p - kx takes the sums of tap
+        // columns < kx from the registers of acc[kx - 1] as its C operand and writes acc[kx] (descending kx: every
+        // source is read before it is overwritten); acc[0] opens from zero.
+#pragma unroll
+        for (int kx = KX - 1; kx >= 0; --kx) {
+          const f32x4_t c0 = kx ? acc[kx - 1][0] : f32x4_t{0.f, 0.f, 0.f, 0.f};
+          const f32x4_t c1 = kx ? acc[kx - 1][1] : f32x4_t{0.f, 0.f, 0.f, 0.f};
+          acc[kx][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wreg[kx][0]),
+                                                               __builtin_bit_cast(bf16x8_t, xa[0]), c0, 0, 0, 0);
+          acc[kx][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wreg[kx][0]),
+                                                               __builtin_bit_cast(bf16x8_t, xb[0]), c1, 0, 0, 0);
+        }
+      } else {
+        // (descending kx in every group: the accumulators that complete with this plane, acc[KX - 1], get their last
+        // MFMAs first and are out of the pipe when the partial sums are written below)
+#pragma unroll
+        for (int kx = KX - 1; kx >= 0; --kx) {
+          mma_chunk<BF16>(acc[kx][0], wreg[kx][j], xa[j % D]);
+          mma_chunk<BF16>(acc[kx][1], wreg[kx][j], xb[j % D]);
+        }
       }
       if (j + D < NPW) {
         xa[j % D] = *reinterpret_cast<const uint4*>(pl + woff[j + D]);
         xb[j % D] = *reinterpret_cast<const uint4*>(pl + woff[j + D] + 16 * ROWB);
       }
       __builtin_amdgcn_sched_barrier(0);
+      // The DMA instructions of plane p + NB - 1 are issued BETWEEN the MFMA groups, UPG per group: issued in a block
+      // they cost the DMA waves 600-800 cycles per plane in front of their matrix work (in-kernel stamps), and the
+      // output stores of the finalizing waves queued behind them for another ~1 300.
+#ifdef WSR_CS_ABL_NODMA
+      if (a.N > 1000)  // (tuning build: no plane is fetched after the prologue)
+#endif
+      if (j >= MB) {
 #pragma unroll
-      for (int k = j * UPG; k < (j + 1) * UPG && k < UPW; ++k)
-        if (dma_wave && dw + 4 * k < NU) cs_bufdma16(srd_nxt, uoff[k], dst_nxt + udst[k]);
-      if (j == 1 && fin) finalize(part, own_prev, p - KX);  // (its LDS reads have long landed)
+        for (int k = (j - MB) * UPG; k < (j - MB + 1) * UPG && k < UPW; ++k)
+          if (dma_wave && dw + 4 * k < NU) cs_bufdma16(srd_nxt, uoff[k], dst_nxt + udst[k]);
+      }
+      if (j == MB + 1 && fin) finalize(part, own_prev, p - KX);  // (its LDS reads have long landed)
     }
     __builtin_amdgcn_sched_barrier(0);
     CS_T(t2);
     CS_ACC(1, t1, t2);
-    CS_T(t3);
-    CS_ACC(2, t2, t3);
-    // ---- output plane p - (KX - 1) is complete: partial sums -> LDS, accumulator set shifts --------------------
+    // ---- output plane p - (KX - 1) is complete: partial sums -> LDS (the set shifts at the first MFMAs of the next plane)
     const f32x4_t acc0 = acc[KX - 1][0], acc1 = acc[KX - 1][1];
-#pragma unroll
-    for (int kx = KX - 1; kx > 0; --kx) { acc[kx][0] = acc[kx - 1][0]; acc[kx][1] = acc[kx - 1][1]; }
-    acc[0][0] = acc[0][1] = f32x4_t{0.f, 0.f, 0.f, 0.f};
     char* scr = scratch + (p & 1) * SCR_B;
     if (!fin0) *reinterpret_cast<f32x4_t*>(scr + wr0) = acc0;
     if (!fin1) *reinterpret_cast<f32x4_t*>(scr + wr1) = acc1;
     own_prev = fin0 ? acc0 : acc1;
-    {  // first fragments of plane p + 1 (published by the previous barrier)
+    {  // first fragments of plane p + 1 (published by this iteration's barrier)
       int sn = slot + 1;
       if (sn >= NB) sn -= NB;
       const char* pn = smem + sn * PLANE_B;
@@ -372,19 +409,20 @@ __global__ __launch_bounds__(512) void conv_slide_fwd_kernel(const CsArgs a) {
       }
     }
     CS_T(t4);
-    CS_ACC(3, t3, t4);
-    wait_landed(young_loop{});  // plane p + 2 has landed; the three planes issued after it stay in flight
-    CS_T(t5);
-    CS_ACC(4, t4, t5);
-    __syncthreads();
-    CS_T(t6);
-    CS_ACC(5, t5, t6);
+    CS_ACC(3, t2, t4);
     if (++slot == NB) slot = 0;
   }
+  __syncthreads();  // the last plane's partial sums
 #ifdef WSR_CS_STAMPS
   if (a.stamps && lane == 0) {
     unsigned long long* q = a.stamps + ((size_t)blockIdx.x * 8 + wave) * 8;
+#if WSR_CS_STAMPS == 2  // wall-clock mode: where the launch's time goes around the loop
+    q[0] = (unsigned long long)st_wall0;
+    q[1] = (unsigned long long)st_wall1;
+    q[2] = (unsigned long long)wall_clock64();
+#else
     for (int k = 0; k < 6; ++k) q[k] = (unsigned long long)st_sum[k];
+#endif
     q[6] = (unsigned long long)(clock64() - st_begin);
     q[7] = (unsigned long long)n_in;
   }
@@ -397,6 +435,9 @@ __global__ __launch_bounds__(512) void conv_slide_fwd_kernel(const CsArgs a) {
     finalize(part, own_prev, n_in - KX);
   }
   cs_dma_wait();  // (zero-record planes issued past the end still write LDS: they must not outlive the workgroup)
+#if defined(WSR_CS_STAMPS) && WSR_CS_STAMPS == 2
+  if (a.stamps && lane == 0) a.stamps[((size_t)blockIdx.x * 8 + wave) * 8 + 3] = (unsigned long long)wall_clock64();
+#endif
 }
 
 template <int KX, int KY, int OC>

@@ -88,6 +88,17 @@ __device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_addr) {
       : "memory");
 }
 __device__ __forceinline__ void dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+// wait until at most n (uniform, run-time) of this wave's DMA units are still in flight
+__device__ __forceinline__ void dma_wait_upto(int n) {
+#define WG_VM(k) case k: asm volatile("s_waitcnt vmcnt(" #k ")" ::: "memory"); break;
+  switch (n) {
+    WG_VM(0) WG_VM(1) WG_VM(2) WG_VM(3) WG_VM(4) WG_VM(5) WG_VM(6) WG_VM(7) WG_VM(8) WG_VM(9) WG_VM(10) WG_VM(11)
+    WG_VM(12) WG_VM(13) WG_VM(14) WG_VM(15) WG_VM(16) WG_VM(17) WG_VM(18) WG_VM(19) WG_VM(20) WG_VM(21) WG_VM(22)
+    WG_VM(23) WG_VM(24) WG_VM(25) WG_VM(26) WG_VM(27) WG_VM(28) WG_VM(29) WG_VM(30) WG_VM(31) WG_VM(32) WG_VM(33)
+    default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+#undef WG_VM
+}
 
 // 32-byte block swizzle of the dy image: 8 consecutive voxels x one n-tile -> 8 distinct 32-byte bank slots
 // (128-byte rows, TN <= 4: two voxels per 256-byte bank row; 256-byte rows, TN = 8: one)
@@ -369,18 +380,31 @@ __global__ __launch_bounds__(512) void wgrad_tile_kernel(const WgtArgs a) {
   };
 
   if (a.prio && wave >= WAVES / 2) __builtin_amdgcn_s_setprio(1);
-  // Software pipeline over the tile list: iteration `it` prefetches tile s0 + it*S into buffer it&1 while
-  // tile s0 + (it-1)*S is contracted out of the other buffer (one DMA call site, one MFMA call site).
+  // Software pipeline over the tile list, a ring of a.nbuf buffers (DT = nbuf - 1 tiles ahead): iteration `it` requests
+  // tile s0 + it*S into buffer it % nbuf while tile s0 + (it-DT)*S is contracted (one DMA call site, one MFMA call
+  // site).  Two buffers for the convs with taps - their tile's MFMAs outlast its DMA; the 1x1x1 filter gradient
+  // contracts a tile in a fraction of its transfer time, and with one tile in flight every tile paid the full HBM
+  // latency: four buffers of 64 voxels, counted waits (every tile is the same number of DMA units per wave).
+  const int DT = a.nbuf - 1;
+  int upt = 0;  // DMA units this wave issues per tile
+#pragma unroll
+  for (int k = 0; k < XK; ++k) upt += (wave + WAVES * k < XU) ? 1 : 0;
+#pragma unroll
+  for (int k = 0; k < YK; ++k) upt += (wave + WAVES * k < YU) ? 1 : 0;
+  const int ntl = (a.ntiles - s0 + a.S - 1) / a.S;  // tiles of this workgroup
+  int bi = 0, bc = 0;                                // ring positions: next to fill, next to contract
   for (int it = 0;; ++it) {
     const int pre = s0 + it * a.S;
 #ifdef WSR_CT_STAMPS
-    if (pre < a.ntiles && !((a.ablate & 1) && it > 0)) issue_tile(pre, it & 1);
+    if (pre < a.ntiles && !((a.ablate & 1) && it > 0)) issue_tile(pre, bi);
 #else
-    if (pre < a.ntiles) issue_tile(pre, it & 1);
+    if (pre < a.ntiles) issue_tile(pre, bi);
 #endif
-    if (it > 0) {
-      const char* Xs = buf0 + ((it - 1) & 1) * a.buf_bytes;
+    bi = bi + 1 == a.nbuf ? 0 : bi + 1;
+    if (it >= DT) {
+      const char* Xs = buf0 + bc * a.buf_bytes;
       const char* Ys = Xs + a.xs_bytes;
+      bc = bc + 1 == a.nbuf ? 0 : bc + 1;
       if constexpr (LEAN) {
         // One x fragment ahead (ring of two): the transposing reads of slot j+1 are in flight during the MFMAs of
         // slot j; the scheduler is fenced, or it sinks the request back to its use and every slot pays an LDS round
@@ -453,13 +477,20 @@ __global__ __launch_bounds__(512) void wgrad_tile_kernel(const WgtArgs a) {
 #ifdef WSR_CT_STAMPS
     const long long tw0 = clock64();
 #endif
-    dma_wait();
-    __syncthreads();  // the prefetched tile has landed for everybody; the buffer just read is free again
+    {  // the tile contracted next (it - DT + 1) must have landed; the younger ones stay in flight
+      const int tnext = it - DT + 1;
+      if (tnext >= 0) {
+        int later = ntl - 1 - tnext;
+        later = later < 0 ? 0 : (later > it - tnext ? it - tnext : later);
+        dma_wait_upto(later * upt);
+      }
+      __syncthreads();  // ... for everybody; the buffer just read is free again
 #ifdef WSR_CT_STAMPS
-    st_bar += clock64() - tw0;
-    ++st_tiles;
+      st_bar += clock64() - tw0;
+      ++st_tiles;
 #endif
-    if (pre >= a.ntiles) break;
+      if (tnext >= 0 && tnext >= ntl) break;
+    }
   }
   WG_STAMP(2);
 
@@ -523,11 +554,14 @@ int launch_tile(WgtArgs& a, hipStream_t st) {
   if (a.KZ == 1 && a.KX * a.KY > 1 && tz > 4 && a.Zo % 4 == 0 && !WSR_ENV_SET("WSR_CT_NOFLAT")) tz = 4;
   static const int cand[][2] = {{8, 8}, {4, 8}, {4, 4}, {2, 4}, {2, 2}, {1, 2}, {1, 1}};
   int best = -1, best_nbuf = 0;
-  for (int nbuf = 2; nbuf >= 2 && best < 0; --nbuf) {  // the kernel is written for two buffers
+  // (taps: two buffers; 1x1x1: a deeper ring of smaller tiles, see the kernel's pipeline comment)
+  const int nbuf_want = taps == 1 ? WSR_ENV_INT("WSR_WG_NBUF", 4) : 2;
+  const int mmax = taps == 1 && nbuf_want > 2 ? WSR_ENV_INT("WSR_WG_MMAX", 64) : 1 << 30;
+  for (int nbuf = nbuf_want; nbuf >= 2 && best < 0; --nbuf) {
     for (int ci = 0; ci < 7; ++ci) {
       const int tx = cand[ci][0], ty = cand[ci][1];
       const int M = tx * ty * tz;
-      if (M & 31) continue;
+      if ((M & 31) || M > mmax) continue;
       if (a.ups && ((tx | ty) & 1)) continue;  // the x0 - px parity must not depend on the tile
       const int L = (tx + a.KX - 1) * (ty + a.KY - 1) * (tz + a.KZ - 1);
       const int xs = CT * round_up(L * 32, 1024), ys = round_up(M * (TN <= 4 ? 128 : 256), 1024);

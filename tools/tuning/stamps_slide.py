@@ -22,6 +22,15 @@ e0.record(); fn(); e1.record()
 torch.cuda.synchronize()
 s = stamps.cpu().numpy().reshape(256, 8, 8).astype(float)
 print(f"event {e0.elapsed_time(e1) * 1e3:.1f} us; planes {s[0, 0, 7]:.0f}")
+if os.environ.get("WSR_CS_WALL"):  # library built with WSR_CS_STAMPS_MODE=2: wall-clock (100 MHz) stamps around the loop
+    w0 = s[:, :, 0].min()
+    us = lambda a: (a - w0) / 100.0
+    print("kernel entry  (us after the first wave): mean %.1f max %.1f" % (us(s[:, :, 0]).mean(), us(s[:, :, 0]).max()))
+    print("loop start    mean %.1f  min %.1f max %.1f" % (us(s[:, :, 1]).mean(), us(s[:, :, 1]).min(), us(s[:, :, 1]).max()))
+    print("loop end      mean %.1f  min %.1f max %.1f" % (us(s[:, :, 2]).mean(), us(s[:, :, 2]).min(), us(s[:, :, 2]).max()))
+    print("kernel end    mean %.1f  min %.1f max %.1f" % (us(s[:, :, 3]).mean(), us(s[:, :, 3]).min(), us(s[:, :, 3]).max()))
+    print("loop clocks per plane %.0f -> shader clock %.0f MHz" % ((s[:, :, 6] / s[:, :, 7]).mean(), (s[:, :, 6] / (s[:, :, 2] - s[:, :, 1]) * 100).mean()))
+    sys.exit(0)
 names = ["dma issue", "reads+mfma", "finalize", "partial wr", "vmcnt wait", "barrier"]
 for wv in range(8):
     per = s[:, wv, :6].mean(axis=0) / s[:, wv, 7].mean()

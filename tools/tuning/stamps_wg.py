@@ -39,8 +39,12 @@ def run(name, cin, cout, k, xyz, in_ctot, out_ctot, out_off, tri=None, ups=False
         (s[:, 4] / s[:, 5]).mean(), tiles, (us(s[:, 2] - s[:, 1]) * clk / s[:, 5]).mean(), clk, us(s[:, 3].max() - t0)))
 
 LR = (32, 32, 128)
-run("lr_conv 128->128 k3", 128, 128, (3, 3, 3), LR, 128, 128, 0)
-run("rdb stacked (4 convs) k3", 224, 128, (3, 3, 3), LR, 256, 256, 128, tri=(128, 32))
-run("up2 128->128 k3 (64^2 -> 128^2)", 128, 128, (3, 3, 3), (64, 64, 128), 128, 128, 0, ups=True)
-run("hr0 144->144 k5", 144, 144, (5, 5, 5), (128, 128, 128), 144, 144, 0)
-run("lff 256->128 k1", 256, 128, (1, 1, 1), LR, 256, 128, 0)
+CASES = {
+    "lr": lambda: run("lr_conv 128->128 k3", 128, 128, (3, 3, 3), LR, 128, 128, 0),
+    "rdb": lambda: run("rdb stacked (4 convs) k3", 224, 128, (3, 3, 3), LR, 256, 256, 128, tri=(128, 32)),
+    "up": lambda: run("up2 128->128 k3 (64^2 -> 128^2)", 128, 128, (3, 3, 3), (64, 64, 128), 128, 128, 0, ups=True),
+    "hr0": lambda: run("hr0 144->144 k5", 144, 144, (5, 5, 5), (128, 128, 128), 144, 144, 0),
+    "lff": lambda: run("lff 256->128 k1", 256, 128, (1, 1, 1), LR, 256, 128, 0),
+}
+for n in (sys.argv[1:] or list(CASES)):
+    CASES[n]()
