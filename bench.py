@@ -203,6 +203,9 @@ def main():
     ap.add_argument("--dry-launch", action="store_true", help="rendezvous of the N ranks only (CPU, gloo)")
     ap.add_argument("--master-port", type=int, default=None)
     ap.add_argument("--no-comm-timing", action="store_true", help="no HIP events around the collectives")
+    ap.add_argument("--single-rank-group", action="store_true",
+                    help="with --gpus 1: run the data-parallel step over a process group of ONE rank (every collective "
+                         "goes through RCCL; what the DP machinery costs before any second GPU)")
     args = ap.parse_args()
     if args.gpus < 1:
         ap.error("--gpus must be >= 1")
@@ -231,8 +234,8 @@ def main():
         os.environ["LOCAL_RANK"] = "0"
     dev = torch.device(f"cuda:{local}")
     torch.cuda.set_device(dev)
-    distributed = wdist.init_from_env(args.backend)
-    assert distributed == (world > 1)
+    distributed = wdist.init_from_env(args.backend, single_rank=args.single_rank_group)
+    assert distributed == (world > 1 or args.single_rank_group)
     rccl_ranks = 1
     if distributed:  # an actual collective, not the environment: this many ranks answered
         ones = torch.ones(1, device=dev)

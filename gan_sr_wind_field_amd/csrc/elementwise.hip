@@ -366,6 +366,39 @@ __global__ void bn_mean_kernel(const float* __restrict__ sums, const float* coun
   mean[c] = sums[c] / cnt;
 }
 
+// SyncBN, the per-channel algebra around its one collective (reference torch_blocks.py:20-25 under data parallelism;
+// engine.py DiscriminatorProgram.forward): every rank sends its local mean and its local centred second moment
+//   send[g][c] = mean_r ,  send[g][C + c] = M2_r = sum d^2 - (sum d)^2 / n      (d = x - mean_r; sum d is ~0, not 0)
+// and combines the gathered shards by the pairwise rule for equal counts (Chan et al.), ranks added in index order:
+//   mean = avg_r mean_r ,  M2 = sum_r M2_r + n * sum_r (mean_r - mean)^2
+// written where bn_finalize reads them (work[g][c] = mean; s2[g][c] = 0, s2[g][C + c] = M2).  Was ~12 torch ops per layer.
+__global__ void bn_shard_stats_kernel(const float* __restrict__ work, int work_stride, const float* __restrict__ s2,
+                                      int s2_stride, float count, float* __restrict__ send, int G, int C) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= G * C) return;
+  const int g = i / C, c = i - g * C;
+  const float sd = s2[(long)g * s2_stride + c], sdd = s2[(long)g * s2_stride + C + c];
+  send[(long)g * 2 * C + c] = work[(long)g * work_stride + c];
+  send[(long)g * 2 * C + C + c] = sdd - sd * sd / count;
+}
+
+__global__ void bn_combine_shards_kernel(const float* __restrict__ allr, int world, float count, float* __restrict__ work,
+                                         int work_stride, float* __restrict__ s2, int s2_stride, int G, int C) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= G * C) return;
+  const int g = i / C, c = i - g * C;
+  const long rs = (long)G * 2 * C;  // one rank's record
+  const float* p = allr + (long)g * 2 * C + c;
+  float msum = 0.f, m2 = 0.f;
+  for (int r = 0; r < world; ++r) { msum += p[r * rs]; m2 += p[r * rs + C]; }
+  const float mean = msum / (float)world;
+  float dev = 0.f;
+  for (int r = 0; r < world; ++r) { const float d = p[r * rs] - mean; dev += d * d; }
+  work[(long)g * work_stride + c] = mean;
+  s2[(long)g * s2_stride + c] = 0.f;
+  s2[(long)g * s2_stride + C + c] = m2 + count * dev;
+}
+
 // from the shifted sums {sum d, sum d^2}, d = x - mean: biased variance, invstd, running-stat update
 // (nn.BatchNorm3d: momentum update with the unbiased variance)
 __global__ void bn_finalize_kernel(const float* __restrict__ sums2, const float* count_dev, float count_host,
@@ -977,6 +1010,25 @@ extern "C" int wsr_bn_mean(const float* sums, const float* count_dev, float coun
   if (!sums || !mean || C <= 0 || (!count_dev && !(count_host > 0.f))) return WSR_EINVAL;
   hipLaunchKernelGGL(bn_mean_kernel, dim3((C + 255) / 256), dim3(256), 0, as_stream(stream), sums, count_dev,
                      count_host, mean, C);
+  WSR_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int wsr_bn_shard_stats(const float* work, int32_t work_stride, const float* s2, int32_t s2_stride, float count,
+                                  float* send, int32_t G, int32_t C, void* stream) {
+  if (!work || !s2 || !send || G <= 0 || C <= 0 || work_stride < C || s2_stride < 2 * C || !(count > 0.f)) return WSR_EINVAL;
+  hipLaunchKernelGGL(bn_shard_stats_kernel, dim3((G * C + 255) / 256), dim3(256), 0, as_stream(stream), work, work_stride,
+                     s2, s2_stride, count, send, G, C);
+  WSR_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int wsr_bn_combine_shards(const float* gathered, int32_t world, float count, float* work, int32_t work_stride,
+                                     float* s2, int32_t s2_stride, int32_t G, int32_t C, void* stream) {
+  if (!gathered || !work || !s2 || world <= 0 || G <= 0 || C <= 0 || work_stride < C || s2_stride < 2 * C || !(count > 0.f))
+    return WSR_EINVAL;
+  hipLaunchKernelGGL(bn_combine_shards_kernel, dim3((G * C + 255) / 256), dim3(256), 0, as_stream(stream), gathered, world,
+                     count, work, work_stride, s2, s2_stride, G, C);
   WSR_LAUNCH_CHECK();
   return 0;
 }

@@ -43,12 +43,18 @@ def _timed(kind: str, t: "Tensor"):
     return _STATS[0].bracket(kind, t) if _STATS[0] is not None else _NULL_BRACKET
 
 
-def init_from_env(backend: Optional[str] = None) -> bool:
+def init_from_env(backend: Optional[str] = None, single_rank: bool = False) -> bool:
     """Initialise the default process group from torchrun's environment.  Returns False
-    (and does nothing) for a single-process run."""
+    (and does nothing) for a single-process run - unless ``single_rank``: then a group of ONE rank is set up, so that
+    every collective of the data-parallel step (gradient buckets, SyncBN statistics, loss scalars) goes through the
+    real transport (RCCL on a one-GPU box) and can be checked / timed there."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world <= 1:
+    if world <= 1 and not single_rank:
         return False
+    if world <= 1:
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
+        os.environ.setdefault("LOCAL_RANK", "0")
     if not dist.is_initialized():
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
@@ -242,14 +248,17 @@ class DataParallel:
         self.stats.add("grad", t)
 
     # ---- gradient buckets ------------------------------------------------------------
-    def grad_ready(self, key, flat: Tensor, lo: int, hi: int) -> None:
-        """range [lo, hi) of ``flat`` is final; launch a collective once a bucket is full"""
+    def grad_ready(self, key, flat: Tensor, lo: int, hi: int, before_launch=None) -> None:
+        """range [lo, hi) of ``flat`` is final (once ``before_launch()`` - the program's pending moves into the flat
+        buffer - has run); launch a collective once a bucket is full"""
         cur = self._open.get(key)
         if cur is None or cur[0] is not flat:
             cur = [flat, lo, lo]
             self._open[key] = cur
         cur[2] = hi
         if cur[2] - cur[1] >= self.bucket_elems:
+            if before_launch is not None:
+                before_launch()
             self._avg_async(flat[cur[1]:cur[2]])
             cur[1] = cur[2]
 
@@ -302,7 +311,7 @@ class DataParallel:
         if progG is None:
             hook_params(gan.G)
         if progG is not None:
-            progG.grad_ready_hook = lambda flat, lo, hi: self.grad_ready("G", flat, lo, hi)
+            progG.grad_ready_hook = lambda flat, lo, hi, pre=None: self.grad_ready("G", flat, lo, hi, pre)
             progG.grad_done_hook = lambda: self.grad_done("G")
         if getattr(gan, "D", None) is not None:
             self.broadcast_module(gan.D)
@@ -311,7 +320,7 @@ class DataParallel:
             if progD is None:
                 hook_params(feats)
             if progD is not None:
-                progD.grad_ready_hook = lambda flat, lo, hi: self.grad_ready("D", flat, lo, hi)
+                progD.grad_ready_hook = lambda flat, lo, hi, pre=None: self.grad_ready("D", flat, lo, hi, pre)
                 progD.grad_done_hook = lambda: self.grad_done("D")
                 if self.sync_bn:
                     progD.stat_allreduce = self.stat_allreduce

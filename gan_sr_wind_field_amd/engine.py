@@ -245,8 +245,8 @@ class ProgramBase:
         self.dt = dt
         self.e = ops.piece_elems(dt)
         self.filters = FilterCache()
-        #: optional hook(flat_grad, lo, hi) called when grad range [lo, hi) is final
-        self.grad_ready_hook: Optional[Callable[[Tensor, int, int], None]] = None
+        #: optional hook(flat_grad, lo, hi, flush) called when grad range [lo, hi) is final once flush() has run
+        self.grad_ready_hook: Optional[Callable[[Tensor, int, int, Callable[[], None]], None]] = None
         #: optional hook() called at the end of backward (flush + wait for gradient collectives)
         self.grad_done_hook: Optional[Callable[[], None]] = None
         #: optional hook(tag, fn) used by bench.py to time selected launches; fn() issues them
@@ -986,10 +986,11 @@ class GeneratorProgram(ProgramBase):
             nonlocal done
             if self.grad_ready_hook is None:
                 return
-            self.flush_unpack()  # the gradients of `params` must be in the flat buffer before it is reduced
+            # (the gradients of a bucket must be in the flat buffer before it is reduced: the hook calls flush_unpack
+            # right before it launches a collective - flushing at every call cost 50 extra unpack launches per step)
             hi = max(sp.offsets[id(p)][0] + (sp.offsets[id(p)][1] + 63) // 64 * 64 for p in params)
             if hi > done:
-                self.grad_ready_hook(flat, done, hi)
+                self.grad_ready_hook(flat, done, hi, self.flush_unpack)
                 done = hi
 
         g_out = g_out.contiguous().float()
@@ -1428,13 +1429,10 @@ class DiscriminatorProgram(ProgramBase):
                 #   mean = avg_r mean_r ,  M2 = sum_r M2_r + n * sum_r (mean_r - mean)^2
                 # - no cancellation beyond the per-rank two-pass one.  (Was: two blocking all-reduces per group.)
                 s2 = st[:, 2 * C_:4 * C_]
-                m2_local = s2[:, C_:] - s2[:, :C_] ** 2 / count  # (sum d is ~0 but not exactly)
-                allr = self.stat_allgather(torch.cat([work[:, :C_], m2_local], dim=1))  # (world, G, 2C)
-                mean_r, m2_r = allr[..., :C_], allr[..., C_:]
-                gmean = mean_r.mean(dim=0)
-                s2[:, :C_] = 0.0
-                s2[:, C_:] = m2_r.sum(dim=0) + count * ((mean_r - gmean) ** 2).sum(dim=0)
-                work[:, :C_] = gmean
+                send = torch.empty((G, 2 * C_), dtype=torch.float32, device=x.device)
+                ops.bn_shard_stats(work, s2, count, send)               # {mean_r, M2_r}
+                allr = self.stat_allgather(send)                         # (world, G, 2C)
+                ops.bn_combine_shards(allr.view(-1, G, 2 * C_), count, work, s2)
                 count = float(n) * self.stat_world
             for gi in range(G):
                 yg, ag = y[gi * Bg:(gi + 1) * Bg], a[gi * Bg:(gi + 1) * Bg]
@@ -1531,9 +1529,8 @@ class DiscriminatorProgram(ProgramBase):
                 else:
                     self.wgrad(s, inp, 0, gy, 0, flat, sp, scratch)
                 if self.grad_ready_hook is not None:
-                    self.flush_unpack()
                     hi = sp.offsets[id(s.weight)][0] + (s.weight.numel() + 63) // 64 * 64
-                    self.grad_ready_hook(flat, done, hi)
+                    self.grad_ready_hook(flat, done, hi, self.flush_unpack)
                     done = hi
             if li > 0:
                 gin = self._empty(inp.shape, g)

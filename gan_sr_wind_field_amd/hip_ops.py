@@ -707,6 +707,26 @@ def bn_mean(sums: Tensor, mean: Tensor, count: float, count_dev: Optional[Tensor
     check(_lib.lib().wsr_bn_mean(_p(sums), _p(count_dev), float(count), _p(mean), mean.numel(), _stream()), "bn_mean")
 
 
+def bn_shard_stats(work: Tensor, s2: Tensor, count: float, send: Tensor) -> None:
+    """SyncBN: this rank's record ``send`` (G, 2C) = {local mean, local centred second moment} from ``work`` (G, >= C:
+    the means) and ``s2`` (G, >= 2C: the shifted sums) - rows may be strided views."""
+    G_, C_ = send.shape[0], send.shape[1] // 2
+    if work.stride(-1) != 1 or s2.stride(-1) != 1 or not send.is_contiguous():
+        raise ValueError("bn_shard_stats wants unit-stride rows")
+    check(_lib.lib().wsr_bn_shard_stats(_p(work), work.stride(0), _p(s2), s2.stride(0), float(count), _p(send), G_, C_,
+                                        _stream()), "bn_shard_stats")
+
+
+def bn_combine_shards(gathered: Tensor, count: float, work: Tensor, s2: Tensor) -> None:
+    """SyncBN: ``gathered`` (world, G, 2C) records of all ranks -> global mean in ``work[:, :C]``, {0, M2} in
+    ``s2[:, :2C]`` (what :func:`bn_finalize` reads with ``count * world``)."""
+    world, G_, C2 = gathered.shape
+    if work.stride(-1) != 1 or s2.stride(-1) != 1 or not gathered.is_contiguous():
+        raise ValueError("bn_combine_shards wants unit-stride rows")
+    check(_lib.lib().wsr_bn_combine_shards(_p(gathered), world, float(count), _p(work), work.stride(0), _p(s2),
+                                           s2.stride(0), G_, C2 // 2, _stream()), "bn_combine_shards")
+
+
 def bn_finalize(sums2: Tensor, mean: Tensor, invstd: Tensor, count: float, eps: float, momentum: float,
                 running_mean: Optional[Tensor], running_var: Optional[Tensor],
                 count_dev: Optional[Tensor] = None) -> None:

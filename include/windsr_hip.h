@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define WSR_ABI_VERSION 4
+#define WSR_ABI_VERSION 5
 
 enum wsr_dtype { WSR_F32 = 0, WSR_BF16 = 1 };
 
@@ -352,6 +352,15 @@ int wsr_bn_stats(const void* x, int32_t C, int64_t nvox, const float* shift, flo
  * nn.BatchNorm3d running-stat update (unbiased variance, `momentum`).  `count_dev` (device scalar, e.g. the
  * all-reduced voxel count under data parallelism) overrides `count_host` when not NULL.                  */
 int wsr_bn_mean(const float* sums, const float* count_dev, float count_host, float* mean, int32_t C, void* stream);
+/* ABI 5 - SyncBN around its one collective per layer (data-parallel nn.BatchNorm3d, torch_blocks.py:20-25).  G groups
+ * (D(real), D(fake)) of C channels; `work` rows hold the local means at [0, C), `s2` rows the shifted sums {sum d,
+ * sum d^2} at [0, 2C) (strides in floats).  _shard_stats writes this rank's record send (G, 2C) = {mean, M2};
+ * _combine_shards takes the gathered (world, G, 2C) records and leaves the global mean in work[:, 0:C) and {0, M2} in
+ * s2[:, 0:2C) - what wsr_bn_finalize reads with count = n * world.  Ranks are added in index order.           */
+int wsr_bn_shard_stats(const float* work, int32_t work_stride, const float* s2, int32_t s2_stride, float count, float* send,
+                       int32_t G, int32_t C, void* stream);
+int wsr_bn_combine_shards(const float* gathered, int32_t world, float count, float* work, int32_t work_stride, float* s2,
+                          int32_t s2_stride, int32_t G, int32_t C, void* stream);
 int wsr_bn_finalize(const float* sums2, const float* count_dev, float count_host, const float* mean, float eps,
                     float momentum, float* invstd, float* var_out, float* running_mean, float* running_var,
                     int32_t C, void* stream);

@@ -78,7 +78,8 @@ def _worker(rank, world, port, out_dir, dtype, bucket_mb, hr_scale, backend="glo
     from oracle.gan import synthetic_batch
 
     torch.cuda.set_device(local)
-    assert wdist.init_from_env(backend)
+    assert wdist.init_from_env(backend, single_rank=world == 1)
+    assert dist.get_world_size() == world and dist.get_backend() == backend
     gan, cfg = _build_gan(dtype, local)
     dp = wdist.attach(gan, bucket_mb=bucket_mb, sync_bn=True)
     dp.stats.timing = True
@@ -123,6 +124,29 @@ def test_two_rank_step_equals_full_batch_hip(hip, tmp_path, bucket_mb, hr_scale)
     assert comm["syncbn_collectives_per_step"] == 2 * r0["bn_layers"], comm
     assert comm["grad_bucket_collectives_per_step"] == r0["n_coll"]
     assert comm["grad_mbytes_per_step"] > 0 and comm["scalar_collectives_per_step"] >= 2
+    assert comm["timed"] and comm["exposed_grad_wait_ms_per_step"] >= 0.0
+
+
+def test_single_rank_group_runs_the_data_parallel_step_over_rccl(hip, tmp_path):
+    """A process group of ONE rank on backend "nccl": every collective of the data-parallel step - ReduceOp.AVG gradient
+    buckets on the collective stream, all_gather_into_tensor SyncBN statistics, the backward sums, the loss scalars,
+    the HIP-event ledger - goes through RCCL on the one-GPU box (the two-rank RCCL test below needs two devices), and
+    the result equals the plain single-process step on the same two samples."""
+    import sys
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    from oracle.gan import synthetic_batch
+
+    world, port = 1, _free_port()
+    mp.spawn(_worker, args=(world, port, str(tmp_path), "fp32", 0.02, 1.0, "nccl"), nprocs=world, join=True)
+    r0 = torch.load(tmp_path / "rank0.pt")
+    gan, cfg = _build_gan("fp32")
+    LR, HR, Z, x, y = synthetic_batch(2, 16, 4, 4, seed=2001)
+    ref = _two_iterations(gan, cfg, LR, HR, Z, x, y)
+    for k, v in ref.items():
+        np.testing.assert_allclose(r0[k].numpy(), v.numpy(), rtol=5e-4, atol=2e-6, err_msg=k)
+    comm = r0["comm"]
+    assert comm["syncbn_collectives_per_step"] == 2 * r0["bn_layers"], comm
+    assert comm["grad_bucket_collectives_per_step"] == r0["n_coll"] > 4
     assert comm["timed"] and comm["exposed_grad_wait_ms_per_step"] >= 0.0
 
 
