@@ -382,9 +382,8 @@ __global__ __launch_bounds__(512) void wgrad_tile_kernel(const WgtArgs a) {
   if (a.prio && wave >= WAVES / 2) __builtin_amdgcn_s_setprio(1);
   // Software pipeline over the tile list, a ring of a.nbuf buffers (DT = nbuf - 1 tiles ahead): iteration `it` requests
   // tile s0 + it*S into buffer it % nbuf while tile s0 + (it-DT)*S is contracted (one DMA call site, one MFMA call
-  // site).  Two buffers for the convs with taps - their tile's MFMAs outlast its DMA; the 1x1x1 filter gradient
-  // contracts a tile in a fraction of its transfer time, and with one tile in flight every tile paid the full HBM
-  // latency: four buffers of 64 voxels, counted waits (every tile is the same number of DMA units per wave).
+  // site).  Two buffers in every shipped launch - a tile's MFMAs and transposing reads outlast its DMA; deeper rings
+  // (counted waits: every tile is the same number of DMA units per wave) are a tuning switch, see launch_tile.
   const int DT = a.nbuf - 1;
   int upt = 0;  // DMA units this wave issues per tile
 #pragma unroll
@@ -554,8 +553,10 @@ int launch_tile(WgtArgs& a, hipStream_t st) {
   if (a.KZ == 1 && a.KX * a.KY > 1 && tz > 4 && a.Zo % 4 == 0 && !WSR_ENV_SET("WSR_CT_NOFLAT")) tz = 4;
   static const int cand[][2] = {{8, 8}, {4, 8}, {4, 4}, {2, 4}, {2, 2}, {1, 2}, {1, 1}};
   int best = -1, best_nbuf = 0;
-  // (taps: two buffers; 1x1x1: a deeper ring of smaller tiles, see the kernel's pipeline comment)
-  const int nbuf_want = taps == 1 ? WSR_ENV_INT("WSR_WG_NBUF", 4) : 2;
+  // (two buffers.  WSR_WG_NBUF = 3..: a deeper ring of smaller tiles for the 1x1x1 gradient, see the kernel's pipeline
+  // comment - measured SLOWER, 55 us against 46 at four buffers of 64 voxels: that launch is bound by the per-tile work
+  // of its transposing reads, 6 750 of 8 670 cycles per 128-voxel tile, not by the latency of one tile in flight)
+  const int nbuf_want = taps == 1 ? WSR_ENV_INT("WSR_WG_NBUF", 2) : 2;
   const int mmax = taps == 1 && nbuf_want > 2 ? WSR_ENV_INT("WSR_WG_MMAX", 64) : 1 << 30;
   for (int nbuf = nbuf_want; nbuf >= 2 && best < 0; --nbuf) {
     for (int ci = 0; ci < 7; ++ci) {
