@@ -1046,3 +1046,39 @@ def test_stacked_filter_parts_equal_the_pack_of_the_stacked_filter(hip, transpos
     o.pack_filter_frag_multi(o.pack_job_table(jobs))
     torch.cuda.synchronize()
     assert torch.equal(out.view(torch.int16), ref.view(torch.int16))
+
+
+@pytest.mark.parametrize("world,G,C_", [(1, 2, 32), (2, 2, 64), (8, 1, 256), (3, 2, 8)])
+def test_syncbn_shard_algebra_vs_float64(hip, world, G, C_):
+    """wsr_bn_shard_stats / wsr_bn_combine_shards (the per-channel algebra around SyncBN's one collective per layer)
+    against the pairwise combination of equal shards in float64: the combined mean / M2 equal the statistics of the
+    concatenated data."""
+    o = ops()
+    gen = torch.Generator().manual_seed(100 * world + C_)
+    n = 40  # values per rank, group and channel
+    data = torch.randn((world, G, n, C_), generator=gen, dtype=torch.float64) * 2.0 + 0.7
+    recs = []
+    for r in range(world):
+        x = data[r]                                         # (G, n, C)
+        mean = x.mean(dim=1)                                # local mean
+        d = x - mean[:, None, :].float().double()           # shifted by the fp32 mean the kernels hold
+        work = torch.zeros((G, 2 * C_), dtype=torch.float32, device=DEV)
+        work[:, :C_] = mean.float().to(DEV)
+        st = torch.zeros((G, 4 * C_), dtype=torch.float32, device=DEV)
+        st[:, 2 * C_:3 * C_] = d.sum(dim=1).float().to(DEV)         # sum d (~0)
+        st[:, 3 * C_:] = (d * d).sum(dim=1).float().to(DEV)         # sum d^2
+        send = torch.empty((G, 2 * C_), dtype=torch.float32, device=DEV)
+        o.bn_shard_stats(work, st[:, 2 * C_:], float(n), send)
+        recs.append(send)
+    gathered = torch.stack(recs)                            # (world, G, 2C)
+    work = torch.full((G, 2 * C_), float("nan"), dtype=torch.float32, device=DEV)
+    st = torch.full((G, 4 * C_), float("nan"), dtype=torch.float32, device=DEV)
+    o.bn_combine_shards(gathered, float(n), work, st[:, 2 * C_:])
+    torch.cuda.synchronize()
+    allx = data.permute(1, 0, 2, 3).reshape(G, world * n, C_)
+    gmean = allx.mean(dim=1)
+    m2 = ((allx - gmean[:, None, :]) ** 2).sum(dim=1)
+    np.testing.assert_allclose(work[:, :C_].cpu().double().numpy(), gmean.numpy(), rtol=2e-6, atol=2e-6)
+    assert torch.equal(st[:, 2 * C_:3 * C_].cpu(), torch.zeros((G, C_)))
+    np.testing.assert_allclose(st[:, 3 * C_:].cpu().double().numpy(), m2.numpy(), rtol=2e-5)
+    assert torch.isnan(work[:, C_:]).all() and torch.isnan(st[:, :2 * C_]).all()  # nothing else is written
