@@ -214,6 +214,12 @@ def main():
         sys.exit(launch_ranks(args, sys.argv[1:]))
     if args.dry_launch:
         return dry_launch(args)
+    # stdout carries the ONE JSON line and nothing else: RCCL prints a version banner to stdout when a communicator
+    # is made (and other libraries may chat there too) - from here on file descriptor 1 is stderr, and the line goes
+    # to the saved descriptor at the end
+    sys.stdout.flush()
+    json_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
     ini, n0, nz0, b0, dt0, kind, slicing, desc = PRESETS[args.config]
     args.ini, args.slicing = ini, slicing
     args.n = n0 if args.n is None else args.n
@@ -322,7 +328,13 @@ def main():
         loss_ok = all(bool(torch.isfinite(v).all()) for v in gan.get_G_train_loss_dict_ref().values())
         assert loss_ok, "non-finite generator loss in the timed region"
 
+    def leave():  # together: a rank that exits while another still waits in a collective hangs the launcher
+        if distributed:
+            torch.distributed.barrier()
+            torch.distributed.destroy_process_group()
+
     if rank != 0:
+        leave()
         return
     ms_per_step = elapsed / args.steps * 1e3
     # One data-parallel step is ONE global optimiser step over world * B samples (weak scaling: B per GPU is
@@ -430,7 +442,8 @@ def main():
             "value": round(tf_s * 1e12 / (step_flops / B), 6), "unit": "train-steps/s", "cores": cores, "kind": "port",
             "sample": f"oracle (PyTorch CPU restatement) full-size G+D pair at 16x16x10->64x64x10 B=1: "
                       f"{dt:.2f} s/pair = {tf_s:.3f} TFLOP/s, scaled by FLOPs to this workload's step"}
-    print(json.dumps(out))
+    print(json.dumps(out), file=json_out, flush=True)
+    leave()
 
 
 if __name__ == "__main__":
