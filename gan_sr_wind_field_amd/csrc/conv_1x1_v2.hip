@@ -66,28 +66,42 @@ __global__ __launch_bounds__(512, 4) void conv1x1_v2_kernel(const C2Args a) {
     const long v = (long)s * 16 + fr;
     return a.in + (v < a.nvox ? v : 0) * a.in_ctot + a.in_off + fg * 8;
   };
+  // The filter's loads go out FIRST: loads return in order per wave, so staged after the strips' loads the filter
+  // (and with it the barrier, and every store of the launch) waited until both strips of the wave had arrived - all
+  // reads, then all writes (27 us for 112 MB).  Now the staging completes under the strips' flight and the stores of
+  // the early strips overlap the reads of the late ones.
+  constexpr int WT = KS * NT * 64 / (WAVES * 64);  // filter fragments (16 B) per thread
+  static_assert(KS * NT * 64 % (WAVES * 64) == 0, "filter fragments divide over the threads");
+  uint4 wtmp[WT];
+  {  // n-tile pair interleave: row i of tile t' <- channel 32(t'>>1) + 8(i>>2) + 4(t'&1) + (i&3)
+    const uint4* src = reinterpret_cast<const uint4*>(a.wf);
+#pragma unroll
+    for (int q = 0; q < WT; ++q) {
+      const int idx = t + q * WAVES * 64;
+      const int l = idx & 63, tp = (idx >> 6) % NT, ks = idx / (64 * NT);
+      const int i = l & 15, g = l >> 4;
+      const int n = 32 * (tp >> 1) + 8 * (i >> 2) + 4 * (tp & 1) + (i & 3);
+      wtmp[q] = src[(ks * NT + (n >> 4)) * 64 + (n & 15) + 16 * g];
+    }
+  }
   uint4 xa[KS], xb[KS];
   if (strip < a.nstrips) {
     const unsigned short* p = xptr(strip);
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) xa[ks] = *reinterpret_cast<const uint4*>(p + ks * 32);
   }
+  {  // (the second strip is requested after the filter has left its registers: 128 VGPRs at four waves per SIMD)
+    uint4* dst = reinterpret_cast<uint4*>(smem);
+#pragma unroll
+    for (int q = 0; q < WT; ++q) dst[t + q * WAVES * 64] = wtmp[q];
+  }
+  __builtin_amdgcn_sched_barrier(0);
   if (strip + stride < a.nstrips) {
     const unsigned short* p = xptr(strip + stride);
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) xb[ks] = *reinterpret_cast<const uint4*>(p + ks * 32);
   }
-  {  // stage the filter with the n-tile pair interleave: row i of tile t' <- channel 32(t'>>1) + 8(i>>2) + 4(t'&1) + (i&3)
-    const uint4* src = reinterpret_cast<const uint4*>(a.wf);
-    uint4* dst = reinterpret_cast<uint4*>(smem);
-    for (int idx = t; idx < KS * NT * 64; idx += WAVES * 64) {
-      const int l = idx & 63, tp = (idx >> 6) % NT, ks = idx / (64 * NT);
-      const int i = l & 15, g = l >> 4;
-      const int n = 32 * (tp >> 1) + 8 * (i >> 2) + 4 * (tp & 1) + (i & 3);
-      dst[idx] = src[(ks * NT + (n >> 4)) * 64 + (n & 15) + 16 * g];
-    }
-    for (int k = t; k < NT * 16; k += WAVES * 64) btab[k] = a.bias ? a.bias[k] : 0.f;
-  }
+  for (int k = t; k < NT * 16; k += WAVES * 64) btab[k] = a.bias ? a.bias[k] : 0.f;
   __syncthreads();
   const char* wl = smem + lane * 16;
   const float rs1 = a.res ? a.beta / a.alpha : 0.f, rs2 = a.res2 ? a.beta2 / a.alpha : 0.f;
