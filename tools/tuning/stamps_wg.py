@@ -13,9 +13,16 @@ def run(name, cin, cout, k, xyz, in_ctot, out_ctot, out_off, tri=None, ups=False
     d = o.make_desc(geom, DT, B, xyz, in_ctot, 0, out_ctot, out_off)
     oxyz = (d.Xo, d.Yo, d.Zo)
     gy = torch.randn((B,) + oxyz + (out_ctot,), device=DEV, generator=g).to(DT)
-    dw = torch.zeros((cout, geom.taps, cin), dtype=torch.float32, device=DEV)
     stamps = torch.zeros((4096, 8), dtype=torch.int64, device=DEV)
-    fn = (lambda: o.conv_wgrad_tri(d, x, gy, dw, *tri)) if tri else (lambda: o.conv_wgrad(d, x, gy, dw))
+    if os.environ.get("WG_ATOMIC"):  # the first form: float atomics into one copy
+        dw = torch.zeros((cout, geom.taps, cin), dtype=torch.float32, device=DEV)
+        fn = (lambda: o.conv_wgrad_tri(d, x, gy, dw, *tri)) if tri else (lambda: o.conv_wgrad(d, x, gy, dw))
+    else:                            # what the step runs: one split copy per workgroup, plain stores
+        tb, tstep = tri if tri else (0, 0)
+        n = o.conv_wgrad_nparts(d, tb, tstep)
+        parts = torch.empty((n, cout, geom.taps, cin), dtype=torch.float32, device=DEV)
+        fn = lambda: o.conv_wgrad_parts(d, x, gy, parts, n, tb, tstep)
+        name += f" [{n} split copies, {parts.numel() * 4 / 1e6:.1f} MB]"
     for _ in range(3):
         fn()
     torch.cuda.synchronize()
