@@ -554,8 +554,9 @@ int launch_tile(WgtArgs& a, hipStream_t st) {
   static const int cand[][2] = {{8, 8}, {4, 8}, {4, 4}, {2, 4}, {2, 2}, {1, 2}, {1, 1}};
   int best = -1, best_nbuf = 0;
   // (two buffers.  WSR_WG_NBUF = 3..: a deeper ring of smaller tiles for the 1x1x1 gradient, see the kernel's pipeline
-  // comment - measured SLOWER, 55 us against 46 at four buffers of 64 voxels: that launch is bound by the per-tile work
-  // of its transposing reads, 6 750 of 8 670 cycles per 128-voxel tile, not by the latency of one tile in flight)
+  // comment - measured SLOWER, 55 us against 46 at four buffers of 64 voxels.  Ablation stamps of that launch: tile
+  // loop 34 us; without LDS reads and MFMAs still 27.6 us - the LDS-DMA stream itself, 134 MB at 5.3 TB/s, dy once per
+  // c-chunk - and without the DMA 21.5 us: it is bound by DMA THROUGHPUT, not by the latency of one tile in flight)
   const int nbuf_want = taps == 1 ? WSR_ENV_INT("WSR_WG_NBUF", 2) : 2;
   const int mmax = taps == 1 && nbuf_want > 2 ? WSR_ENV_INT("WSR_WG_MMAX", 64) : 1 << 30;
   for (int nbuf = nbuf_want; nbuf >= 2 && best < 0; --nbuf) {
