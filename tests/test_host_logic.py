@@ -226,3 +226,17 @@ def test_validation_and_checkpoint_roundtrip(monkeypatch, tmp_path):
         assert torch.equal(v, before[k]), k
     assert gan.load_model(None, "None", "null") == (None, None)
     assert "Generator:" in str(gan)
+
+
+def test_graft_entry_build_compiles_and_checks_the_library():
+    """the driver's "does it build" entry point: make (gfx950 cross-compile, no GPU needed), load, ABI version and
+    every symbol of include/windsr_hip.h"""
+    import importlib.util
+    import os
+
+    from conftest import REPO
+
+    spec = importlib.util.spec_from_file_location("graft_entry", os.path.join(REPO, "__graft_entry__.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    mod.build()
