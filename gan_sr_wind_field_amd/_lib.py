@@ -65,6 +65,10 @@ def lib() -> C.CDLL:
             f"{LIB_PATH} not found: build the gfx950 kernels first "
             "(python -c 'import __graft_entry__ as g; g.build()' or make -C gan_sr_wind_field_amd/csrc). "
             "There is no CPU / ATen fallback for the hot path.")
+    # PyTorch's own HIP runtime must be in the process BEFORE this library is: libwindsr_hip.so needs libamdhip64 by
+    # soname, and loaded first it would bring in the system's copy - two runtimes, and the kernels launch into the one
+    # that holds no device ("no ROCm-capable device", seen with build() and smoke() in one process)
+    import torch  # noqa: F401
     L = C.CDLL(LIB_PATH)
     for name in EXPORTS:
         if not hasattr(L, name):
