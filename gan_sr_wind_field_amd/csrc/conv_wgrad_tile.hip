@@ -418,6 +418,11 @@ __global__ __launch_bounds__(512) void wgrad_tile_kernel(const WgtArgs a) {
           bfr[0] = bf_of(k, 0);
 #pragma unroll
           for (int j = 0; j < SPW; ++j) {
+#ifdef WSR_CT_STAMPS
+            // (tuning build, ablate & 16: only every fourth slot reads its x fragment, the others copy the previous
+            // one - wrong sums, the timing of a kernel that derives the kz-shifted fragments in registers)
+            if ((a.ablate & 16) && ((j + 1) & 3)) { if (j + 1 < SPW) bfr[(j + 1) & 1] = bfr[j & 1]; } else
+#endif
             if (j + 1 < SPW) bfr[(j + 1) & 1] = bf_of(k, j + 1);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
