@@ -409,7 +409,9 @@ __global__ __launch_bounds__(512) void wgrad_tile_kernel(const WgtArgs a) {
         // slot j; the scheduler is fenced, or it sinks the request back to its use and every slot pays an LDS round
         // trip (counters before: waves parked at s_waitcnt half of the time).  8.65 -> 8.0 ms on the 5x5x5 144 -> 144
         // gradient.  Measured and NOT kept: carrying the ring and the dy fragments across K-steps (in-place reload
-        // after the last use: +3 %, a second dy set: spills) - the plain per-K-step form is the fastest.
+        // after the last use: +3 %, a second dy set: spills) - the plain per-K-step form is the fastest; a ring of
+        // three with the DMA geometry decoded again per border tile instead of held in 9 registers (+3 %: the
+        // allocator fills the 256 registers either way and spills 24 bytes instead of 8).
         for (int ks = 0; ks < ksteps; ++ks) {
           const KP k = kp_of(Xs, Ys, ks);
           uint4 af[TN], bfr[2];
