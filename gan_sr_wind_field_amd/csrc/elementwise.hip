@@ -851,7 +851,8 @@ extern "C" int wsr_unpack_wgrad_multi(const wsr_unpack_job_t* jobs_dev, int32_t 
 
 extern "C" int wsr_unpack_wgrad_reduce_multi(const wsr_unpack_job_t* jobs_dev, int32_t n_jobs, void* stream) {
   if (!jobs_dev || n_jobs <= 0 || n_jobs > 65535) return WSR_EINVAL;
-  hipLaunchKernelGGL(unpack_reduce_multi_kernel, dim3(128, (unsigned)n_jobs), dim3(512), 0, as_stream(stream), jobs_dev);
+  const int gx = WSR_ENV_INT("WSR_UNPACK_GRID", 128);  // (tuning aid: workgroups per job)
+  hipLaunchKernelGGL(unpack_reduce_multi_kernel, dim3((unsigned)gx, (unsigned)n_jobs), dim3(512), 0, as_stream(stream), jobs_dev);
   WSR_LAUNCH_CHECK();
   return 0;
 }
