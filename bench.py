@@ -435,12 +435,14 @@ def main():
         out["comm"]["bucket_mb"] = cfg.dist.bucket_mb
         out["comm"]["sync_bn"] = bool(cfg.dist.sync_bn)
     if world == 1 and not args.no_cpu_baseline:
-        cores = min(os.cpu_count() or 1, 16)
+        # all cores this process may run on ("all physical cores, count stated"); the affinity mask is
+        # what a container / cgroup actually grants, os.cpu_count() the host's total
+        cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
         dt, sample_flops = cpu_baseline(cores)
         tf_s = sample_flops / dt / 1e12
         out["cpu_baseline"] = {
-            "value": round(tf_s * 1e12 / (step_flops / B), 6), "unit": "train-steps/s", "cores": cores, "kind": "port",
-            "sample": f"oracle (PyTorch CPU restatement) full-size G+D pair at 16x16x10->64x64x10 B=1: "
+            "value": round(tf_s * 1e12 / (step_flops / B), 6), "unit": "train-steps/s", "cores": cores, "host_cpus": os.cpu_count(),
+            "kind": "port", "sample": f"oracle (PyTorch CPU restatement) full-size G+D pair at 16x16x10->64x64x10 B=1: "
                       f"{dt:.2f} s/pair = {tf_s:.3f} TFLOP/s, scaled by FLOPs to this workload's step"}
     print(json.dumps(out), file=json_out, flush=True)
     leave()

@@ -191,26 +191,14 @@ int launch_c1(const C1Args& a0, hipStream_t st) {
 
 }  // namespace
 
-int wsr_conv1x1_v2_bf16(const unsigned short* in, int in_ctot, int in_off, int red, const unsigned short* wfrag,
+// The superseded four-wave form (round 1).  Built only by `make TUNING=1`; conv_1x1_v2.hip's dispatcher falls back
+// to it for the shapes the 16-wave form does not cover and under WSR_C1_V1.
+int wsr_conv1x1_v1_bf16(const unsigned short* in, int in_ctot, int in_off, int red, const unsigned short* wfrag,
                         unsigned short* out, int out_ctot, int out_off, int n_out, long nvox, const float* bias,
                         const unsigned short* res, int res_ctot, int res_off, int res_c1, float alpha, float beta, int act,
                         float slope, const wsr_lrelu_mask_t* mask, const unsigned short* res2, int res2_ctot, int res2_off,
-                        float beta2, hipStream_t st);  // conv_1x1_v2.hip
-
-// Called by the tile entry points for 1x1x1 convs; WSR_EUNSUPPORTED -> the halo-tile kernel takes over.
-// `red` = reduction channels (multiple of 32), `n_out` = produced channels.
-int wsr_conv1x1_bf16(const unsigned short* in, int in_ctot, int in_off, int red, const unsigned short* wfrag,
-                     unsigned short* out, int out_ctot, int out_off, int n_out, long nvox, const float* bias,
-                     const unsigned short* res, int res_ctot, int res_off, int res_c1, float alpha, float beta, int act,
-                     float slope, const wsr_lrelu_mask_t* mask, const unsigned short* res2, int res2_ctot, int res2_off,
-                     float beta2, hipStream_t st) {
+                        float beta2, hipStream_t st) {
   if (red % 32 || red > 256 || n_out % 4 || n_out > 256) return WSR_EUNSUPPORTED;
-  {  // the 16-wave form (conv_1x1_v2.hip) for the shapes it is built for
-    const int rc = wsr_conv1x1_v2_bf16(in, in_ctot, in_off, red, wfrag, out, out_ctot, out_off, n_out, nvox, bias, res,
-                                       res_ctot, res_off, res_c1, alpha, beta, act, slope, mask, res2, res2_ctot,
-                                       res2_off, beta2, st);
-    if (rc != WSR_EUNSUPPORTED) return rc;
-  }
   if (in_ctot % 8 || in_off % 8 || out_ctot % 4 || out_off % 4 || (res && (res_ctot % 4 || res_off % 4)))
     return WSR_EUNSUPPORTED;
   C1Args a{};

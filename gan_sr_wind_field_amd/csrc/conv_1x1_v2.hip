@@ -227,13 +227,14 @@ int launch_c2(C2Args& a, hipStream_t st) {
 
 }  // namespace
 
-// Same contract as wsr_conv1x1_bf16 (conv_1x1.hip), which tries this form first for the shapes it covers.
-int wsr_conv1x1_v2_bf16(const unsigned short* in, int in_ctot, int in_off, int red, const unsigned short* wfrag,
+static int wsr_conv1x1_v2_bf16(const unsigned short* in, int in_ctot, int in_off, int red, const unsigned short* wfrag,
                         unsigned short* out, int out_ctot, int out_off, int n_out, long nvox, const float* bias,
                         const unsigned short* res, int res_ctot, int res_off, int res_c1, float alpha, float beta, int act,
                         float slope, const wsr_lrelu_mask_t* mask, const unsigned short* res2, int res2_ctot, int res2_off,
                         float beta2, hipStream_t st) {
+#ifdef WSR_TUNING
   if (WSR_ENV_SET("WSR_C1_V1")) return WSR_EUNSUPPORTED;  // tuning switch: the four-wave form
+#endif
   if (!((red == 256 && n_out == 128) || (red == 128 && n_out == 256))) return WSR_EUNSUPPORTED;
   // 16-byte accesses on every operand: channel windows on 8-channel boundaries
   if (in_ctot % 8 || in_off % 8 || out_ctot % 8 || out_off % 8) return WSR_EUNSUPPORTED;
@@ -264,4 +265,30 @@ int wsr_conv1x1_v2_bf16(const unsigned short* in, int in_ctot, int in_off, int r
   }
   if (mask) return rx ? launch_c2<16, 4, true, true>(a, st) : launch_c2<16, 4, true, false>(a, st);
   return rx ? launch_c2<16, 4, false, true>(a, st) : launch_c2<16, 4, false, false>(a, st);
+}
+
+#ifdef WSR_TUNING
+int wsr_conv1x1_v1_bf16(const unsigned short* in, int in_ctot, int in_off, int red, const unsigned short* wfrag,
+                        unsigned short* out, int out_ctot, int out_off, int n_out, long nvox, const float* bias,
+                        const unsigned short* res, int res_ctot, int res_off, int res_c1, float alpha, float beta, int act,
+                        float slope, const wsr_lrelu_mask_t* mask, const unsigned short* res2, int res2_ctot, int res2_off,
+                        float beta2, hipStream_t st);  // conv_1x1.hip (make TUNING=1)
+#endif
+
+// Called by the tile entry points for 1x1x1 convs; WSR_EUNSUPPORTED -> the halo-tile kernel takes over.
+// `red` = reduction channels, `n_out` = produced channels.
+int wsr_conv1x1_bf16(const unsigned short* in, int in_ctot, int in_off, int red, const unsigned short* wfrag,
+                     unsigned short* out, int out_ctot, int out_off, int n_out, long nvox, const float* bias,
+                     const unsigned short* res, int res_ctot, int res_off, int res_c1, float alpha, float beta, int act,
+                     float slope, const wsr_lrelu_mask_t* mask, const unsigned short* res2, int res2_ctot, int res2_off,
+                     float beta2, hipStream_t st) {
+  const int rc = wsr_conv1x1_v2_bf16(in, in_ctot, in_off, red, wfrag, out, out_ctot, out_off, n_out, nvox, bias, res,
+                                     res_ctot, res_off, res_c1, alpha, beta, act, slope, mask, res2, res2_ctot,
+                                     res2_off, beta2, st);
+#ifdef WSR_TUNING
+  if (rc == WSR_EUNSUPPORTED)
+    return wsr_conv1x1_v1_bf16(in, in_ctot, in_off, red, wfrag, out, out_ctot, out_off, n_out, nvox, bias, res, res_ctot,
+                               res_off, res_c1, alpha, beta, act, slope, mask, res2, res2_ctot, res2_off, beta2, st);
+#endif
+  return rc;
 }

@@ -36,19 +36,23 @@ int wsr_ct_run_masked(CtArgs& a, int tpk, hipStream_t st);  // conv_tile_masked.
 int wsr_ct_run_narrow_masked(CtArgs& a, int tpk, hipStream_t st);  // conv_tile_narrow_masked.hip
 int wsr_ct_run_small(CtArgs& a, int tpk, hipStream_t st);          // conv_tile_small.hip
 int wsr_ct_run_strided(CtArgs& a, int tpk, hipStream_t st);        // conv_tile_strided.hip
-int wsr_ct_run_w4(CtArgs& a, int tpk, int which, hipStream_t st);  // conv_tile_w4.hip
+#ifdef WSR_TUNING
+int wsr_ct_run_w4(CtArgs& a, int tpk, int which, hipStream_t st);  // conv_tile_w4.hip (make TUNING=1)
+#endif
 
 namespace {
 
 int dispatch_ct(CtArgs& a, int tpk, hipStream_t st) {
   const int N = a.Cout;
   if ((a.sx | a.sy | a.sz) != 1) return wsr_ct_run_strided(a, tpk, st);
+#ifdef WSR_TUNING
   if (WSR_ENV_SET("WSR_CT_W4")) {  // tuning switch: four-wave workgroups
     if ((long)a.B * a.Xo * a.Yo * a.Zo >= 128L * 512) {
       const int rc = wsr_ct_run_w4(a, tpk, WSR_ENV_RAW("WSR_CT_W4"), st);
       if (rc != WSR_EUNSUPPORTED) return rc;
     }
   }
+#endif
   // small volumes (< 128 tiles of 512 voxels): 128-voxel tiles where an instantiation exists
   if ((long)a.B * a.Xo * a.Yo * a.Zo < 128L * 512 && !WSR_ENV_SET("WSR_CT_NOSMALL")) {
     const int rc = wsr_ct_run_small(a, tpk, st);

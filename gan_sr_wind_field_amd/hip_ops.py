@@ -197,9 +197,9 @@ def conv_fwd_tile(desc: ConvDesc, x: Tensor, wfrag: Tensor, y: Tensor, *, bias: 
 
 
 def conv1x1_covers(red: int, n_out: int, masked: bool) -> bool:
-    """shapes the streaming 1x1x1 kernel is instantiated for (conv_1x1.hip, ``wsr_conv1x1_bf16``): reduction
+    """shapes the streaming 1x1x1 kernel is instantiated for (conv_1x1_v2.hip, ``wsr_conv1x1_bf16``): reduction
     channels x produced channels.  Only that kernel may run a 1x1x1 input gradient in place."""
-    shapes = {(128, 256), (128, 128)} if masked else {(256, 128), (128, 256), (128, 128)}
+    shapes = {(128, 256)} if masked else {(256, 128), (128, 256)}
     return (red, n_out) in shapes
 
 
