@@ -97,6 +97,21 @@ def make_gan(args, dev, dtype):
     return wind_field_GAN_3D(cfg), cfg
 
 
+def granted_cores():
+    """CPU cores this process may actually use: the affinity mask, cut by the cgroup's CPU quota when there is one (a
+    container on a many-core host: os.cpu_count() is the HOST's count, and that many threads on a 16-core share
+    oversubscribe - the oracle then runs many times slower than on the cores it really has)"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            quota, period = f.read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period) + 0.5)))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
+
+
 def cpu_baseline(n_threads):
     """The oracle (CPU restatement of the reference, kind "port") timed on this host:
     full-size G + D at the reference's own CPU-runnable case (16x16x10 -> 64x64x10, B=1),
@@ -115,8 +130,10 @@ def cpu_baseline(n_threads):
     gan = ogan.OracleGAN(sdG, sdD, gs, ds, ogan.TrainSpec(d_g_train_period=1))
     LR, HR, Z, x, y = ogan.synthetic_batch(1, 16, 10, 4, seed=2001)
     gan.feed_xy(x, y)
+    tw = time.time()
     gan.optimize_parameters(LR, HR, Z, 0)
     gan.optimize_parameters(LR, HR, Z, 1)
+    print(f"[bench] cpu_baseline: warm-up pair {time.time() - tw:.1f} s", file=sys.stderr, flush=True)
     t0, pairs = time.time(), 0
     while pairs < 2 or (time.time() - t0 < 12 and pairs < 8):
         gan.optimize_parameters(LR, HR, Z, 2 * pairs + 2)
@@ -261,9 +278,17 @@ def main():
     #   the dominant HBM-bound kernel:  the streaming 1x1x1 conv (LFF forward, 256 -> 128)
     #   the memory-bound conv3d launches: the last conv in z-folded form - forward (5,5,1) 144 -> 15 and its input
     #   gradient 15 -> 144 with the LeakyReLU / Dropout3d mask of the 5x5x5 conv below it in the epilogue
-    probe_events = {"mfma": [], "hbm": [], "hbm_res2": [], "conv_dgrad": [], "conv_fwd": []}
+    #   the rest of SURVEY 8(d)'s memory-bound conv3d set: terrain convs (1 -> 16, 16 -> 16 at HR resolution), the
+    #   feature conv (4 -> 128) and the discriminator's first conv (3 -> 32, D(real) and D(fake) in one launch)
+    probe_events = {"mfma": [], "hbm": [], "hbm_res2": [], "conv_dgrad": [], "conv_fwd": [], "terrain0_fwd": [],
+                    "terrain1_fwd": [], "terrain1_dgrad": [], "feature_fwd": [], "d0_fwd": []}
     timing_on = [False]
     last_conv = "hr_convs.2.zfold" if gan.G.program().zfold_active() else "hr_convs.2"
+    d0_name = gan.D.features.program().layers[0].conv.name if kind == "gan" else None
+    side_tags = {"fwd:terrain_convs.0.0": "terrain0_fwd", "fwd:terrain_convs.1.0": "terrain1_fwd",
+                 "dgrad:terrain_convs.1.0": "terrain1_dgrad", "fwd:model.0.0": "feature_fwd"}
+    if d0_name:
+        side_tags["fwd:" + d0_name] = "d0_fwd"
 
     def probe(tag, fn):
         which = None
@@ -277,6 +302,8 @@ def main():
                 which = "conv_dgrad"
             elif tag == "fwd:" + last_conv:
                 which = "conv_fwd"
+            else:
+                which = side_tags.get(tag)
         if which is None:
             fn()
             return
@@ -287,6 +314,8 @@ def main():
         probe_events[which].append((e0, e1))
 
     gan.G.program().launch_probe = probe
+    if kind == "gan":
+        gan.D.features.program().launch_probe = probe
 
     if kind == "gan":
         def step(i):
@@ -393,6 +422,26 @@ def main():
     default_shape = args.dtype == "bf16" and n == 32 and nz == 128 and B == 1 and s == 4
     if default_shape:
         conv_d["traffic"], conv_f["traffic"] = recorded_traffic("hr1_dgrad"), recorded_traffic("hr1_fwd")
+    # the other members of the memory-bound conv3d set: (Cin * V_in + Cout * V_out) * sizeof + filter
+    tf_c, nf_c = gan.G.program().tf, gan.G.program().nf
+    side = [
+        ("terrain0_fwd", "terrain_convs.0 forward (3x3x3, 1 -> %d, LeakyReLU)" % tf_c, V * (1 + tf_c) * esz + 27 * tf_c * esz),
+        ("terrain1_fwd", "terrain_convs.1 forward (3x3x3, %d -> %d into the concat window)" % (tf_c, tf_c),
+         V * 2 * tf_c * esz + 27 * tf_c * tf_c * esz),
+        ("terrain1_dgrad", "terrain_convs.1 input gradient (3x3x3, %d -> %d)" % (tf_c, tf_c),
+         V * 2 * tf_c * esz + 27 * tf_c * tf_c * esz),
+        ("feature_fwd", "model.0 feature conv forward (3x3x3, 4 -> %d)" % nf_c, vox * (4 + nf_c) * esz + 27 * 4 * nf_c * esz),
+    ]
+    if kind == "gan":
+        d0 = gan.D.features.program().layers[0].conv
+        side.append(("d0_fwd", "D features.0.0 forward (3x3x3, %d -> %d, D(real) + D(fake) in one launch)" % (d0.cin, d0.cout),
+                     2 * V * (d0.cin + d0.cout) * esz + 27 * d0.cin * d0.cout * esz))
+    side_blocks = []
+    for key, name, nbytes in side:
+        blk = hbm_block(probe_events[key], nbytes, name)
+        if default_shape:
+            blk["traffic"] = recorded_traffic(key)
+        side_blocks.append(blk)
     out = {
         "metric": "GAN train-steps/sec (G+D fwd+bwd)" if kind == "gan" else "generator train-steps/sec (G fwd+bwd+Adam)",
         "value": round(value, 4), "unit": "train-steps/s",
@@ -425,19 +474,21 @@ def main():
                          "algorithmic_bytes": int(h_bytes) if h_bytes else None, "launches_timed": h_n,
                          "launches_with_second_residual": len(h2),
                          "avg_launch_us": round(h_ms * 1e3, 2) if h_ms else None},
-        # the worse of the two memory-bound conv3d launches carries the name; both are listed
-        "roofline_hbm_conv": dict(min((conv_d, conv_f), key=lambda r: r["frac"] if r["frac"] is not None else 9.0),
+        # the WORST of the memory-bound conv3d launches carries the name; all of them are listed
+        "roofline_hbm_conv": dict(min([conv_d, conv_f] + side_blocks,
+                                      key=lambda r: r["frac"] if r["frac"] is not None else 9.0),
                                   traffic_measured_in_run=False),
-        "roofline_hbm_convs": [conv_d, conv_f],
+        "roofline_hbm_convs": [conv_d, conv_f] + side_blocks,
     }
     if dp is not None:
         out["comm"] = dp.stats.summary(args.steps)
         out["comm"]["bucket_mb"] = cfg.dist.bucket_mb
         out["comm"]["sync_bn"] = bool(cfg.dist.sync_bn)
     if world == 1 and not args.no_cpu_baseline:
-        # all cores this process may run on ("all physical cores, count stated"); the affinity mask is
-        # what a container / cgroup actually grants, os.cpu_count() the host's total
-        cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+        # all cores this process may run on ("all physical cores, count stated")
+        cores = granted_cores()
+        print(f"[bench] cpu_baseline: oracle on {cores} threads (host reports {os.cpu_count()} CPUs) ...", file=sys.stderr,
+              flush=True)
         dt, sample_flops = cpu_baseline(cores)
         tf_s = sample_flops / dt / 1e12
         out["cpu_baseline"] = {

@@ -90,20 +90,25 @@ static inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream
 // the environment per launch (~2 000 launches per step: milliseconds of host time on the launch-bound real-data
 // shapes).  Each call site now caches its value; wsr_reload_env() (C ABI) bumps the generation so that a process
 // that changes the environment at run time (the tests do) sees the new values.
-extern int g_wsr_env_gen;  // elementwise.hip
+// Thread-safe: the generation and every call site's (generation, value) pair are single atomics - a race costs a
+// second getenv, never a torn read (entry points may be called from the autograd thread and the main thread at once).
+#include <atomic>
 #include <climits>
 #include <cstdlib>
+extern std::atomic<int> g_wsr_env_gen;  // elementwise.hip
 struct WsrEnvCache {
-  int gen = -1;
-  int val = INT_MIN;  // INT_MIN: variable not set
+  std::atomic<unsigned long long> gv{~0ull};  // (generation << 32) | value bits; INT_MIN: variable not set
 };
 static inline int wsr_env_lookup(WsrEnvCache& c, const char* name) {
-  if (c.gen != g_wsr_env_gen) {
+  const int gen = g_wsr_env_gen.load(std::memory_order_acquire);
+  unsigned long long gv = c.gv.load(std::memory_order_relaxed);
+  if ((int)(gv >> 32) != gen) {
     const char* e = getenv(name);
-    c.val = e ? atoi(e) : INT_MIN;
-    c.gen = g_wsr_env_gen;
+    const int val = e ? atoi(e) : INT_MIN;
+    gv = ((unsigned long long)(unsigned)gen << 32) | (unsigned)val;
+    c.gv.store(gv, std::memory_order_relaxed);
   }
-  return c.val;
+  return (int)(unsigned)(gv & 0xFFFFFFFFull);
 }
 // value of an integer switch, or INT_MIN when it is not set
 #define WSR_ENV_RAW(name) ([]() -> int { static WsrEnvCache c_; return wsr_env_lookup(c_, name); }())

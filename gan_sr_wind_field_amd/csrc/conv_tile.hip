@@ -239,10 +239,6 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ part, long part_s
   }
 }
 
-void* g_ct_ws = nullptr;  // caller's split-reduction workspace (wsr_conv_tile_workspace)
-long g_ct_ws_bytes = 0;
-int g_ct_ws_dev = -1;     // device that was current when it was registered: launches on another device do not split
-
 }  // namespace
 
 int wsr_ct_splitk_reduce(const CtArgs& a, hipStream_t st) {
@@ -257,20 +253,12 @@ int wsr_ct_splitk_reduce(const CtArgs& a, hipStream_t st) {
   return 0;
 }
 
-extern "C" int wsr_conv_tile_workspace(void* ws, int64_t bytes) {
-  if (bytes < 0 || (ws == nullptr) != (bytes == 0)) return WSR_EINVAL;
-  g_ct_ws = ws;
-  g_ct_ws_bytes = (long)bytes;
-  g_ct_ws_dev = -1;
-  if (ws && hipGetDevice(&g_ct_ws_dev) != hipSuccess) g_ct_ws_dev = -1;
-  return 0;
-}
-
 extern "C" int wsr_pack_filter_frag_multi(const wsr_pack_job_t* jobs_dev, int32_t n_jobs, void* stream) {
   if (!jobs_dev || n_jobs <= 0 || n_jobs > 65535) return WSR_EINVAL;
   // workgroups per job: a generator's table is ~1 000 jobs of mostly 16-28 items (empty workgroups cost dispatch time),
   // a discriminator's 43 jobs of up to 512 (measured: 16 / 32 / 128 workgroups per job win at 940 / 398 / 43 jobs)
-  const int gx = WSR_ENV_INT("WSR_PK_GRID", n_jobs >= 512 ? 16 : (n_jobs >= 128 ? 32 : 128));
+  int gx = WSR_ENV_INT("WSR_PK_GRID", n_jobs >= 512 ? 16 : (n_jobs >= 128 ? 32 : 128));
+  gx = gx < 1 ? 1 : (gx > 1024 ? 1024 : gx);
   hipLaunchKernelGGL(pack_frag_multi_kernel, dim3((unsigned)gx, (unsigned)n_jobs), dim3(256), 0, as_stream(stream), jobs_dev);
   WSR_LAUNCH_CHECK();
   return 0;
@@ -331,12 +319,8 @@ static int run_conv_tile(CtArgs& a, int red, hipStream_t st) {
                  ? 1
                  : 0;
   if (a.act == 2 && !(a.vec_ok && (a.Cout & 3) == 0)) return WSR_EUNSUPPORTED;  // vector epilogue only
-  a.ws = nullptr;
-  a.ws_bytes = 0;
-  if (g_ct_ws) {  // the workspace is ONE buffer on ONE device: a launch on another device runs un-split
-    int dev = -1;
-    if (hipGetDevice(&dev) == hipSuccess && dev == g_ct_ws_dev) { a.ws = g_ct_ws; a.ws_bytes = g_ct_ws_bytes; }
-  }
+  // (a.ws / a.ws_bytes: the split-reduction workspace of THIS call, set by the entry points from their arguments)
+  if (a.ws_bytes < 0 || (a.ws == nullptr) != (a.ws_bytes == 0)) return WSR_EINVAL;
   if (a.act_c1 != 0x7FFFFFFF && (a.act_c1 & 3)) return WSR_EINVAL;
   return dispatch_ct(a, tpk, st);
 }
@@ -388,6 +372,8 @@ extern "C" int wsr_conv3d_fwd_tile(const wsr_conv_t* c, const void* x, const voi
     if (a.act == 2 && (!a.res || ep->out_planar)) return WSR_EINVAL;
     a.out_planar = ep->out_planar;
     if (a.res && (a.res_off < 0 || a.res_off + c->Cout > a.res_ctot)) return WSR_EINVAL;
+    a.ws = ep->ws;
+    a.ws_bytes = (long)ep->ws_bytes;
   }
   a.B = c->B; a.Xi = c->Xi; a.Yi = c->Yi; a.Zi = c->Zi;
   a.Xo = c->Xo; a.Yo = c->Yo; a.Zo = c->Zo;
@@ -426,8 +412,10 @@ extern "C" int wsr_conv3d_fwd_tile(const wsr_conv_t* c, const void* x, const voi
 }
 
 extern "C" int wsr_conv3d_dgrad_tile(const wsr_conv_t* c, const void* dy, const void* wfrag_t, void* dx, float alpha,
-                                     int accumulate, int dx_planar, const wsr_lrelu_mask_t* mask, void* stream) {
+                                     int accumulate, int dx_planar, const wsr_lrelu_mask_t* mask,
+                                     const wsr_dgrad_opts_t* opts, void* stream) {
   if (!conv_geom_ok(c) || !dy || !wfrag_t || !dx) return WSR_EINVAL;
+  if (opts && opts->acc_src && !accumulate) return WSR_EINVAL;
   if (mask && (!mask->y || dx_planar || mask->c0 < 0 || mask->c1 > c->Cin || mask->c0 >= mask->c1 ||
                mask->c0 % 4 || mask->y_ctot % 4 || mask->y_off % 4 ||
                mask->y_off + (mask->c1 - mask->c0) > mask->y_ctot))
@@ -445,11 +433,15 @@ extern "C" int wsr_conv3d_dgrad_tile(const wsr_conv_t* c, const void* dy, const 
   if (accumulate) {  // 1: every produced channel; n > 1: the first n (a multiple of 4) only
     if (dx_planar) return WSR_EUNSUPPORTED;
     if (accumulate > 1 && (accumulate & 3)) return WSR_EINVAL;
-    a.res = (const unsigned short*)dx;
+    a.res = (const unsigned short*)((opts && opts->acc_src) ? opts->acc_src : dx);
     a.res_ctot = c->in_ctot;
     a.res_off = c->in_off;
     a.res_c1 = accumulate > 1 ? accumulate : 0x7FFFFFFF;
     a.beta = 1.f;
+  }
+  if (opts) {
+    a.ws = opts->ws;
+    a.ws_bytes = (long)opts->ws_bytes;
   }
   a.B = c->B;
   a.Xi = c->Xo; a.Yi = c->Yo; a.Zi = c->Zo;            // gathered tensor = dy

@@ -5,10 +5,10 @@
 #include "common.h"
 #include "stencil.h"
 
-int g_wsr_env_gen = 0;  // generation of the cached environment switches (common.h)
+std::atomic<int> g_wsr_env_gen{0};  // generation of the cached environment switches (common.h)
 
 extern "C" int wsr_reload_env(void) {
-  ++g_wsr_env_gen;
+  g_wsr_env_gen.fetch_add(1, std::memory_order_acq_rel);
   return 0;
 }
 
@@ -851,7 +851,8 @@ extern "C" int wsr_unpack_wgrad_multi(const wsr_unpack_job_t* jobs_dev, int32_t 
 
 extern "C" int wsr_unpack_wgrad_reduce_multi(const wsr_unpack_job_t* jobs_dev, int32_t n_jobs, void* stream) {
   if (!jobs_dev || n_jobs <= 0 || n_jobs > 65535) return WSR_EINVAL;
-  const int gx = WSR_ENV_INT("WSR_UNPACK_GRID", 128);  // (tuning aid: workgroups per job)
+  int gx = WSR_ENV_INT("WSR_UNPACK_GRID", 128);  // (tuning aid: workgroups per job)
+  gx = gx < 1 ? 1 : (gx > 1024 ? 1024 : gx);
   hipLaunchKernelGGL(unpack_reduce_multi_kernel, dim3((unsigned)gx, (unsigned)n_jobs), dim3(512), 0, as_stream(stream), jobs_dev);
   WSR_LAUNCH_CHECK();
   return 0;

@@ -40,6 +40,11 @@ STACK_FWD = __import__("os").environ.get("WSR_STACK_FWD", "1") != "0"
 GD_INPLACE = __import__("os").environ.get("WSR_GD_INPLACE", "1") != "0"
 #: run the last conv of the generator in its z-folded form (WSR_ZFOLD=0: plain 5x5x5 conv with 3 outputs)
 ZFOLD = __import__("os").environ.get("WSR_ZFOLD", "1") != "0"
+#: filter gradients of the generator's dense blocks on a second HIP stream (they depend only on saved activations and the
+#: block's output gradients and feed nothing in the input-gradient chain): 0 = in line on the compute stream, N >= 2 =
+#: side stream with a ring of N dense gradient buffers (the running block gradient moves from buffer to buffer so that
+#: a filter-gradient launch may still read the previous one)
+WGRAD_STREAM = int(__import__("os").environ.get("WSR_WGRAD_STREAM", "0"))
 POISON_BUFFERS = bool(int(__import__("os").environ.get("WSR_POISON_BUFFERS", "0")))
 #: filter gradients without float atomics: every spatial split of a wgrad launch stores its partial sums to its own
 #: copy and the unpack pass adds the copies in index order - two backward passes give bit-identical gradients
@@ -263,6 +268,23 @@ class ProgramBase:
         self._stack_specs = None
         self._stack_fwd_specs = None
         self._nparts: Dict[tuple, int] = {}
+        self._side: Optional[torch.cuda.Stream] = None
+        self._events: List[torch.cuda.Event] = []
+        self._events_used = 0
+
+    def side_stream(self, dev) -> "torch.cuda.Stream":
+        """the program's second HIP stream (made once per device)"""
+        if self._side is None or self._side.device != torch.device(dev):
+            self._side = torch.cuda.Stream(device=dev)
+        return self._side
+
+    def _event(self) -> "torch.cuda.Event":
+        """an event from the program's pool (re-used every pass: the sequence of fences is the same)"""
+        if self._events_used == len(self._events):
+            self._events.append(torch.cuda.Event())
+        ev = self._events[self._events_used]
+        self._events_used += 1
+        return ev
 
     def cp(self, c: int) -> int:
         """channel count padded to whole 16-byte pieces"""
@@ -273,7 +295,6 @@ class ProgramBase:
         """bring the fragment-order filter copies of all tile-kernel convs up to date in one launch"""
         if not (self.use_tile and self.dt == torch.bfloat16):
             return
-        ops.ensure_tile_workspace(self.conv_sites()[0].weight.device)  # split reductions of small launches
         sites = [s for s in self.conv_sites() if self.tile_ok(s)]
         fstack = list(self.stacked_fwd_specs())
         fcov = {id(p) for _, parts, _, _ in fstack for p, *_ in parts}
@@ -359,7 +380,7 @@ class ProgramBase:
             run()
 
     def dgrad(self, s: ConvSite, g: Tensor, g_off: int, dx: Tensor, dx_off: int, in_xyz, *, alpha: float = 1.0,
-              accumulate: bool = False, dx_planar: bool = False, mask=None) -> None:
+              accumulate: bool = False, dx_planar: bool = False, mask=None, acc_src: Optional[Tensor] = None) -> None:
         """dx[window] (+)= alpha * conv^T(g[window]);  in_xyz = stored input extent of the conv.
         ``mask`` = (y, y_off, c0, c1[, chan_scale]): afterwards multiply channels [c0, c1) of the window by the
         LeakyReLU derivative taken from channels [y_off, ...) of ``y`` - and by the Dropout3d keep factors
@@ -373,8 +394,11 @@ class ProgramBase:
         def run():
             m = None if mask is None else (mask[0], mask[1], mask[2], mask[3], self.slope) + tuple(mask[4:5])
             if self.tile_ok(s) and ops.conv_dgrad_tile(d, g, self.filters.get_frag(s.weight, True), dx, alpha=alpha,
-                                                       accumulate=accumulate, dx_planar=dx_planar, mask=m):
+                                                       accumulate=accumulate, dx_planar=dx_planar, mask=m,
+                                                       acc_src=acc_src):
                 return
+            if acc_src is not None:
+                raise RuntimeError("accumulating from another buffer needs the tile kernels (set WSR_WGRAD_STREAM=0)")
             if int(accumulate) > 1:
                 raise RuntimeError("partial accumulation needs the tile kernels (set WSR_GD_INPLACE=0)")
             ops.conv_dgrad(d, g, self._wt(s), dx, alpha=alpha, accumulate=accumulate, dx_planar=dx_planar)
@@ -558,6 +582,7 @@ class ProgramBase:
         self._arena_off = 0
         self._arena_need = 0
         self._arena_dev = dev
+        self._events_used = 0
         if DETERMINISTIC:
             # split copies are written with plain stores: nothing to zero.  The arena is PERSISTENT (sized by the
             # first backward pass of a shape): stable addresses keep the cached unpack job tables valid
@@ -1075,8 +1100,65 @@ class GeneratorProgram(ProgramBase):
         gd = self._empty((B, X, Y, nz, dense), g_out) if bufs else None
         inplace = (GD_INPLACE and gd is not None and self.dt == torch.bfloat16 and self.use_tile
                    and ops.conv1x1_covers(nf, dense, True))
+        # Filter gradients on a second stream (WSR_WGRAD_STREAM = ring size): they read the saved dense buffer and the
+        # block's output gradients and feed nothing in the input-gradient chain.  The running gradient then MOVES through
+        # a ring of dense gradient buffers - block j reads its output gradient in ring[slot][..., :nf] and writes its
+        # input gradients (all `dense` channels) to ring[slot + 1] - so that the side stream may still read a buffer
+        # while the chain is one or two blocks further; fences: one event per block and stream.
+        side = None
+        if WGRAD_STREAM >= 2 and inplace and DETERMINISTIC and bufs:
+            side = self.side_stream(dev)
+            main = torch.cuda.current_stream(dev)
+            ring = [gd] + [self._empty(gd.shape, g_out) for _ in range(WGRAD_STREAM - 1)]
+            free_ev: List[Optional[torch.cuda.Event]] = [None] * len(ring)
+            slot = 0
         for rdbs, rr_scale in zip(reversed(self.rrdbs), reversed(self.rrdb_scales)):
             g_skip = g  # d(out)/d(x_rr) through the RRDB shortcut
+            if side is not None:
+                ops.chan_axpby(ring[slot], 0, g, 0, nf, alpha=rr_scale)
+                for convs, lff, rdb_scale in reversed(rdbs):
+                    bi -= 1
+                    buf = bufs[bi]
+                    src, nxt = ring[slot], (slot + 1) % len(ring)
+                    dst = ring[nxt]
+                    nc = len(convs)
+                    last = nf + (nc - 1) * gc
+                    ev = self._event()
+                    ev.record(main)
+                    side.wait_event(ev)  # the block's output gradient (src[..., :nf]) is complete
+                    with torch.cuda.stream(side):
+                        self.wgrad(lff, buf, 0, src, 0, flat, sp, scratch, scale=rdb_scale)
+                        rows = ops.chan_sum_rows(nf, src.numel() // src.shape[-1])
+                        if not rows:
+                            raise RuntimeError("LFF bias gradient outside the two-pass sum (set WSR_WGRAD_STREAM=0)")
+                        pr = self._arena_take(rows * nf, dev).view(rows, nf)
+                        ops.chan_sum_partials(src, 0, nf, pr)
+                        self._pending_unpack.append((pr[0].view(1, 1, nf), sp.view(flat, lff.bias).view(1, nf, 1),
+                                                     rdb_scale, rows, nf))
+                        fe = self._event()
+                        fe.record(side)  # ... and the side stream's readers of `src` (this and, earlier in stream order,
+                        free_ev[slot] = fe  # the previous block's stacked filter gradient) are done
+                    if free_ev[nxt] is not None:  # `dst` is about to be overwritten: its side-stream readers first
+                        main.wait_event(free_ev[nxt])
+                        free_ev[nxt] = None
+                    self.dgrad(lff, src, 0, dst, 0, (X, Y, nz), alpha=rdb_scale, accumulate=nf, acc_src=src,
+                               mask=(buf, last, last, last + gc) if nc else None)
+                    if STACK_DGRAD and self.dense_stackable(convs):
+                        self.dgrad_dense(convs, dst, buf, (X, Y, nz))
+                    else:
+                        for i in reversed(range(nc)):
+                            off = nf + i * gc
+                            m = (buf, off - gc, off - gc, off) if i > 0 else None
+                            self.dgrad(convs[i], dst, off, dst, 0, (X, Y, nz), accumulate=True, mask=m)
+                    ev = self._event()
+                    ev.record(main)
+                    side.wait_event(ev)  # all growth-channel gradients of the block are final
+                    with torch.cuda.stream(side):
+                        self.wgrad_dense(convs, buf, dst, flat, sp, scratch)
+                        ready(lff.weight, lff.bias, *[c.weight for c in convs])
+                    slot = nxt
+                ops.chan_axpby(g, 0, ring[slot], 0, nf, alpha=1.0, beta=1.0)  # g (= g_skip) += chain gradient
+                continue
             if inplace:
                 # the gradient of the current block's output lives in gd[..., :nf]: the LFF input gradient is
                 # taken in place (1x1x1: voxel-local) with the block's identity shortcut as a residual on those
@@ -1126,6 +1208,10 @@ class GeneratorProgram(ProgramBase):
             else:
                 ops.chan_axpby(go, 0, g_skip, 0, nf, alpha=1.0, beta=1.0)
                 g = go
+        if side is not None:  # join: everything below (and the optimizer) sees the trunk's filter gradients
+            ev = self._event()
+            ev.record(side)
+            main.wait_event(ev)
         # ---- feature conv: total grad of f = trunk path + skip path
         ops.chan_axpby(g, 0, gs, 0, nf, alpha=1.0, beta=1.0)
         self.wgrad(self.feature, saved["x_nd"], 0, g, 0, flat, sp, scratch)

@@ -156,24 +156,27 @@ def conv_fwd(desc: ConvDesc, x: Tensor, w: Tensor, y: Tensor, *, bias: Optional[
 
 
 _tile_ws: dict = {}
+TILE_WS_BYTES = 32 << 20
 
 
-def ensure_tile_workspace(dev, nbytes: int = 32 << 20) -> None:
-    """Give the tile entry points their split-reduction workspace (``wsr_conv_tile_workspace``) once per process:
-    launches with few workgroups and a long reduction (the discriminator's deep layers) then spread the reduction
-    channels over up to 256 workgroups.  The buffer is owned here and lives as long as the process."""
-    if _tile_ws.get("dev") == dev:
-        return
-    ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-    check(_lib.lib().wsr_conv_tile_workspace(_p(ws), ws.numel()), "conv_tile_workspace")
-    _tile_ws["dev"], _tile_ws["ws"] = dev, ws
+def tile_workspace(dev=None):
+    """(pointer, bytes) of the split-reduction workspace the tile entry points get with every call (``wsr_epilogue_t.ws``,
+    ``wsr_dgrad_opts_t.ws``): launches with few workgroups and a long reduction (the discriminator's deep layers) then
+    spread the reduction channels over up to 256 workgroups.  One buffer per (device, stream) - launches on one
+    stream are ordered, launches on different streams may overlap and must not share partial sums; the library itself
+    keeps no state.  Owned here, lives as long as the process."""
+    key = (_raw_device() if _raw_device is not None else torch.cuda.current_device(), _stream().value)
+    ws = _tile_ws.get(key)
+    if ws is None:
+        ws = _tile_ws[key] = torch.empty(TILE_WS_BYTES, dtype=torch.uint8, device=f"cuda:{key[0]}")
+    return ws.data_ptr(), ws.numel()
 
 
 def conv_fwd_tile(desc: ConvDesc, x: Tensor, wfrag: Tensor, y: Tensor, *, bias: Optional[Tensor] = None,
                   chan_scale: Optional[Tensor] = None, res: Optional[Tensor] = None, res_off: int = 0,
                   alpha: float = 1.0, beta: float = 0.0, act=False, slope: float = 0.2,
                   out_planar: bool = False, act_c1: int = 0, res2: Optional[Tensor] = None, res2_off: int = 0,
-                  beta2: float = 0.0) -> bool:
+                  beta2: float = 0.0, use_ws: bool = True) -> bool:
     """LDS halo-tile forward conv (bf16, stride 1).  Returns False when the shape is outside
     the tile kernels (the caller then uses :func:`conv_fwd`).  ``act`` = 2 / ``act_c1``: the two stages of a
     split dense-block conv (see ``wsr_epilogue_t``)."""
@@ -189,6 +192,8 @@ def conv_fwd_tile(desc: ConvDesc, x: Tensor, wfrag: Tensor, y: Tensor, *, bias: 
     if res2 is not None:
         _need_cuda(res2)
         ep.res2, ep.res2_ctot, ep.res2_off, ep.beta2 = _p(res2), res2.shape[-1], res2_off, beta2
+    if use_ws:
+        ep.ws, ep.ws_bytes = tile_workspace()
     rc = _lib.lib().wsr_conv3d_fwd_tile(C.byref(desc), _p(x), _p(wfrag), _p(y), C.byref(ep), _stream())
     if rc == _lib.WSR_EUNSUPPORTED:
         return False
@@ -204,10 +209,18 @@ def conv1x1_covers(red: int, n_out: int, masked: bool) -> bool:
 
 
 def conv_dgrad_tile(desc: ConvDesc, dy: Tensor, wfrag_t: Tensor, dx: Tensor, *, alpha: float = 1.0,
-                    accumulate: bool = False, dx_planar: bool = False, mask=None) -> bool:
+                    accumulate: bool = False, dx_planar: bool = False, mask=None, acc_src: Optional[Tensor] = None,
+                    use_ws: bool = True) -> bool:
     """``mask`` = (y, y_off, c0, c1, slope): fold ``leaky_relu_backward`` of produced channels [c0, c1) into
-    the epilogue, the mask taken from channels [y_off, y_off + c1 - c0) of the saved output ``y``."""
-    _need_cuda(dy, wfrag_t, dx)
+    the epilogue, the mask taken from channels [y_off, y_off + c1 - c0) of the saved output ``y``.
+    ``acc_src``: with ``accumulate``, the tensor (same layout as ``dx``) whose values are added instead of dx's own."""
+    _need_cuda(dy, wfrag_t, dx, acc_src)
+    if acc_src is not None and acc_src.shape != dx.shape:
+        raise ValueError("acc_src must have dx's layout")
+    opts = _lib.DgradOpts()
+    opts.acc_src = _p(acc_src)
+    if use_ws:
+        opts.ws, opts.ws_bytes = tile_workspace()
     mp = None
     if mask is not None:
         y, y_off, c0, c1, slope = mask[:5]
@@ -218,7 +231,7 @@ def conv_dgrad_tile(desc: ConvDesc, dy: Tensor, wfrag_t: Tensor, dx: Tensor, *, 
         m.chan_scale = _p(cs)
         mp = C.byref(m)
     rc = _lib.lib().wsr_conv3d_dgrad_tile(C.byref(desc), _p(dy), _p(wfrag_t), _p(dx), alpha, int(accumulate),
-                                          int(dx_planar), mp, _stream())
+                                          int(dx_planar), mp, C.byref(opts), _stream())
     if rc == _lib.WSR_EUNSUPPORTED:
         return False
     check(rc, "conv3d_dgrad_tile")

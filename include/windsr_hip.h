@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define WSR_ABI_VERSION 5
+#define WSR_ABI_VERSION 6
 
 enum wsr_dtype { WSR_F32 = 0, WSR_BF16 = 1 };
 
@@ -91,6 +91,15 @@ typedef struct wsr_epilogue {
   int32_t out_planar;       /* 1: y is fp32 planar (B, Cout, Xo, Yo, Zo)        */
   int32_t act_c1;           /* > 0 (tile kernels only): bias and activation apply to channels < act_c1 only, the rest
                                are stored as raw sums - the first stage of a split dense-block conv            */
+  /* ABI 6 - split-reduction workspace of THIS call (tile entry point only; NULL / 0 = never split): device memory the
+   * caller owns.  With it, launches that would otherwise run on a few workgroups with a long reduction (the deep
+   * layers of the discriminator, Discriminator_3D.py:66-169: 128..1024 voxels x 256..512 channels x 27..48 taps)
+   * split the reduction channels over up to 256 workgroups; the fp32 partial sums go through the workspace and a
+   * second launch on the same stream adds them in index order (bit-reproducible) and applies the epilogue.  Launches
+   * that may run concurrently (different streams / threads) take different workspaces - the library keeps no
+   * state between calls.  Results do not depend on its presence beyond fp32 summation order.                 */
+  void* ws;
+  int64_t ws_bytes;
   const void* res2;         /* second residual, y += beta2*res2[..., res2_off + c] (streaming 1x1x1 kernel only,
                                WSR_EUNSUPPORTED elsewhere): the last LFF of an RRDB adds the dense block's and the
                                RRDB's shortcut at once (torch_blocks.py:290,330)                                */
@@ -142,16 +151,20 @@ typedef struct wsr_lrelu_mask {
   const float* chan_scale;  /* optional [B][Cin]: every produced channel is also multiplied by it - the
                                Dropout3d keep factors of that layer (Generator_3D...py:104), backward       */
 } wsr_lrelu_mask_t;
+/* ABI 6 - optional extras of the tile input gradient (NULL = none of them):
+ *   acc_src : with `accumulate`, the tensor whose values are added (dx's own layout: in_ctot channels per voxel, the
+ *             window at in_off) - NULL = dx itself.  Lets the running gradient of a residual chain move from one
+ *             buffer to the next instead of being updated in place, so that a filter-gradient launch on another
+ *             stream may still read the previous buffer (the dense blocks' backward pass, torch_blocks.py:256-290).
+ *   ws / ws_bytes : split-reduction workspace of this call, as wsr_epilogue_t.ws.                            */
+typedef struct wsr_dgrad_opts {
+  const void* acc_src;
+  void* ws;
+  int64_t ws_bytes;
+} wsr_dgrad_opts_t;
 int wsr_conv3d_dgrad_tile(const wsr_conv_t* c, const void* dy, const void* wfrag_t, void* dx, float alpha,
-                          int accumulate, int dx_planar, const wsr_lrelu_mask_t* mask, void* stream);
-/* Optional workspace of the tile entry points (device memory, caller-owned; NULL / 0 withdraws it).  With it,
- * launches that would otherwise run on a few workgroups with a long reduction (the deep layers of the
- * discriminator, Discriminator_3D.py:66-169: 128..1024 voxels x 256..512 channels x 27..48 taps) split the
- * reduction channels over up to 256 workgroups; the fp32 partial sums go through the workspace and a second
- * launch adds them in index order (bit-reproducible) and applies the epilogue.  One workspace per process; the
- * launches that use it must be stream-ordered with each other.  Results do not depend on its presence beyond
- * fp32 summation order.                                                                                   */
-int wsr_conv_tile_workspace(void* ws, int64_t bytes);
+                          int accumulate, int dx_planar, const wsr_lrelu_mask_t* mask, const wsr_dgrad_opts_t* opts,
+                          void* stream);
 int64_t wsr_frag_filter_elems(int32_t rows, int32_t red, int32_t taps);
 int wsr_pack_filter_frag(const float* w, void* out, int32_t Cout, int32_t Cin, int32_t KX, int32_t KY, int32_t KZ,
                          int32_t transpose, void* stream);

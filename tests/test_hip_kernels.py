@@ -150,7 +150,7 @@ def test_upconv_fused_upsample(golden, hip, dt):
 ])
 def test_split_reduction_matches_single_pass(hip, case):
     """Launches with few workgroups and long reductions split the reduction channels over more workgroups when the
-    caller provides a workspace (wsr_conv_tile_workspace): same result as the single-pass launch up to the fp32
+    caller passes a workspace with the call (wsr_epilogue_t.ws / wsr_dgrad_opts_t.ws, ABI 6): same result as the single-pass launch up to the fp32
     summation order (both sides round the same sums to bf16 once: 2e-3), forward and input gradient, and as the fp32
     CPU conv of the same bf16-rounded operands (4e-3); two split launches are bit-identical."""
     o = ops()
@@ -169,14 +169,8 @@ def test_split_reduction_matches_single_pass(hip, case):
     bd = bias.to(DEV) if has_bias else None
     ys = []
     for ws in (False, True, True):
-        if ws:
-            o._tile_ws.clear()
-            o.ensure_tile_workspace(torch.device(DEV))
-        else:
-            assert hip.wsr_conv_tile_workspace(None, 0) == 0
-            o._tile_ws.clear()
         yb = torch.full((B,) + oxyz + (cout,), float("nan"), dtype=dt, device=DEV)
-        assert o.conv_fwd_tile(d, xb, wf, yb, bias=bd, act=act, slope=0.2)
+        assert o.conv_fwd_tile(d, xb, wf, yb, bias=bd, act=act, slope=0.2, use_ws=ws)
         ys.append(from_ndhwc(yb, 0, cout))
     y_ref = F.conv3d(x, w, bias, stride=st, padding=pad)
     if act:
@@ -190,18 +184,71 @@ def test_split_reduction_matches_single_pass(hip, case):
         wft = o.pack_filter_frag(w.to(DEV), transpose=True)
         dxs = []
         for ws in (False, True):
-            if ws:
-                o.ensure_tile_workspace(torch.device(DEV))
-            else:
-                assert hip.wsr_conv_tile_workspace(None, 0) == 0
-                o._tile_ws.clear()
             dxb = torch.full((B,) + xyz + (cin,), float("nan"), dtype=dt, device=DEV)
-            assert o.conv_dgrad_tile(d, gb, wft, dxb, alpha=0.5)
+            assert o.conv_dgrad_tile(d, gb, wft, dxb, alpha=0.5, use_ws=ws)
             dxs.append(from_ndhwc(dxb, 0, cin))
         xr = x.clone().requires_grad_(True)
         (dx_ref,) = torch.autograd.grad(F.conv3d(xr, w, None, stride=st, padding=pad), xr, gy)
         assert rel_l2(dxs[0], 0.5 * dx_ref) < 4e-3 and rel_l2(dxs[1], 0.5 * dx_ref) < 4e-3
-    o.ensure_tile_workspace(torch.device(DEV))
+
+
+def test_split_reduction_is_reentrant_across_streams(hip):
+    """ABI 6: the split-reduction workspace travels with the call (the library keeps no state between calls), so two
+    split launches may be in flight on two streams at once - each with its own workspace - and give exactly what each
+    gives alone.  (ABI 5 registered ONE process-wide workspace: concurrent launches would have mixed their partial
+    sums.)  Many rounds, alternating issue order."""
+    o = ops()
+    dt = torch.bfloat16
+    torch.manual_seed(11)
+    cases = [(256, 256, (3, 3, 3), (8, 8, 16)), (512, 256, (3, 3, 3), (4, 4, 8))]
+    jobs = []
+    for cin, cout, k, xyz in cases:
+        x = torch.randn(1, cin, *xyz).to(dt).float()
+        w = (torch.randn(cout, cin, *k) / math.sqrt(cin * 27)).to(dt).float()
+        d = o.make_desc(o.ConvGeom(cin, cout, k, (1, 1, 1), (1, 1, 1)), dt, 1, xyz, cin, 0, cout, 0)
+        xb, wf = to_ndhwc(x, cin, 0, dt), o.pack_filter_frag(w.to(DEV))
+        alone = torch.empty((1,) + xyz + (cout,), dtype=dt, device=DEV)
+        assert o.conv_fwd_tile(d, xb, wf, alone)
+        jobs.append((d, xb, wf, alone, xyz, cout))
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    ptrs = set()
+    for rnd in range(12):
+        outs = []
+        order = (0, 1) if rnd % 2 == 0 else (1, 0)
+        for i in order:
+            d, xb, wf, alone, xyz, cout = jobs[i]
+            with torch.cuda.stream(streams[i]):
+                ptrs.add(o.tile_workspace()[0])
+                y = torch.full((1,) + xyz + (cout,), float("nan"), dtype=dt, device=DEV)
+                assert o.conv_fwd_tile(d, xb, wf, y)
+                outs.append((i, y))
+        torch.cuda.synchronize()
+        for i, y in outs:
+            assert torch.equal(y, jobs[i][3]), (rnd, i)
+    assert len(ptrs) == 2  # one workspace per stream
+
+
+def test_dgrad_accumulates_from_another_buffer(hip):
+    """ABI 6 ``wsr_dgrad_opts_t.acc_src``: dx = alpha * conv^T(dy) + acc_src on the first n channels, everything else
+    freshly written - the same numbers as accumulating in place on a copy of acc_src.  3x3x3 on the halo-tile kernel
+    and the in-place-capable streaming 1x1x1 kernel (LFF input gradient, 128 -> 256 with the identity shortcut)."""
+    o = ops()
+    dt = torch.bfloat16
+    torch.manual_seed(5)
+    for (cin, cout, k, pad, xyz, n_acc) in [(64, 32, (3, 3, 3), (1, 1, 1), (8, 8, 16), 32),
+                                            (256, 128, (1, 1, 1), (0, 0, 0), (8, 16, 16), 128)]:
+        gy = torch.randn(1, cout, *xyz).to(dt).float()
+        w = (torch.randn(cout, cin, *k) / math.sqrt(cout)).to(dt).float()
+        d = o.make_desc(o.ConvGeom(cin, cout, k, (1, 1, 1), pad), dt, 1, xyz, cin, 0, cout, 0)
+        gb = to_ndhwc(gy, cout, 0, dt)
+        wft = o.pack_filter_frag(w.to(DEV), transpose=True)
+        src = torch.randn((1,) + xyz + (cin,), device=DEV).to(dt)
+        inplace = src.clone()
+        assert o.conv_dgrad_tile(d, gb, wft, inplace, alpha=0.7, accumulate=n_acc)
+        moved = torch.full_like(src, float("nan"))
+        assert o.conv_dgrad_tile(d, gb, wft, moved, alpha=0.7, accumulate=n_acc, acc_src=src)
+        assert torch.equal(moved, inplace)
 
 
 @pytest.mark.parametrize("batched", [True, False])

@@ -351,6 +351,90 @@ def test_gan_train_step_trace_fp32_vs_reference(golden, hip):
             assert rel_l2(gan.D.state_dict()[k[8:]], T(g[k])) < 2e-3, k
 
 
+def test_gan_train_step_noise_trace_fp32_vs_reference(golden, hip, monkeypatch):
+    """The instance-noise / noisy-label / Dropout3d branch (reference GAN_models/wind_field_GAN_3D.py:221-304, 627-678,
+    tools/trainingtricks.py:18-59) ON THE HIP PATH against the reference trace ``gan_trace_noise.npz``: every random
+    draw of the branch is routed to the CPU generator in the reference's order and shapes - the instance noise as
+    ``torch.rand(shape)``, a Dropout3d mask as ATen's feature dropout draws it (one Bernoulli per (sample, channel) on
+    a (B, C, 1, 1, 1) tensor; the generator's through the injectable ``dropout_scale``), the labels already are CPU
+    ``torch.normal`` draws - and everything else (G, D, losses, both Adam steps) runs through the HIP programs."""
+    import torch.nn.functional as F
+    from gan_sr_wind_field_amd.tools import trainingtricks
+
+    g = golden("gan_trace_noise.npz")
+    p = float(g["dropout"])
+    gan, cfg = _gpu_gan(use_noise=bool(g["use_noise"]), dropout=p)
+    gs = onets.GSpec(in_channels=4, nf=16, n_rrdb=1, gc=8, tf=4, hr_kern=5, upscale=4, dropout_p=p)
+    ds = onets.DSpec(bf=4, nz=4, enable_slicing=True, dropout_p=p)
+    gan.G.load_state_dict(onets.deterministic_state(onets.g_param_shapes(gs), seed=41, scale=0.5))
+    gan.D.load_state_dict(onets.deterministic_state(onets.d_param_shapes(ds), seed=43, scale=1.0))
+
+    draws = {"noise": 0, "g_mask": 0, "d_mask": 0}
+
+    def cpu_instance_noise(sigma_base, shape, it, niter, device=torch.device("cpu")):
+        draws["noise"] += 1
+        scale = torch.sqrt(sigma_base.cpu() * (1 - (it.cpu() - 1) / niter.cpu()))
+        return (torch.rand(shape) * scale).to(device)
+
+    monkeypatch.setattr(trainingtricks, "instance_noise", cpu_instance_noise)
+
+    def cpu_feature_mask(b, c, prob):  # what nn.Dropout3d multiplies a (b, c, X, Y, Z) CPU tensor by
+        return F.dropout3d(torch.ones(b, c, 1, 1, 1), prob, True)
+
+    g_forward = gan.G.forward
+
+    def forward_with_cpu_mask(x, Z, dropout_scale=None):
+        if dropout_scale is None and gan.G.training and p > 0:
+            draws["g_mask"] += 1
+            c = gan.G.hr_convs[0][0].out_channels
+            dropout_scale = cpu_feature_mask(x.shape[0], c, p).reshape(x.shape[0], c).to(x.device)
+        return g_forward(x, Z, dropout_scale)
+
+    monkeypatch.setattr(gan.G, "forward", forward_with_cpu_mask)
+
+    class CpuDropout3d(torch.nn.Dropout3d):
+        def forward(self, x):
+            if not self.training or self.p == 0:
+                return x
+            draws["d_mask"] += 1
+            return x * cpu_feature_mask(x.shape[0], x.shape[1], self.p).to(x.device)
+
+    gan.D.dropout = CpuDropout3d(p=p)
+
+    LR, HR, Z, x, y = (t.to(DEV) for t in ogan.synthetic_batch(2, 16, 4, 4, seed=2001))
+    gan.feed_xy_niter(x, y, torch.tensor(cfg.training.niter, device=DEV), cfg.training.d_g_train_ratio,
+                      cfg.training.d_g_train_period)
+    torch.manual_seed(4242)  # RNG state at the first optimize_parameters call of the recorded trace
+    keys = ["total", "adversarial", "pix", "xy_gradient", "z_gradient", "divergence", "xy_divergence", "feature_D"]
+    for row, it in enumerate(g["its"]):
+        gan.optimize_parameters(LR, HR, Z, int(it))
+        if int(it) > 2 * cfg.training.d_g_train_period:
+            gan.update_learning_rate()
+        if g["kinds"][row]:
+            got = [float(gan.get_G_train_loss_dict_ref()[k]) for k in keys]
+            np.testing.assert_allclose(got, g["G_losses"][row], rtol=1e-3, atol=1e-7, err_msg=f"it={it}")
+        else:
+            np.testing.assert_allclose(float(gan.get_D_loss_dict_ref()["train_loss"]), g["D_loss"][row], rtol=1e-3,
+                                       err_msg=f"it={it}")
+        sdG, sdD = gan.G.state_dict(), gan.D.state_dict()
+        wg = [float(sdG[k].double().abs().sum())
+              for k in ("model.0.0.weight", "hr_convs.2.weight", "model.1.module.0.RDBs.1.LFF.bias")]
+        wd = [float(sdD[k].double().abs().sum())
+              for k in ("features.0.0.0.weight", "classifier.2.weight", "features.1.1.1.running_var")]
+        np.testing.assert_allclose(wg, g["wsum_g"][row], rtol=2e-4, err_msg=f"it={it}")
+        np.testing.assert_allclose(wd, g["wsum_d"][row], rtol=2e-4, err_msg=f"it={it}")
+        assert abs(gan.optimizer_G.param_groups[0]["lr"] - g["lr"][row]) < 1e-12
+    # the branch really ran: noise for every D input (+ the reference's one debug draw), a generator mask per
+    # G-iteration (the D-iteration's generator pass runs in eval mode), two discriminator masks per D-iteration
+    n_g, n_d = int(np.sum(g["kinds"])), int(np.sum(1 - g["kinds"]))
+    assert draws == {"noise": 2 * (n_g + n_d) + 1, "g_mask": n_g, "d_mask": 2 * n_d}, draws
+    for k in g.files:
+        if k.startswith("final_G."):
+            assert rel_l2(gan.G.state_dict()[k[8:]], T(g[k])) < 2e-3, k
+        if k.startswith("final_D."):
+            assert rel_l2(gan.D.state_dict()[k[8:]], T(g[k])) < 2e-3, k
+
+
 def test_discriminator_feature_extractor_loss(hip):
     """``use_D_feature_extractor_cost`` (reference GAN_models/wind_field_GAN_3D.py:372-375, 577-583: a frozen deep copy
     of D.features, MSE between its features of HR and of the generated field): the loss entry against the oracle's
