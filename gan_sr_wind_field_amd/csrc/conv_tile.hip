@@ -346,6 +346,11 @@ int wsr_conv1x1_bf16(const unsigned short* in, int in_ctot, int in_off, int red,
                      float slope, const wsr_lrelu_mask_t* mask, const unsigned short* res2, int res2_ctot, int res2_off,
                      float beta2, hipStream_t st);  // conv_1x1.hip
 
+// conv_thin.hip: sliding-window kernel of the 3x3x3 convs with <= 16 reduction channels
+int wsr_conv_thin3(const unsigned short* in, int in_ctot, int in_off, int red, const unsigned short* wfrag,
+                   unsigned short* out, int out_ctot, int out_off, int n_out, int B, int X, int Y, int Z, const float* bias,
+                   float alpha, int act, float slope, hipStream_t st);
+
 extern "C" int wsr_conv3d_fwd_tile(const wsr_conv_t* c, const void* x, const void* wfrag, void* y,
                                    const wsr_epilogue_t* ep, void* stream) {
   if (!conv_geom_ok(c) || !x || !wfrag || !y) return WSR_EINVAL;
@@ -406,6 +411,14 @@ extern "C" int wsr_conv3d_fwd_tile(const wsr_conv_t* c, const void* x, const voi
       zero_page()) {
     const int rc = wsr_conv_slide_fwd(a.in, a.in_ctot, a.in_off, c->Cin, a.wf, (float*)a.out, c->Cout, c->B, c->Xi, c->Yi,
                                       c->Zi, c->KX, c->KY, c->px, c->py, a.bias, zero_page(), as_stream(stream));
+    if (rc != WSR_EUNSUPPORTED) return rc;
+  }
+  // 3x3x3 "same" conv over <= 16 stored channels (terrain convs, feature conv, the discriminator's first conv): memory-bound
+  if ((c->KX & c->KY & c->KZ) == 3 && (c->KX | c->KY | c->KZ) == 3 && (c->px & c->py & c->pz) == 1 &&
+      (c->px | c->py | c->pz) == 1 && (c->sx | c->sy | c->sz) == 1 && !a.ups && !c->lat && !a.out_planar &&
+      !a.chan_scale && !a.res && a.act <= 1 && a.act_c1 == 0x7FFFFFFF && c->Cin <= 16) {
+    const int rc = wsr_conv_thin3(a.in, a.in_ctot, a.in_off, c->Cin, a.wf, (unsigned short*)a.out, a.out_ctot, a.out_off,
+                                  a.Cout, c->B, c->Xi, c->Yi, c->Zi, a.bias, a.alpha, a.act, a.slope, as_stream(stream));
     if (rc != WSR_EUNSUPPORTED) return rc;
   }
   return run_conv_tile(a, c->Cin, as_stream(stream));
@@ -470,6 +483,13 @@ extern "C" int wsr_conv3d_dgrad_tile(const wsr_conv_t* c, const void* dy, const 
     const int rc = wsr_conv_slide_dgrad(a.in, a.in_ctot, a.in_off, c->Cout, a.wf, (unsigned short*)a.out, a.out_ctot,
                                         a.out_off, c->Cin, c->B, c->Xi, c->Yi, c->Zi, c->KX, c->KY, a.px, a.py, alpha, mask,
                                         zero_page(), as_stream(stream));
+    if (rc != WSR_EUNSUPPORTED) return rc;
+  }
+  if (!mask && !accumulate && !dx_planar && !c->lat && ux == 1 && (c->KX & c->KY & c->KZ) == 3 &&
+      (c->KX | c->KY | c->KZ) == 3 && (c->px & c->py & c->pz) == 1 && (c->px | c->py | c->pz) == 1 && c->Cout <= 16) {
+    // input gradient of such a conv with a thin OUTPUT side (terrain_convs.1, 16 -> 16): the same sliding-window kernel
+    const int rc = wsr_conv_thin3(a.in, a.in_ctot, a.in_off, c->Cout, a.wf, (unsigned short*)a.out, a.out_ctot, a.out_off,
+                                  a.Cout, c->B, c->Xi, c->Yi, c->Zi, nullptr, alpha, 0, 0.f, as_stream(stream));
     if (rc != WSR_EUNSUPPORTED) return rc;
   }
   if (mask) {

@@ -1012,6 +1012,86 @@ def test_conv_slide_input_gradient_vs_cpu(hip, name, k, xyz, B, ctot, off, drop)
         assert bool((dxb[..., :off] == 7.0).all()), name
 
 
+@pytest.mark.parametrize("name,cin,cout,xyz,B,in_ctot,in_off,out_ctot,out_off,bias,act", [
+    ("terrain1", 16, 16, (12, 16, 32), 1, 16, 0, 144, 128, False, False),   # 16 -> 16 into the concat window, TZ = 32
+    ("terrain0", 1, 16, (9, 24, 32), 1, 8, 0, 16, 0, False, True),          # 1 channel padded to 8, LeakyReLU
+    ("d_first", 3, 32, (10, 20, 48), 2, 8, 0, 32, 0, True, True),           # two samples, Z = 48 (16-level tiles), bias
+    ("feature", 4, 128, (16, 12, 16), 1, 8, 0, 256, 0, False, False),       # n-tiles over the waves, 4-row tiles
+    ("ragged", 16, 16, (5, 13, 16), 2, 24, 8, 40, 16, True, False),         # partial y tile, input window, x < 8
+    ("segments", 8, 32, (70, 8, 16), 1, 8, 0, 32, 0, False, True),          # one column: the x axis is cut into segments
+    ("narrow_out", 16, 12, (8, 16, 16), 1, 16, 0, 16, 4, False, False),     # 12 outputs: the tail channels of the n-tile are dropped
+])
+def test_conv_thin_forward_vs_cpu(hip, name, cin, cout, xyz, B, in_ctot, in_off, out_ctot, out_off, bias, act):
+    """sliding-window kernel of the 3x3x3 convs with <= 16 stored reduction channels (conv_thin.hip; reference
+    Generator_3D_Resnet_ESRGAN.py:78-85, 111-119, Discriminator_3D.py:67-75): against an fp32 CPU conv of the same
+    bf16-rounded operands (the result is rounded to bf16 once: 4e-3), bit-identical between two launches, channels
+    outside the written window untouched, and equal - up to that one rounding - to the halo-tile kernel it replaces."""
+    o = ops()
+    dt = torch.bfloat16
+    gen = torch.Generator().manual_seed(5 + xyz[0])
+    x = torch.randn((B, cin) + tuple(xyz), generator=gen).bfloat16().float()
+    w = (torch.randn((cout, cin, 3, 3, 3), generator=gen) / math.sqrt(cin * 27)).bfloat16().float()
+    bv = torch.randn(cout, generator=gen) * 0.3 if bias else None
+    cp = (cin + 7) // 8 * 8
+    xb = to_ndhwc(x, in_ctot, in_off, dt)
+    if in_off:
+        xb[..., :in_off] = float("nan")  # canary: channels outside the window must not be read
+    d = o.make_desc(o.ConvGeom(cin, cout, (3, 3, 3), (1, 1, 1), (1, 1, 1)), dt, B, xyz, in_ctot, in_off, out_ctot, out_off,
+                    cin=cp)
+    wf = o.pack_filter_frag(packed_master(w))
+    ref = F.conv3d(x, w, bv, 1, 1)
+    if act:
+        ref = F.leaky_relu(ref, 0.2)
+    outs = []
+    for _ in range(2):
+        y = torch.full((B,) + tuple(xyz) + (out_ctot,), 7.0, dtype=dt, device=DEV)
+        assert o.conv_fwd_tile(d, xb, wf, y, bias=bv.to(DEV) if bias else None, act=act, slope=0.2)
+        outs.append(y)
+    got = from_ndhwc(outs[0], out_off, cout)
+    assert torch.isfinite(got).all(), name
+    assert rel_l2(got, ref) < 4e-3, name
+    assert torch.equal(outs[0], outs[1]), name
+    keep = torch.ones(out_ctot, dtype=torch.bool)
+    keep[out_off:out_off + cout] = False
+    assert bool((outs[0][..., keep.to(DEV)] == 7.0).all()), name
+    import os
+    os.environ["WSR_NO_THIN"] = "1"
+    reload_wsr_env()
+    try:
+        y2 = torch.full((B,) + tuple(xyz) + (out_ctot,), 7.0, dtype=dt, device=DEV)
+        assert o.conv_fwd_tile(d, xb, wf, y2, bias=bv.to(DEV) if bias else None, act=act, slope=0.2)
+    finally:
+        del os.environ["WSR_NO_THIN"]
+        reload_wsr_env()
+    assert rel_l2(got, from_ndhwc(y2, out_off, cout)) < 4e-3, name
+
+
+@pytest.mark.parametrize("name,cin,cout,xyz,B,alpha", [("terrain1", 16, 16, (12, 16, 32), 1, 1.0),
+                                                       ("wide_in", 64, 16, (6, 9, 16), 2, 0.5),
+                                                       ("thin8", 16, 8, (8, 8, 48), 1, 1.0)])
+def test_conv_thin_input_gradient_vs_cpu(hip, name, cin, cout, xyz, B, alpha):
+    """input gradient of a 3x3x3 conv with <= 16 OUTPUT channels (terrain_convs.1, reference
+    Generator_3D_Resnet_ESRGAN.py:111-119) on the same sliding-window kernel: fp32 CPU autograd of the same
+    bf16-rounded operands."""
+    o = ops()
+    dt = torch.bfloat16
+    gen = torch.Generator().manual_seed(31 + xyz[0])
+    w = (torch.randn((cout, cin, 3, 3, 3), generator=gen) / math.sqrt(cout * 27)).bfloat16().float()
+    gy = torch.randn((B, cout) + tuple(xyz), generator=gen).bfloat16().float()
+    cop = (cout + 7) // 8 * 8
+    gb = to_ndhwc(gy, cop, 0, dt)
+    d = o.make_desc(o.ConvGeom(cin, cout, (3, 3, 3), (1, 1, 1), (1, 1, 1)), dt, B, xyz, cin, 0, cop, 0, cout=cop)
+    wpad = torch.cat([w, torch.zeros((cop - cout,) + tuple(w.shape[1:]))]) if cop != cout else w
+    wft = o.pack_filter_frag(packed_master(wpad), transpose=True)
+    dxb = torch.full((B,) + tuple(xyz) + (cin,), float("nan"), dtype=dt, device=DEV)
+    assert o.conv_dgrad_tile(d, gb, wft, dxb, alpha=alpha)
+    xg = torch.zeros((B, cin) + tuple(xyz), requires_grad=True)
+    F.conv3d(xg, w, None, 1, 1).backward(gy)
+    got = from_ndhwc(dxb, 0, cin)
+    assert torch.isfinite(got).all(), name
+    assert rel_l2(got, alpha * xg.grad) < 4e-3, name
+
+
 @pytest.mark.parametrize("sz,cin,cout,xyz,B", [(1, 32, 32, (16, 16, 8), 2), (2, 64, 128, (8, 16, 12), 1),
                                                 (2, 32, 64, (12, 8, 6), 1)])
 def test_strided_filter_gradient_in_parity_form(hip, sz, cin, cout, xyz, B):

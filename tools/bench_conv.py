@@ -28,8 +28,7 @@ def timeit(fn, iters=20, warm=3):
     return e0.elapsed_time(e1) / iters  # ms
 
 
-def conv_case(name, cin, cout, k, xyz, in_ctot=None, out_ctot=None, out_off=0, ups=False, what="fwd"):
-    B = 1
+def conv_case(name, cin, cout, k, xyz, in_ctot=None, out_ctot=None, out_off=0, ups=False, what="fwd", B=1, nbytes=None):
     in_ctot = in_ctot or cin
     geom = o.ConvGeom(cin, cout, k, (1, 1, 1), tuple(kk // 2 for kk in k), upsample=ups)
     g = torch.Generator(device=DEV).manual_seed(1)
@@ -55,7 +54,8 @@ def conv_case(name, cin, cout, k, xyz, in_ctot=None, out_ctot=None, out_off=0, u
         gy = torch.randn_like(y)
         dw = torch.zeros((cout, geom.taps, cin), dtype=torch.float32, device=DEV)
         ms = timeit(lambda: o.conv_wgrad(d, x, gy, dw))
-    print(f"{name:28s} {what:12s} {ms * 1e3:9.1f} us  {flops / ms / 1e9:8.1f} TF/s")
+    extra = f"  {nbytes / ms / 1e6:8.1f} GB/s algorithmic = {nbytes / ms / 1e6 / 8000:.3f} of 8 TB/s" if nbytes else ""
+    print(f"{name:28s} {what:12s} {ms * 1e3:9.1f} us  {flops / ms / 1e9:8.1f} TF/s{extra}")
 
 
 def tri_case():
@@ -94,6 +94,17 @@ CASES = {
     "hr1": lambda: [conv_case("hr1 144->3 k5", 144, 3, (5, 5, 5), HR, 144, 8, what=w) for w in ("fwd", "dgrad", "wgrad")],
     "lr": lambda: [conv_case("lr_conv 128->128", 128, 128, (3, 3, 3), LR, what=w) for w in ("fwd", "dgrad", "wgrad")],
 }
+
+# the memory-bound 3x3x3 convs with a thin input side (conv_thin.hip), benchmark shapes; bytes = (Cin V + Cout V) * 2
+VH, VL = 128 ** 3, 32 * 32 * 128
+CASES["thin"] = lambda: [
+    conv_case("terrain0 1->16", 8, 16, (3, 3, 3), HR, 8, 16, 0, nbytes=VH * 17 * 2),
+    conv_case("terrain1 16->16 (concat)", 16, 16, (3, 3, 3), HR, 16, 144, 128, nbytes=VH * 32 * 2),
+    conv_case("terrain1 dgrad", 16, 16, (3, 3, 3), HR, 16, 16, 0, what="dgrad", nbytes=VH * 32 * 2),
+    conv_case("feature 4->128", 8, 128, (3, 3, 3), LR, 8, 256, 0, nbytes=VL * 132 * 2),
+    conv_case("D first 3->32 (pair)", 8, 32, (3, 3, 3), HR, 8, 32, 0, B=2, nbytes=2 * VH * 35 * 2),
+]
+
 
 def up_parity_wgrad_case():
     B, xyz, c = 1, (64, 64, 128), 128
