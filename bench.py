@@ -7,7 +7,7 @@ Default workload (N = 1): BASELINE.json configs[2] in reference semantics (SURVE
 LR (B,4,32,32,128) -> HR (B,3,128,128,128), full-size G (16 RRDB, nf 128) and the
 128^3 D, bf16 compute with fp32 loss, dropout / instance noise / Adam all on.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--config C3p|C1|C1b|C2|C4|C5b|C5c|C5lit]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config C3p|C1|C1b|C2|C3lit|C4|C5b|C5c|C5lit]
                     [--dtype bf16|fp32] [--batch B] [--n N --nz NZ]
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
 
@@ -39,6 +39,8 @@ PRESETS = {
     "C1": ("local", 16, 10, 1, "bf16", "gan", True, "C1 shipped local ini: D with slicing, 64x64x10 HR patches"),
     "C1b": ("local", 32, 10, 1, "bf16", "gan", False, "C1b the reference's real patch size, no slicing"),
     "C2": ("local", 64, 64, 1, "fp32", "g_only", False, "C2 generator-only fwd+bwd+Adam, fp32"),
+    "C3lit": ("local", 128, 128, 1, "bf16", "g_only", False,
+              "C3 literal reading: generator-only fwd+bwd+Adam at LR 128^3 (4.8e9-element HR tensors; D cannot take 512x512)"),
     "C5b": ("upscale8", 16, 10, 8, "bf16", "gan", False, "C5b upscale8 ini (x8, three UpConv stages), full G+D step"),
     "C5c": ("upscale8", 16, 128, 1, "bf16", "gan", False, "C5c x8 to 128^3, full G+D step"),
     "C5lit": ("upscale8", 64, 64, 1, "bf16", "g_only", False, "C5 literal: x8 generator-only fwd+bwd+Adam, HBM stress"),

@@ -151,6 +151,10 @@ class wind_field_GAN_3D(BaseGAN):
         """mean over the (global) batch - the RaGAN average logit"""
         return torch.mean(t) if self.dp is None else self.dp.batch_mean(t)
 
+    def _means(self, a: torch.Tensor, b: torch.Tensor):
+        """both RaGAN average logits; under data parallelism in ONE collective per pass"""
+        return (torch.mean(a), torch.mean(b)) if self.dp is None else self.dp.batch_means(a, b)
+
     def _flags(self, flags) -> list:
         """host-side truth of a list of 0-d device flags in one round trip - set when set on ANY rank"""
         f = torch.stack([v.reshape(()).to(torch.float32) for v in flags])
@@ -218,8 +222,9 @@ class wind_field_GAN_3D(BaseGAN):
         if t.gan_type == "relativistic":
             adv = self.criterion(fake_y_pred - y_pred, self.HR_labels)
         elif t.gan_type == "relativisticavg":
-            adv = (self.criterion(fake_y_pred - self._mean(y_pred), self.HR_labels)
-                   + self.criterion(y_pred - self._mean(fake_y_pred), self.fake_HR_labels)) / 2.0
+            m_real, m_fake = self._means(y_pred, fake_y_pred)
+            adv = (self.criterion(fake_y_pred - m_real, self.HR_labels)
+                   + self.criterion(y_pred - m_fake, self.fake_HR_labels)) / 2.0
         else:
             raise NotImplementedError(f"Only relativistic and relativisticavg GAN are implemented, not {t.gan_type}")
 
@@ -354,8 +359,9 @@ class wind_field_GAN_3D(BaseGAN):
         if gan_type == "relativistic":
             loss_D = self.criterion(y_pred - fake_y_pred, self.HR_labels)
         elif gan_type == "relativisticavg":
-            loss_D = (self.criterion(y_pred - self._mean(fake_y_pred), self.HR_labels)
-                      + self.criterion(fake_y_pred - self._mean(y_pred), self.fake_HR_labels)) / 2.0
+            m_real, m_fake = self._means(y_pred, fake_y_pred)
+            loss_D = (self.criterion(y_pred - m_fake, self.HR_labels)
+                      + self.criterion(fake_y_pred - m_real, self.fake_HR_labels)) / 2.0
             # reference (:558-559): ``if torch.all(labels == 0.9): loss_D -= 0.1985`` - the same value without
             # the host round trip of the ``if``
             loss_D = loss_D - 0.1985 * torch.all(self.HR_labels == 0.9)

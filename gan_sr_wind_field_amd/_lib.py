@@ -126,7 +126,7 @@ def lib() -> C.CDLL:
         "wsr_bn_finalize": [vp, vp, f32, vp, f32, f32, vp, vp, vp, vp, i32, vp],
         "wsr_bn_apply_lrelu": [vp, vp, vp, vp, vp, vp, i32, i64, i32, f32, i32, vp],
         "wsr_bn_bwd_reduce": [vp, vp, vp, vp, vp, i32, i64, i32, f32, vp, vp, i32, vp],
-        "wsr_bn_bwd_apply": [vp, vp, vp, vp, vp, vp, vp, f32, i32, i64, i32, vp],
+        "wsr_bn_bwd_apply": [vp, vp, vp, vp, vp, vp, vp, f32, vp, f32, i32, i64, i32, vp],
         "wsr_adam_step": [vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, i32, vp],
     }
     for name, argtypes in sig.items():

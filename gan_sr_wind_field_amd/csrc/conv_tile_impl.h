@@ -222,6 +222,12 @@ void conv_tile_kernel(const CtArgs a) {
   // The halo geometry is the same for every chunk, so each wave resolves the source of "its" DMA units
   // (u = wave + WAVES*k) once: element offset of the lane's voxel (or OOB), octet plane, LDS offset.
   constexpr int XK = ct_xk(WAVES, TM);  // max units per wave per chunk (checked on the host; strided tiles: 13)
+  // Offsets are 32-bit and RELATIVE to the first x-plane the tile's halo touches (a 64-bit workgroup-uniform base):
+  // tensors beyond 2^32 elements (the literal 128^3 -> 512 x 512 x 128 reading of BASELINE.json configs[2]: 4.8e9 in a
+  // 144-channel HR tensor) only need the halo's few planes to stay below 2^32 elements (checked on the host).
+  const int gx_lo = max(x0 * a.sx - ppx, 0) >> U;  // first stored x-plane of the halo
+  const long vox_base = ((long)b * a.Xi + gx_lo) * a.il_m * ((long)a.Yi * a.il_m) * a.Zi;
+  const unsigned short* in_base = a.in + vox_base * a.in_ctot;
   unsigned xoff[XK];
   int xo8[VM ? 1 : XK], xdst[VM ? 1 : XK];  // voxel-major rows: octet = lane & 1, unit u lands at u KB
 #pragma unroll
@@ -245,8 +251,8 @@ void conv_tile_kernel(const CtArgs a) {
                   gz = z0 * a.sz - a.pz + (int)(v - q * Lz);
         if ((unsigned)gx < (unsigned)(a.Xi << U) && (unsigned)gy < (unsigned)(a.Yi << U) &&
             (unsigned)gz < (unsigned)a.Zi) {
-          // 32-bit arithmetic: the host checked that the whole tensor is below 2^32 elements
-          const unsigned vox = ((((unsigned)b * a.Xi + (gx >> U)) * a.il_m + a.il_ox) * (a.Yi * a.il_m) +
+          // 32-bit arithmetic on the voxel index relative to plane gx_lo (the host checked the halo's extent)
+          const unsigned vox = ((((unsigned)((gx >> U) - gx_lo)) * a.il_m + a.il_ox) * (a.Yi * a.il_m) +
                                 (gy >> U) * a.il_m + a.il_oy) * a.Zi + gz;
           off = vox * (unsigned)a.in_ctot + (unsigned)(a.in_off + 8 * pl);
         }
@@ -267,7 +273,7 @@ void conv_tile_kernel(const CtArgs a) {
       const int u = wave + WAVES * k;
       if (u >= u0 && u < u1) {
         const bool ok = xoff[k] != 0xFFFFFFFFu && (chunk + c_begin) * CK + xo8[VM ? 0 : k] < a.cin_valid;
-        const unsigned short* src = ok ? a.in + (size_t)xoff[k] + (chunk + c_begin) * CK
+        const unsigned short* src = ok ? in_base + (size_t)xoff[k] + (chunk + c_begin) * CK
                                        : reinterpret_cast<const unsigned short*>(a.zero16);
         glds16(src, dst + (VM ? u * 1024 : xdst[VM ? 0 : k]));
       }
@@ -654,7 +660,10 @@ int launch_ct(CtArgs& a, hipStream_t st) {
   }
   if (ts_max < 1) return WSR_EUNSUPPORTED;
   if ((VM ? (L + 31) / 32 : ((L + 63) / 64) * PL) > ct_xk(WAVES, TM) * WAVES) return WSR_EUNSUPPORTED;  // XK units per wave
-  if ((long)a.B * a.Xi * a.Yi * a.Zi * a.in_ctot * (a.il_m * a.il_m) >= 0xFFFFFFFFL) return WSR_EUNSUPPORTED;  // 32-bit element offsets
+  {  // 32-bit element offsets relative to the halo's first x-plane: (stored planes the halo spans + 1) x plane size
+    const long lx = ((long)(a.TX - 1) * a.sx + a.KX + 1) * a.il_m + 1;
+    if (lx * a.Yi * a.il_m * a.Zi * a.in_ctot >= 0xFFFFFFFFL) return WSR_EUNSUPPORTED;
+  }
   const int nph = (a.nts + ts_max - 1) / ts_max;
   a.TS = (a.nts + nph - 1) / nph;  // balanced stages
   const size_t lds = (size_t)a.off_ws + (size_t)2 * a.TS * NTW * 1024;

@@ -482,6 +482,44 @@ __global__ void bn_bwd_apply_kernel(const typename T::elem* __restrict__ g, cons
   }
 }
 
+// The same, 8 bf16 per thread (C a multiple of 8), with the LeakyReLU derivative of the layer's OUTPUT `act` folded in
+// (eval-mode BatchNorm in a pass that wants no parameter gradients - D inside a generator iteration: one pass over
+// the gradient instead of lrelu_bwd + this).
+__global__ void bn_bwd_apply_v8_kernel(const unsigned short* __restrict__ g, const unsigned short* __restrict__ x,
+                                       unsigned short* dx, const unsigned short* __restrict__ act, float slope,
+                                       const float* mean, const float* invstd, const float* gamma, const float* sums,
+                                       float inv_n, int C, long nvox) {
+  const long total8 = nvox * C / 8;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total8; i += (long)gridDim.x * blockDim.x) {
+    const int c0 = (int)((i * 8) % C);
+    const uint4 gv = *reinterpret_cast<const uint4*>(g + i * 8);
+    uint4 av = make_uint4(0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u), xv = make_uint4(0u, 0u, 0u, 0u);
+    if (act) av = *reinterpret_cast<const uint4*>(act + i * 8);
+    if (sums) xv = *reinterpret_cast<const uint4*>(x + i * 8);
+    const unsigned gw[4] = {gv.x, gv.y, gv.z, gv.w}, aw[4] = {av.x, av.y, av.z, av.w}, xw[4] = {xv.x, xv.y, xv.z, xv.w};
+    unsigned ow[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      float r[2];
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int c = c0 + 2 * k + h;
+        const unsigned short gb = h ? (unsigned short)(gw[k] >> 16) : (unsigned short)(gw[k] & 0xFFFFu);
+        const unsigned short ab = h ? (unsigned short)(aw[k] >> 16) : (unsigned short)(aw[k] & 0xFFFFu);
+        float v = bf2f(gb) * ((short)ab > 0 ? 1.f : slope);  // bf16 sign test on the raw bits: y > 0
+        if (sums) {
+          const unsigned short xb = h ? (unsigned short)(xw[k] >> 16) : (unsigned short)(xw[k] & 0xFFFFu);
+          const float xh = (bf2f(xb) - mean[c]) * invstd[c];
+          v = v - sums[c] * inv_n - xh * sums[C + c] * inv_n;
+        }
+        r[h] = v * gamma[c] * invstd[c];
+      }
+      ow[k] = (unsigned)f2bf(r[0]) | ((unsigned)f2bf(r[1]) << 16);
+    }
+    *reinterpret_cast<uint4*>(dx + i * 8) = make_uint4(ow[0], ow[1], ow[2], ow[3]);
+  }
+}
+
 // ---- Adam --------------------------------------------------------------------------------
 __global__ void adam_kernel(float* p, const float* __restrict__ g, float* m, float* v, long n, float step_size,
                             float beta1, float beta2, float eps, float wd, float bc2_sqrt) {
@@ -1094,10 +1132,18 @@ extern "C" int wsr_bn_bwd_reduce(void* dy, const void* y, const void* x, const f
 }
 
 extern "C" int wsr_bn_bwd_apply(const void* g, const void* x, void* dx, const float* mean, const float* invstd,
-                                const float* gamma, const float* sums, float inv_n, int32_t C, int64_t nvox,
-                                int32_t dtype, void* stream) {
+                                const float* gamma, const float* sums, float inv_n, const void* act_y, float slope,
+                                int32_t C, int64_t nvox, int32_t dtype, void* stream) {
   if (!g || !x || !dx || !mean || !invstd || !gamma || C <= 0 || nvox <= 0) return WSR_EINVAL;
   const long total = nvox * C;
+  if (dtype == WSR_BF16 && C % 8 == 0 && !(((size_t)g | (size_t)x | (size_t)dx | (size_t)act_y) & 15)) {
+    hipLaunchKernelGGL(bn_bwd_apply_v8_kernel, dim3(ew_grid(total / 8)), dim3(EW_BLOCK), 0, as_stream(stream),
+                       (const unsigned short*)g, (const unsigned short*)x, (unsigned short*)dx,
+                       (const unsigned short*)act_y, slope, mean, invstd, gamma, sums, inv_n, C, (long)nvox);
+    WSR_LAUNCH_CHECK();
+    return 0;
+  }
+  if (act_y) return WSR_EUNSUPPORTED;  // the caller runs wsr_lrelu_bwd_inplace first
   DISPATCH_T(dtype,
              hipLaunchKernelGGL(bn_bwd_apply_kernel<BF16>, dim3(ew_grid(total)), dim3(EW_BLOCK), 0, as_stream(stream),
                                 (const unsigned short*)g, (const unsigned short*)x, (unsigned short*)dx, mean, invstd,

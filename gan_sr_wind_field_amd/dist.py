@@ -30,17 +30,23 @@ import torch.distributed as dist
 
 Tensor = torch.Tensor
 
-#: ledger of the attached DataParallel (the autograd functions below have no handle on it)
-_STATS: list = [None]
+#: ledgers of the attached DataParallel objects by process group (the autograd functions below only know their group)
+_LEDGERS: dict = {}
 
 
-def _note(kind: str, t: "Tensor") -> None:
-    if _STATS[0] is not None:
-        _STATS[0].add(kind, t)
+def _gkey(group) -> int:
+    return 0 if group is None else id(group)
 
 
-def _timed(kind: str, t: "Tensor"):
-    return _STATS[0].bracket(kind, t) if _STATS[0] is not None else _NULL_BRACKET
+def _note(kind: str, t: "Tensor", group=None) -> None:
+    st = _LEDGERS.get(_gkey(group))
+    if st is not None:
+        st.add(kind, t)
+
+
+def _timed(kind: str, t: "Tensor", group=None):
+    st = _LEDGERS.get(_gkey(group))
+    return st.bracket(kind, t) if st is not None else _NULL_BRACKET
 
 
 def init_from_env(backend: Optional[str] = None, single_rank: bool = False) -> bool:
@@ -62,7 +68,16 @@ def init_from_env(backend: Optional[str] = None, single_rank: bool = False) -> b
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend == "nccl":
             torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
-        dist.init_process_group(backend=backend)
+        if world <= 1:
+            # a group of one needs no TCP store: a private file keeps two such runs on one box (or one next to a real
+            # torchrun job on the default port) from colliding on MASTER_PORT
+            import tempfile
+            fd, path = tempfile.mkstemp(prefix="wsr_pg_")
+            os.close(fd)
+            os.unlink(path)
+            dist.init_process_group(backend=backend, init_method=f"file://{path}", rank=0, world_size=1)
+        else:
+            dist.init_process_group(backend=backend)
     return True
 
 
@@ -74,8 +89,8 @@ class _BatchMean(torch.autograd.Function):
     def forward(ctx, t: Tensor, group):
         # equal shards per rank: the global element count is numel * world (no device round trip)
         total = t.sum().float().reshape(1)
-        _note("scalar", total)
-        with _timed("scalar", total):
+        _note("scalar", total, group)
+        with _timed("scalar", total, group):
             dist.all_reduce(total, group=group)
         count = float(t.numel() * dist.get_world_size(group))
         ctx.group, ctx.count, ctx.shape, ctx.dtype = group, count, t.shape, t.dtype
@@ -84,12 +99,38 @@ class _BatchMean(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g: Tensor):
         g = g.clone().float()
-        _note("scalar", g)
-        with _timed("scalar", g):
+        _note("scalar", g, ctx.group)
+        with _timed("scalar", g, ctx.group):
             dist.all_reduce(g, group=ctx.group)
         # the later gradient average over ranks divides by N once more, exactly as it does
         # for every other term of the per-rank mean losses
         return (g / ctx.count).to(ctx.dtype).expand(ctx.shape), None
+
+
+class _BatchMean2(torch.autograd.Function):
+    """(mean a, mean b) over the global batch in ONE collective per pass - the two average logits of the relativistic
+    average GAN losses (reference wind_field_GAN_3D.py:360-364, 552-556) are needed together: 2 + 2 scalar
+    collectives per loss become 1 + 1."""
+
+    @staticmethod
+    def forward(ctx, a: Tensor, b: Tensor, group):
+        tot = torch.stack([a.sum().float(), b.sum().float()])
+        _note("scalar", tot, group)
+        with _timed("scalar", tot, group):
+            dist.all_reduce(tot, group=group)
+        world = dist.get_world_size(group)
+        ctx.group = group
+        ctx.meta = ((float(a.numel() * world), a.shape, a.dtype), (float(b.numel() * world), b.shape, b.dtype))
+        return (tot[0] / ctx.meta[0][0]).to(a.dtype), (tot[1] / ctx.meta[1][0]).to(b.dtype)
+
+    @staticmethod
+    def backward(ctx, ga: Tensor, gb: Tensor):
+        g = torch.stack([ga.reshape(()).float(), gb.reshape(()).float()])
+        _note("scalar", g, ctx.group)
+        with _timed("scalar", g, ctx.group):
+            dist.all_reduce(g, group=ctx.group)
+        (ca, sa, da), (cb, sb, db) = ctx.meta
+        return (g[0] / ca).to(da).expand(sa), (g[1] / cb).to(db).expand(sb), None
 
 
 class _GlobalMax(torch.autograd.Function):
@@ -102,8 +143,8 @@ class _GlobalMax(torch.autograd.Function):
     @staticmethod
     def forward(ctx, t: Tensor, group):
         g = t.detach().clone()
-        _note("scalar", g)
-        with _timed("scalar", g):
+        _note("scalar", g, group)
+        with _timed("scalar", g, group):
             dist.all_reduce(g, op=dist.ReduceOp.MAX, group=group)
         ctx.group = group
         ctx.save_for_backward(t.detach() == g)
@@ -113,8 +154,8 @@ class _GlobalMax(torch.autograd.Function):
     def backward(ctx, grad: Tensor):
         (owner,) = ctx.saved_tensors
         grad = grad.clone()
-        _note("scalar", grad)
-        with _timed("scalar", grad):
+        _note("scalar", grad, ctx.group)
+        with _timed("scalar", grad, ctx.group):
             dist.all_reduce(grad, group=ctx.group)
         return grad * owner.to(grad.dtype), None
 
@@ -193,7 +234,7 @@ _NULL_BRACKET = _NullBracket()
 
 
 class DataParallel:
-    def __init__(self, group=None, bucket_mb: float = 32.0, sync_bn: bool = True):
+    def __init__(self, group=None, bucket_mb: float = 32.0, sync_bn: bool = True, tail_mb: float = 1.0):
         if not dist.is_initialized():
             raise RuntimeError("torch.distributed is not initialised (use init_from_env or torchrun)")
         self.group = group
@@ -205,12 +246,19 @@ class DataParallel:
         self._pending: List = []      # (work, tensor) of in-flight gradient buckets
         self._open = {}               # program id -> [flat, lo, hi] of the bucket being filled
         self.n_collectives = 0        # bookkeeping for tests / DESIGN.md numbers
+        #: buckets shrink towards the end of a backward pass: the final collective cannot hide under anything, so a bucket
+        #: also closes once it holds at least as much as everything still to come (>= tail_mb) - 32, 32, ..., 16, 8, 4, 2, 1
+        self.tail_elems = max(1, int(tail_mb * 1024 * 1024 / 4))
         self.stats = CommStats()
-        _STATS[0] = self.stats
+        _LEDGERS[_gkey(group)] = self.stats  # (one ledger per process group: a later DataParallel on another group keeps its own)
 
     # ---- collectives used inside the step ----------------------------------------
     def batch_mean(self, t: Tensor) -> Tensor:
         return _BatchMean.apply(t, self.group)
+
+    def batch_means(self, a: Tensor, b: Tensor):
+        """(global mean of a, global mean of b) with one collective per pass"""
+        return _BatchMean2.apply(a, b, self.group)
 
     def global_max(self, t: Tensor) -> Tensor:
         """maximum over the ranks; differentiable when ``t`` is (see :class:`_GlobalMax`)"""
@@ -256,7 +304,8 @@ class DataParallel:
             cur = [flat, lo, lo]
             self._open[key] = cur
         cur[2] = hi
-        if cur[2] - cur[1] >= self.bucket_elems:
+        size, remaining = cur[2] - cur[1], flat.numel() - hi
+        if size >= self.bucket_elems or (size >= self.tail_elems and size >= remaining):
             if before_launch is not None:
                 before_launch()
             self._avg_async(flat[cur[1]:cur[2]])

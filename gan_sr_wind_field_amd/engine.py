@@ -911,25 +911,15 @@ class GeneratorProgram(ProgramBase):
         else:
             run()
 
-    # ---- forward -------------------------------------------------------------------
-    def forward(self, x: Tensor, Z: Tensor, training: bool, save: bool, drop_scale: Optional[Tensor]):
-        """x (B, Cin, X, Y, nz), Z (B, 1, sX, sY, nz) planar fp32 -> (B, 3, sX, sY, nz) fp32 (+ saved state)"""
-        B, _, X, Y, nz = x.shape
-        nf, gc, tf, sl = self.nf, self.gc, self.tf, self.slope
-        ops._need_cuda(x, Z, self.feature.weight)  # inputs and parameters on the current device
-        self.refresh_filters(backward=save)
-        x = x.contiguous().float()
-        Z = Z.contiguous().float()
-        cin_p = self.cp(self.feature.cin)
-        x_nd = self._empty((B, X, Y, nz, cin_p), x)
-        ops.planar_to_ndhwc(x, x_nd, 0, cin_p)
+    def _trunk(self, first: Tensor, x: Tensor, bufs: List[Tensor]) -> Tensor:
+        """the RRDB stack on ``first`` (block input in channels [0, nf) of a dense buffer); appends every block's dense
+        buffer to ``bufs`` (the backward pass reads them) and returns the stack's output (nf channels)"""
+        nf, gc, sl = self.nf, self.gc, self.slope
+        B, X, Y, nz = first.shape[:4]
         nconv = len(self.rrdbs[0][0][0]) if self.rrdbs else 0
         dense = nf + nconv * gc
         total_rdbs = sum(len(r) for r in self.rrdbs)
-        first = self._empty((B, X, Y, nz, dense if total_rdbs else nf), x)
-        self.conv(self.feature, x_nd, 0, first, 0)
         buf = first
-        bufs: List[Tensor] = []
         seen = 0
         for rdbs, rr_scale in zip(self.rrdbs, self.rrdb_scales):
             rr_in = buf
@@ -953,6 +943,27 @@ class GeneratorProgram(ProgramBase):
             # RRDB residual: out = rr_scale * chain + x_rr
             if not (rdbs and fold):
                 ops.chan_axpby(buf, 0, rr_in, 0, nf, alpha=1.0, beta=rr_scale)
+        return buf
+
+    # ---- forward -------------------------------------------------------------------
+    def forward(self, x: Tensor, Z: Tensor, training: bool, save: bool, drop_scale: Optional[Tensor]):
+        """x (B, Cin, X, Y, nz), Z (B, 1, sX, sY, nz) planar fp32 -> (B, 3, sX, sY, nz) fp32 (+ saved state)"""
+        B, _, X, Y, nz = x.shape
+        nf, gc, tf, sl = self.nf, self.gc, self.tf, self.slope
+        ops._need_cuda(x, Z, self.feature.weight)  # inputs and parameters on the current device
+        self.refresh_filters(backward=save)
+        x = x.contiguous().float()
+        Z = Z.contiguous().float()
+        cin_p = self.cp(self.feature.cin)
+        x_nd = self._empty((B, X, Y, nz, cin_p), x)
+        ops.planar_to_ndhwc(x, x_nd, 0, cin_p)
+        nconv = len(self.rrdbs[0][0][0]) if self.rrdbs else 0
+        dense = nf + nconv * gc
+        total_rdbs = sum(len(r) for r in self.rrdbs)
+        first = self._empty((B, X, Y, nz, dense if total_rdbs else nf), x)
+        self.conv(self.feature, x_nd, 0, first, 0)
+        bufs: List[Tensor] = []
+        buf = self._trunk(first, x, bufs)
         t_last = buf
         s = self._empty((B, X, Y, nz, nf), x)
         self.conv(self.lr_conv, t_last, 0, s, 0, res=first, res_off=0, beta=1.0)
@@ -1065,16 +1076,22 @@ class GeneratorProgram(ProgramBase):
         del gt0
         # ---- up-convs, last to first.  g lives in window [0, nf) of gbuf
         gbuf = ghcat
+        masked = False  # gbuf already carries the LeakyReLU derivative of the up-conv output it is the gradient of
         for u in reversed(range(len(self.ups))):
             site, (inp, outp) = self.ups[u], saved["up_io"][u]
-            ops.lrelu_bwd_(gbuf, 0, outp, 0, nf, sl)
+            if not masked:
+                ops.lrelu_bwd_(gbuf, 0, outp, 0, nf, sl)
+            masked = False
             if self.subpixel_active(u) and SUBPIXEL_WGRAD:
                 self.up_wgrad(u, inp, gbuf, flat, sp)
             else:
                 self.wgrad(site, inp, 0, gbuf, 0, flat, sp, scratch)
             gin = self._empty(inp.shape, g_out)
             if self.subpixel_active(u):
-                self.up_dgrad(u, gbuf, gin)
+                # the input of up-conv u is the LeakyReLU output of up-conv u - 1: its derivative rides on the epilogue
+                # of the last parity launch instead of a pass of its own
+                masked = u > 0
+                self.up_dgrad(u, gbuf, gin, mask=(inp, 0, 0, nf) if masked else None)
             else:
                 fine = self._empty((B, inp.shape[1] * 2, inp.shape[2] * 2, nz, nf), g_out)
                 self.dgrad(site, gbuf, 0, fine, 0, tuple(inp.shape[1:4]))
@@ -1598,14 +1615,19 @@ class DiscriminatorProgram(ProgramBase):
                                          sums_all[gi - g0], 1.0 / r["count"][gi])
                 else:
                     mean, invstd = r["mean"][0], r["invstd"][0]
-                    if l.act:
-                        ops.lrelu_bwd_(g, 0, act_o, 0, g.shape[-1], sl)
-                    if need_dw:  # eval-mode BN: d beta = sum g, d gamma = sum g * xhat
-                        sums = torch.empty(2 * C_, dtype=torch.float32, device=dev)
-                        ops.bn_bwd_reduce(g, act_o, y_o, mean, invstd, False, sl, sums)
-                        sp.view(flat, bn.bias).copy_(sums[:C_])
-                        sp.view(flat, bn.weight).copy_(sums[C_:])
-                    ops.bn_bwd_apply(g, y_o, gy, mean, invstd, bn.weight.detach(), None, 0.0)
+                    # (no parameter gradients wanted - D inside a generator iteration: the LeakyReLU derivative rides
+                    # on the BatchNorm pass instead of a pass of its own)
+                    fused = (l.act and not need_dw and
+                             ops.bn_bwd_apply(g, y_o, gy, mean, invstd, bn.weight.detach(), None, 0.0, act_y=act_o, slope=sl))
+                    if not fused:
+                        if l.act:
+                            ops.lrelu_bwd_(g, 0, act_o, 0, g.shape[-1], sl)
+                        if need_dw:  # eval-mode BN: d beta = sum g, d gamma = sum g * xhat
+                            sums = torch.empty(2 * C_, dtype=torch.float32, device=dev)
+                            ops.bn_bwd_reduce(g, act_o, y_o, mean, invstd, False, sl, sums)
+                            sp.view(flat, bn.bias).copy_(sums[:C_])
+                            sp.view(flat, bn.weight).copy_(sums[C_:])
+                        ops.bn_bwd_apply(g, y_o, gy, mean, invstd, bn.weight.detach(), None, 0.0)
             inp = r["inp"][lo:]
             lattice_ok = (li in self.dparity and tuple(inp.shape[1:3]) == (2 * gy.shape[1], 2 * gy.shape[2])
                           and inp.shape[3] == s.stride[2] * gy.shape[3] and inp.shape[-1] == self.cp(s.cin))

@@ -766,10 +766,16 @@ def bn_bwd_reduce(dy: Tensor, y: Tensor, x: Tensor, mean: Tensor, invstd: Tensor
 
 
 def bn_bwd_apply(g: Tensor, x: Tensor, dx: Tensor, mean: Tensor, invstd: Tensor, gamma: Tensor,
-                 sums: Optional[Tensor], inv_n: float) -> None:
+                 sums: Optional[Tensor], inv_n: float, act_y: Optional[Tensor] = None, slope: float = 0.2) -> bool:
+    """``act_y``: fold the LeakyReLU derivative of the layer's saved output into the pass (bf16, C % 8 == 0);
+    returns False when that form is not available (nothing was launched: run ``lrelu_bwd_`` and call again without)"""
     C_ = x.shape[-1]
-    check(_lib.lib().wsr_bn_bwd_apply(_p(g), _p(x), _p(dx), _p(mean), _p(invstd), _p(gamma), _p(sums), inv_n, C_,
-                                      x.numel() // C_, dtype_id(x.dtype), _stream()), "bn_bwd_apply")
+    rc = _lib.lib().wsr_bn_bwd_apply(_p(g), _p(x), _p(dx), _p(mean), _p(invstd), _p(gamma), _p(sums), inv_n, _p(act_y),
+                                     slope, C_, x.numel() // C_, dtype_id(x.dtype), _stream())
+    if rc == _lib.WSR_EUNSUPPORTED and act_y is not None:
+        return False
+    check(rc, "bn_bwd_apply")
+    return True
 
 
 def adam_step(p: Tensor, g: Tensor, m: Tensor, v: Tensor, lr: float, beta1: float, beta2: float, eps: float,

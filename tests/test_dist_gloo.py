@@ -178,6 +178,19 @@ def test_bench_launcher_starts_one_rank_per_gpu():
     assert r1.returncode == 0 and json.loads(r1.stdout.splitlines()[-1])["ranks"] == [[0, 0]]
 
 
+def test_bench_launcher_rendezvous_of_eight_ranks():
+    """the driver's N = 8 command line, as far as it can be rehearsed without GPUs: ``--gpus 8`` becomes eight ranks
+    that all answer one all-reduce (gloo) with distinct (RANK, LOCAL_RANK) pairs, and rank 0 prints the one line"""
+    import json
+    r = _run_bench(["--gpus", "8", "--dry-launch"], timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1  # rank 0 only
+    out = json.loads(lines[0])
+    assert out["dry_launch"] and out["n_gpus"] == 8
+    assert sorted(map(tuple, out["ranks"])) == [(i, i) for i in range(8)]
+
+
 def test_bench_refuses_a_mislabelled_world():
     """inside a torchrun environment whose WORLD_SIZE differs from --gpus the run stops instead of printing a
     line with the wrong n_gpus"""
@@ -202,8 +215,24 @@ def _ledger_worker(rank, world, port, out_dir):
     dp.stat_allreduce(s)
     m = dp.global_max(torch.tensor([float(rank)]))
     mean = dp.batch_mean(torch.tensor([float(rank), float(rank)]))
-    torch.save(dict(flat=flat, stat=stat, s=s, m=m, mean=mean, comm=dp.stats.summary(1)),
-               os.path.join(out_dir, f"r{rank}.pt"))
+    # both RaGAN average logits in ONE collective per pass (forward and backward)
+    a = torch.tensor([float(rank), 2.0 * rank], requires_grad=True)
+    b = torch.tensor([1.0 + rank], requires_grad=True)
+    ma, mb = dp.batch_means(a, b)
+    (3.0 * ma + 5.0 * mb).backward()
+    comm = dp.stats.summary(1)
+    # buckets shrink towards the end of the pass (tail_mb): a second ledger on its own would be the same object here,
+    # so the sizes are read off the collectives' tensors
+    dp2 = wdist.DataParallel(bucket_mb=4 * 100 / 2**20, tail_mb=4 * 10 / 2**20)
+    sizes = []
+    avg = dp2._avg_async
+    dp2._avg_async = lambda t: (sizes.append(t.numel()), avg(t))[1]
+    flat2 = torch.full((450,), float(rank + 1))
+    for lo in range(0, 450, 10):
+        dp2.grad_ready("G", flat2, lo, lo + 10)
+    dp2.grad_done("G")
+    torch.save(dict(flat=flat, stat=stat, s=s, m=m, mean=mean, comm=comm, ma=ma.detach(), mb=mb.detach(), ga=a.grad,
+                    gb=b.grad, sizes=sizes, flat2=flat2), os.path.join(out_dir, f"r{rank}.pt"))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -218,5 +247,12 @@ def test_comm_ledger_counts_collectives_and_bytes(tmp_path):
     c = r["comm"]
     assert c["grad_bucket_collectives_per_step"] == 5            # 4 full buckets of 100 + the 50-float tail
     assert abs(c["grad_mbytes_per_step"] - 450 * 4 / 1e6) < 1e-3
-    assert c["syncbn_collectives_per_step"] == 2 and c["scalar_collectives_per_step"] == 2
-    assert c["collectives_per_step"] == 9 and c["timed"] is False and c["exposed_grad_wait_ms_per_step"] is None
+    assert c["syncbn_collectives_per_step"] == 2
+    assert c["scalar_collectives_per_step"] == 4                 # global_max, batch_mean, batch_means forward + backward
+    assert c["collectives_per_step"] == 11 and c["timed"] is False and c["exposed_grad_wait_ms_per_step"] is None
+    # means over the global batch (rank 0: a = [0, 0], b = [1]; rank 1: a = [1, 2], b = [2]) and their gradients:
+    # d(3 ma + 5 mb) summed over both ranks' losses = 6 / 4 per element of a, 10 / 2 per element of b
+    assert abs(float(r["ma"]) - 0.75) < 1e-6 and abs(float(r["mb"]) - 1.5) < 1e-6
+    assert torch.allclose(r["ga"], torch.full((2,), 1.5)) and torch.allclose(r["gb"], torch.full((1,), 5.0))
+    # geometric tail: full buckets, then each bucket at least as large as what is still to come; the last one is tiny
+    assert r["sizes"] == [100, 100, 100, 80, 40, 20, 10] and torch.allclose(r["flat2"], torch.full((450,), 1.5))

@@ -532,6 +532,18 @@ def test_batchnorm_kernels(hip, dt, C_):
     dxb = torch.empty_like(xb)
     o.bn_bwd_apply(gb, xb, dxb, mean, invstd, g_d, s2, 1.0 / n)
     assert rel_l2(dxb.float().cpu(), xl.grad.permute(0, 2, 3, 4, 1).float()) < (1e-4 if dt == torch.float32 else 1.5e-2)
+    # eval mode, no parameter gradients (D inside a generator iteration): the LeakyReLU derivative of the layer's output
+    # rides on the BatchNorm pass (ABI 6) - equal to lrelu_bwd followed by the plain eval-mode pass
+    g0 = gy.to(DEV).to(dt)
+    want = g0.clone()
+    o.lrelu_bwd_(want, 0, yb, 0, C_, 0.2)
+    ref = torch.empty_like(xb)
+    assert o.bn_bwd_apply(want, xb, ref, mean, invstd, g_d, None, 0.0)
+    got = torch.full_like(xb, float("nan"))
+    fused = o.bn_bwd_apply(g0, xb, got, mean, invstd, g_d, None, 0.0, act_y=yb, slope=0.2)
+    assert fused == (dt == torch.bfloat16 and C_ % 8 == 0)
+    if fused:  # (one bf16 rounding instead of two)
+        assert rel_l2(got.float().cpu(), ref.float().cpu()) < 6e-3
 
 
 def test_adam_matches_torch(hip):
@@ -1010,6 +1022,41 @@ def test_conv_slide_input_gradient_vs_cpu(hip, name, k, xyz, B, ctot, off, drop)
     assert rel_l2(got, ref) < 4e-3, name  # bf16 rounding of the result
     if off:
         assert bool((dxb[..., :off] == 7.0).all()), name
+
+
+def test_conv_tile_beyond_32_bit_element_offsets(hip):
+    """A 144-channel tensor of 512 x 512 x 128 voxels holds 4.8e9 elements (BASELINE.json configs[2] read literally):
+    the halo-tile kernel addresses it with 32-bit offsets relative to a 64-bit per-workgroup base.  The last x-planes of
+    a 3x3x3 144 -> 144 conv over the WHOLE tensor (19 GB of operands) equal, bit for bit, the same conv on a crop of
+    those planes + halo - which sits entirely below 2^32 and is pinned to the CPU conv by the other tests - and so do
+    the planes on both sides of the 2^32-element boundary; forward and input gradient."""
+    o = ops()
+    dt = torch.bfloat16
+    C_, X, Y, Z = 144, 512, 512, 128
+    assert X * Y * Z * C_ > 2 ** 32
+    gen = torch.Generator(device=DEV).manual_seed(9)
+    x = torch.empty((1, X, Y, Z, C_), dtype=dt, device=DEV)
+    for x0 in range(0, X, 32):  # (fill in slabs: randn makes an fp32 temporary)
+        x[:, x0:x0 + 32] = torch.randn((1, 32, Y, Z, C_), generator=gen, device=DEV).to(dt)
+    w = (torch.randn((C_, C_, 3, 3, 3), generator=gen, device=DEV) / math.sqrt(C_ * 27))
+    geom = o.ConvGeom(C_, C_, (3, 3, 3), (1, 1, 1), (1, 1, 1))
+    plane = Y * Z * C_
+    xb = 2 ** 32 // plane  # the x-plane that holds element 2^32
+    for transpose in (False, True):
+        wf = o.pack_filter_frag(w, transpose=transpose)
+        run = (lambda d, a, b: o.conv_dgrad_tile(d, a, wf, b)) if transpose else (lambda d, a, b: o.conv_fwd_tile(d, a, wf, b))
+        y = torch.empty_like(x)
+        assert run(o.make_desc(geom, dt, 1, (X, Y, Z), C_, 0, C_, 0), x, y)
+        for lo, hi in ((X - 10, X), (xb - 4, xb + 5)):
+            clo, chi = max(lo - 1, 0), min(hi + 1, X)
+            crop = x[:, clo:chi].contiguous()
+            yc = torch.empty_like(crop)
+            assert run(o.make_desc(geom, dt, 1, (chi - clo, Y, Z), C_, 0, C_, 0), crop, yc)
+            assert torch.isfinite(y[:, lo:hi].float()).all()
+            assert torch.equal(y[:, lo:hi], yc[:, lo - clo:hi - clo]), (transpose, lo, hi)
+        del y
+    del x
+    torch.cuda.empty_cache()
 
 
 @pytest.mark.parametrize("name,cin,cout,xyz,B,in_ctot,in_off,out_ctot,out_off,bias,act", [

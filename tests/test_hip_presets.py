@@ -4,6 +4,8 @@
   C1b   the reference's real patch size 32x32x10 -> 128x128x10, no slicing
   C2    generator-only fwd + bwd + Adam, fp32, 64x64x64 -> 256x256x64
   C3'   the benchmark default (full-size properties: test_hip_networks.py::test_full_size_c3_*)
+  C3lit BASELINE.json configs[2] read literally: generator-only at LR 128^3 -> 512 x 512 x 128 (144-channel HR tensors
+        of 4.8e9 elements: beyond 32-bit element offsets; D cannot consume 512 x 512)
   C4    the per-GPU shape of the 8-GPU run: C3' at batch 4
   C5b   upscale8 ini (x8, three UpConv stages), batch 8, 16x16x10 -> 128x128x10, full G + D step
   C5lit x8 generator-only at 64x64x64 -> 512x512x64 (4.8 GB per 144-channel HR tensor: the HBM stress case)
@@ -40,7 +42,7 @@ def _bench():
     return mod
 
 
-@pytest.mark.parametrize("preset", ["C1", "C1b", "C2", "C4", "C5b", "C5lit"])
+@pytest.mark.parametrize("preset", ["C1", "C1b", "C2", "C3lit", "C4", "C5b", "C5lit"])
 def test_preset_runs(hip, preset):
     from gan_sr_wind_field_amd.process_data import synthetic_batch
 
@@ -70,9 +72,9 @@ def test_preset_runs(hip, preset):
         a = gan.G(LR, Z)
         assert a.shape == (B, 3, s * n, s * n, nz) and torch.isfinite(a).all()
         assert torch.equal(a, gan.G(LR, Z))
-        # the fp32 program on the same weights - also for C5lit, whose 144-channel HR tensors hold 2.4e9 elements
-        # (9.7 GB in fp32): every kernel of the fp32 program indexes with 64-bit element offsets, the bf16 tile kernels
-        # refuse tensors beyond their 32-bit offsets (WSR_EUNSUPPORTED -> generic kernel)
+        # the fp32 program on the same weights - also for C5lit / C3lit, whose 144-channel HR tensors hold 2.4e9 / 4.8e9
+        # elements (19 GB in fp32 at C3lit): every kernel of the fp32 program indexes with 64-bit element offsets, the
+        # bf16 tile kernels with 32-bit offsets relative to the halo's first x-plane (64-bit workgroup base)
         if dtype == "bf16":
             sd = gan.G.state_dict()
             del gan
