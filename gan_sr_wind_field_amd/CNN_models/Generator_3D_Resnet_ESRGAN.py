@@ -24,6 +24,46 @@ from ..tools import loggingclass as lc
 from .torch_blocks import RRDB, SkipConnectionBlock, create_conv_lrelu_layer, create_UpConv_block
 
 
+class ProgramStack(nn.Sequential):
+    """``Generator_3D.model`` / ``.hr_convs`` / ``.terrain_convs``: the reference's ``nn.Sequential`` (same children,
+    same ``state_dict`` keys) whose elements are executed by the generator's HIP program.  Calling the stack, or a
+    slice of it - ``G.model[:2](LR)``, ``G.hr_convs[:-2](t)``, ``G.terrain_convs(Z)`` as in the reference's
+    ``plot_data.py:770-793`` - runs those elements one after the other on planar fp32 tensors (inference only: no
+    gradients); the training path is ``Generator_3D.forward``."""
+
+    def bind(self, owner: "Generator_3D", name: str, lo: int = 0):
+        import weakref
+        object.__setattr__(self, "_owner", weakref.ref(owner))  # (not a sub-module: no cycle in .modules())
+        object.__setattr__(self, "_stack", name)
+        object.__setattr__(self, "_lo", lo)
+        return self
+
+    def __getitem__(self, idx):
+        if not isinstance(idx, slice):
+            return super().__getitem__(idx)
+        n = len(self)
+        lo, hi, step = idx.indices(n)
+        if step != 1:
+            raise IndexError("slices of a program stack are contiguous")
+        sub = ProgramStack(*[super(ProgramStack, self).__getitem__(i) for i in range(lo, hi)])
+        return sub.bind(self._owner(), self._stack, self._lo + lo)
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        owner = getattr(self, "_owner", lambda: None)()
+        if owner is None:
+            raise RuntimeError("this stack is not bound to a Generator_3D")
+        if not x.is_cuda:
+            raise RuntimeError("Generator_3D runs on the MI355X HIP kernels only (no CPU fallback)")
+        prog = owner.program()
+        with torch.no_grad():
+            for k, child in enumerate(self):
+                if isinstance(child, (nn.Dropout3d, nn.Dropout)):
+                    x = child(x)  # (hr_convs[1]: identity in eval mode, torch's own mask otherwise)
+                else:
+                    x = prog.run_stage(self._stack, self._lo + k, x)
+        return x
+
+
 class Generator_3D(nn.Module, lc.GlobalLoggingClass):
     def __init__(self, in_channels: int, out_channels: int, number_of_features: int, number_of_RRDBs: int,
                  upscale: int = 4, hr_kern_size: int = 3, number_of_RDB_convs: int = 5, RDB_gc: int = 32,
@@ -75,9 +115,9 @@ class Generator_3D(nn.Module, lc.GlobalLoggingClass):
         upsampler = [create_UpConv_block(nf, nf, scale=2, lrelu_negative_slope=slope,
                                          number_of_z_layers=number_of_z_layers, mode=conv_mode)
                      for _ in range(n_up)]
-        self.model = nn.Sequential(feature_conv, shortcut, *upsampler)
-        self.hr_convs = nn.Sequential(*hr_convs)
-        self.terrain_convs = nn.Sequential(*terrain_convs)
+        self.model = ProgramStack(feature_conv, shortcut, *upsampler).bind(self, "model")
+        self.hr_convs = ProgramStack(*hr_convs).bind(self, "hr_convs")
+        self.terrain_convs = ProgramStack(*terrain_convs).bind(self, "terrain_convs")
         self._program = None
         self.status_logs.append("Generator: finished init")
 
@@ -121,4 +161,6 @@ class Generator_3D(nn.Module, lc.GlobalLoggingClass):
         memo[id(self)] = new
         for k, v in self.__dict__.items():
             setattr(new, k, None if k == "_program" else copy.deepcopy(v, memo))
+        for name in ("model", "hr_convs", "terrain_convs"):  # (the copies' stacks belong to the copy)
+            getattr(new, name).bind(new, name)
         return new

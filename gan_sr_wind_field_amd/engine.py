@@ -945,6 +945,74 @@ class GeneratorProgram(ProgramBase):
                 ops.chan_axpby(buf, 0, rr_in, 0, nf, alpha=1.0, beta=rr_scale)
         return buf
 
+    # ---- single stages (inference only) ---------------------------------------------
+    def run_stage(self, stack: str, idx: int, x: Tensor) -> Tensor:
+        """One element of ``Generator_3D.model`` / ``.terrain_convs`` / ``.hr_convs`` on a planar fp32
+        (B, C, X, Y, Z) tensor, as the reference's ``nn.Sequential`` children compute it - what
+        ``G.model[:2](LR)``, ``G.terrain_convs(Z)``, ``G.hr_convs[:-2](t)`` are made of (reference
+        plot_data.py:770-793).  No gradients, no saved state; the full forward pass stays ``GeneratorProgram.forward``."""
+        ops._need_cuda(x, self.feature.weight)
+        self.refresh_filters(backward=False)
+        x = x.detach().contiguous().float()
+        B, C_, X, Y, nz = x.shape
+        nf, sl = self.nf, self.slope
+
+        def to_nd(c_fill, ctot=None):
+            buf = self._empty((B, X, Y, nz, ctot or c_fill), x)
+            ops.planar_to_ndhwc(x, buf, 0, c_fill)
+            return buf
+
+        def need(c):
+            if C_ != c:
+                raise ValueError(f"{stack}[{idx}] takes {c} channels, got {C_}")
+
+        nconv = len(self.rrdbs[0][0][0]) if self.rrdbs else 0
+        dense = nf + nconv * self.gc if self.rrdbs else nf
+        if stack == "model" and idx == 0:      # feature conv
+            need(self.feature.cin)
+            y = self._empty((B, X, Y, nz, nf), x)
+            self.conv(self.feature, to_nd(self.cp(C_)), 0, y, 0)
+            return ops.ndhwc_to_planar(y, nf)
+        if stack == "model" and idx == 1:      # x + lr_conv(RRDB stack(x))
+            need(nf)
+            first = to_nd(nf, dense)
+            t_last = self._trunk(first, x, [])
+            y = self._empty((B, X, Y, nz, nf), x)
+            self.conv(self.lr_conv, t_last, 0, y, 0, res=first, res_off=0, beta=1.0)
+            return ops.ndhwc_to_planar(y, nf)
+        if stack == "model" and 2 <= idx < 2 + len(self.ups):   # nearest x(2,2,1) + conv + LeakyReLU
+            need(nf)
+            y = self._empty((B, 2 * X, 2 * Y, nz, nf), x)
+            self.up_conv(idx - 2, to_nd(nf), y)
+            return ops.ndhwc_to_planar(y, nf)
+        if stack == "terrain_convs" and idx in (0, 1):
+            site = (self.terrain0, self.terrain1)[idx]
+            need(site.cin)
+            y = self._empty((B, X, Y, nz, self.cp(site.cout)), x, zero=self.cp(site.cout) != site.cout)
+            if idx == 0:
+                self.conv(site, to_nd(self.cp(C_)), 0, y, 0, act=True, slope=sl)
+            else:
+                self.conv(site, to_nd(self.cp(C_)), 0, y, 0)
+            return ops.ndhwc_to_planar(y, site.cout)
+        if stack == "hr_convs" and idx == 0:   # conv + LeakyReLU (Dropout3d is hr_convs[1], a torch module)
+            need(self.hr0.cin)
+            y = self._empty((B, X, Y, nz, self.cp(self.hr0.cout)), x, zero=self.cp(self.hr0.cout) != self.hr0.cout)
+            self.conv(self.hr0, to_nd(self.cp(C_)), 0, y, 0, act=True, slope=sl)
+            return ops.ndhwc_to_planar(y, self.hr0.cout)
+        if stack == "hr_convs" and idx == 2:   # last conv (+ bias), planar out
+            need(self.hr1.cin)
+            h = to_nd(self.cp(C_))
+            out = torch.empty((B, self.hr1.cout, X, Y, nz), dtype=torch.float32, device=x.device)
+            if self.zfold_active():
+                kz = self.hr1.kernel[2]
+                parts = torch.empty((B, self.hr1.cout * kz, X, Y, nz), dtype=torch.float32, device=x.device)
+                self.conv(self.hr1z, h, 0, parts, 0, out_planar=True)
+                ops.zfold(parts, out, self.hr1.bias.detach() if self.hr1.bias is not None else None, kz, self.hr1.pad[2])
+            else:
+                self.conv(self.hr1, h, 0, out, 0, out_planar=True)
+            return out
+        raise IndexError(f"Generator_3D.{stack} has no element {idx} that runs on the HIP program")
+
     # ---- forward -------------------------------------------------------------------
     def forward(self, x: Tensor, Z: Tensor, training: bool, save: bool, drop_scale: Optional[Tensor]):
         """x (B, Cin, X, Y, nz), Z (B, 1, sX, sY, nz) planar fp32 -> (B, 3, sX, sY, nz) fp32 (+ saved state)"""

@@ -490,6 +490,50 @@ def test_gan_train_step_bf16_noise_dropout_runs(hip):
     assert not torch.equal(d0, gan.D.state_dict()["classifier.2.weight"])
 
 
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_generator_stacks_are_callable_and_sliceable(hip, dt):
+    """``G.model[:2](LR)``, ``G.model(LR)``, ``G.terrain_convs(Z)``, ``G.hr_convs[:-2](t)``, ``G.hr_convs[:-3](t)`` - what the
+    reference's ``plot_data.get_feature_maps`` (plot_data.py:770-793) calls - run through the HIP program and equal the
+    oracle's intermediate features; chained together with ``hr_convs[-1]`` they reproduce ``G(LR, Z)``."""
+    import torch.nn.functional as F
+
+    spec = onets.GSpec(in_channels=4, nf=16, n_rrdb=2, gc=8, tf=8, hr_kern=5, upscale=4)
+    G, sd = build_G(spec, dt, 21, scale=0.5)
+    G.eval()
+    LR, HR, Z, x, y = ogan.synthetic_batch(2, 6, 5, 4, seed=3)
+    LRd, Zd = LR.to(DEV), Z.to(DEV)
+    tol = 2e-5 if dt == torch.float32 else 2e-2
+    # oracle intermediates (reference Generator_3D_Resnet_ESRGAN.py:198-229)
+    f = F.conv3d(LR, sd["model.0.0.weight"], None, 1, 1)
+    t = f
+    for r in range(spec.n_rrdb):
+        t = onets.rrdb_forward(sd, f"model.1.module.{r}", t, spec)
+    lr_feat = f + F.conv3d(t, sd[f"model.1.module.{spec.n_rrdb}.0.weight"], None, 1, 1)
+    up_feat = onets.generator_trunk(sd, LR, spec)
+    ter = onets.terrain_features(sd, Z, spec)
+    pre = torch.cat((up_feat, ter), dim=1)
+    act = F.leaky_relu(F.conv3d(pre, sd["hr_convs.0.0.weight"], None, 1, 2), spec.slope)
+    with torch.no_grad():
+        got_lr = G.model[:2](LRd)
+        got_up = G.model(LRd)
+        got_ter = G.terrain_convs(Zd)
+        got_pre = torch.cat((got_up, got_ter), dim=1)
+        got_act = G.hr_convs[:-2](got_pre)
+        got_id = G.hr_convs[:-3](got_pre)
+        sr = G.hr_convs[-1:](G.hr_convs[1:2](got_act))
+        full = G(LRd, Zd)
+    assert got_lr.shape == lr_feat.shape and rel_l2(got_lr, lr_feat) < tol
+    assert got_up.shape == up_feat.shape and rel_l2(got_up, up_feat) < tol
+    assert rel_l2(G.model[2:](got_lr), up_feat) < tol       # a slice that starts in the middle
+    assert got_ter.shape == ter.shape and rel_l2(got_ter, ter) < tol
+    assert rel_l2(got_act, act) < tol
+    assert got_id is got_pre or torch.equal(got_id, got_pre)  # the empty slice is the identity, as for nn.Sequential
+    assert rel_l2(sr, full) < (1e-5 if dt == torch.float32 else 2e-2)
+    assert not got_lr.requires_grad and list(G.state_dict().keys()) == list(sd.keys())
+    with pytest.raises(RuntimeError):
+        G.model[:2](LR)  # CPU tensors: no fallback
+
+
 def test_full_size_generator_properties(hip):
     """Shipped-config G (34.77 M parameters) at 16x16x10 -> 64x64x10: linear response of the
     output to the last conv's bias, bf16 close to fp32, parameter gradients finite."""
