@@ -217,6 +217,8 @@ def main():
     ap.add_argument("--n", type=int, default=None, help="LR X=Y extent")
     ap.add_argument("--nz", type=int, default=None, help="vertical levels")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-fp32-side", action="store_true",
+                    help="skip the fp32 (reference arithmetic) side measurement of the default line")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="nccl = RCCL over xGMI")
     ap.add_argument("--one-device", action="store_true", help="every rank on cuda:0 (rehearsal with --backend gloo)")
     ap.add_argument("--dry-launch", action="store_true", help="rendezvous of the N ranks only (CPU, gloo)")

@@ -95,8 +95,8 @@ def lib() -> C.CDLL:
         "wsr_conv3d_fwd_tile": [C.POINTER(ConvDesc), vp, vp, vp, C.POINTER(Epilogue), vp],
         "wsr_conv3d_dgrad_tile": [C.POINTER(ConvDesc), vp, vp, vp, f32, C.c_int, C.c_int, C.POINTER(LreluMask),
                                   C.POINTER(DgradOpts), vp],
-        "wsr_pack_filter_frag": [vp, vp, i32, i32, i32, i32, i32, i32, vp],
-        "wsr_pack_filter_frag_multi": [vp, i32, vp],
+        "wsr_pack_filter_frag": [vp, vp, i32, i32, i32, i32, i32, i32, i32, vp],
+        "wsr_pack_filter_frag_multi": [vp, i32, i32, vp],
         "wsr_pack_filter": [vp, vp, i32, i32, i32, i32, i32, i32, vp],
         "wsr_unpack_wgrad": [vp, vp, i32, i32, i32, i32, f32, i32, vp],
         "wsr_unpack_wgrad_multi": [vp, i32, vp],
@@ -133,7 +133,7 @@ def lib() -> C.CDLL:
         fn = getattr(L, name)
         fn.argtypes = argtypes
         fn.restype = C.c_int
-    L.wsr_frag_filter_elems.argtypes = [i32, i32, i32]
+    L.wsr_frag_filter_elems.argtypes = [i32, i32, i32, i32]
     L.wsr_frag_filter_elems.restype = C.c_int64
     L.wsr_physics_loss_workspace_floats.argtypes = []
     L.wsr_physics_loss_workspace_floats.restype = C.c_int64

@@ -36,6 +36,7 @@ int wsr_ct_run_masked(CtArgs& a, int tpk, hipStream_t st);  // conv_tile_masked.
 int wsr_ct_run_narrow_masked(CtArgs& a, int tpk, hipStream_t st);  // conv_tile_narrow_masked.hip
 int wsr_ct_run_small(CtArgs& a, int tpk, hipStream_t st);          // conv_tile_small.hip
 int wsr_ct_run_strided(CtArgs& a, int tpk, hipStream_t st);        // conv_tile_strided.hip
+int wsr_ct_run_f32(CtArgs& a, int tpk, hipStream_t st);            // conv_tile_f32*.hip
 #ifdef WSR_TUNING
 int wsr_ct_run_w4(CtArgs& a, int tpk, int which, hipStream_t st);  // conv_tile_w4.hip (make TUNING=1)
 #endif
@@ -44,6 +45,7 @@ namespace {
 
 int dispatch_ct(CtArgs& a, int tpk, hipStream_t st) {
   const int N = a.Cout;
+  if (a.f32) return wsr_ct_run_f32(a, tpk, st);  // (stride 1 only: the entry points checked)
   if ((a.sx | a.sy | a.sz) != 1) return wsr_ct_run_strided(a, tpk, st);
 #ifdef WSR_TUNING
   if (WSR_ENV_SET("WSR_CT_W4")) {  // tuning switch: four-wave workgroups
@@ -78,22 +80,31 @@ int dispatch_ct(CtArgs& a, int tpk, hipStream_t st) {
 // transpose = 1: rows n = Cin, reduction c = Cout, taps flipped (input gradient).
 __device__ uint4 g_zero16 = {0u, 0u, 0u, 0u};
 
-__global__ void pack_frag_kernel(const float* __restrict__ w, unsigned short* __restrict__ out, int Cout, int Cin,
+// K-step shape of a reduction over `redp` stored channels (a multiple of the piece size `epp`): TPK taps x 32/TPK
+// bytes... in channels: bf16 (epp 8) 32 / 16 / 8 per tap, fp32 (epp 4) 16 / 8 / 4
+static inline int ct_tpk(int redp, int taps, int epp) {
+  if (taps == 1) return redp % (4 * epp) == 0 ? 1 : (redp % (2 * epp) == 0 ? 2 : 4);
+  return redp % (2 * epp) == 0 ? 2 : 4;
+}
+
+template <class T>
+__global__ void pack_frag_kernel(const float* __restrict__ w, typename T::elem* __restrict__ out, int Cout, int Cin,
                                  int KX, int KY, int KZ, int transpose, int TPK, int nchunks, int nts, int NT_total) {
-  const int PL = 4 / TPK, CK = 8 * PL;
+  constexpr int EPP = T::EPP;
+  const int PL = 4 / TPK, CK = EPP * PL;
   const int taps = KX * KY * KZ;
-  const long total = (long)nchunks * nts * NT_total * 512;
+  const long total = (long)nchunks * nts * NT_total * 64 * EPP;
   const int rows = transpose ? Cin : Cout, red = transpose ? Cout : Cin;
   for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
-    const int e = (int)(idx & 7);
-    const int lane = (int)((idx >> 3) & 63);
-    long q = idx >> 9;
+    const int e = (int)(idx % EPP);
+    const int lane = (int)((idx / EPP) & 63);
+    long q = idx / (64 * EPP);
     const int nt = (int)(q % NT_total); q /= NT_total;
     const int ts = (int)(q % nts);
     const int chunk = (int)(q / nts);
     const int i = lane & 15, g = lane >> 4;
     const int tap = ts * TPK + g / PL;
-    const int c = chunk * CK + (g % PL) * 8 + e;
+    const int c = chunk * CK + (g % PL) * EPP + e;
     const int n = nt * 16 + i;
     float v = 0.f;
     if (tap < taps && c < red && n < rows) {
@@ -103,7 +114,50 @@ __global__ void pack_frag_kernel(const float* __restrict__ w, unsigned short* __
         v = w[((long)c * Cin + n) * taps + (taps - 1 - tap)];
       }
     }
-    out[idx] = f2bf(v);
+    stf<T>(out + idx, v);
+  }
+}
+
+// The job-table form for any element type, one element per thread (gather): what the fp32 programs use - their
+// packing is < 0.1 % of a step; the bf16 programs take the LDS-staged kernel below.
+template <class T>
+__global__ void pack_frag_multi_gather_kernel(const wsr_pack_job_t* __restrict__ jobs) {
+  constexpr int EPP = T::EPP;
+  const wsr_pack_job_t j = jobs[blockIdx.y];
+  const int taps = j.KX * j.KY * j.KZ;
+  const bool part = j.red_total > 0;  // one source of a stacked dense-block filter
+  const int rows = part ? (j.transpose ? j.c_n : j.rows_total) : (j.transpose ? j.Cin : j.Cout);
+  const int red = part ? j.red_total : (j.transpose ? j.Cout : j.Cin);
+  const int redp = (red + EPP - 1) / EPP * EPP;
+  const int TPK = taps == 1 ? (redp % (4 * EPP) == 0 ? 1 : (redp % (2 * EPP) == 0 ? 2 : 4)) : (redp % (2 * EPP) == 0 ? 2 : 4);
+  const int PL = 4 / TPK, CK = EPP * PL;
+  const int nts = (taps + TPK - 1) / TPK, NT_total = (rows + 15) / 16;
+  const int chunk0 = part && j.transpose ? j.red_off / CK : 0;
+  const int nchunks = part && j.transpose ? (j.Cout + CK - 1) / CK : (redp + CK - 1) / CK;
+  const int nt0 = part && !j.transpose ? j.row_off / 16 : 0;
+  const int ntl = part && !j.transpose ? (j.Cout + 15) / 16 : NT_total;
+  const int src_rows = j.transpose ? (part ? j.c_n : j.Cin) : j.Cout;
+  const int src_red = j.transpose ? j.Cout : (part ? j.c_n : j.Cin);
+  const int c_lo = part ? j.c_lo : 0;
+  typename T::elem* __restrict__ out = reinterpret_cast<typename T::elem*>(j.out);
+  const long total = (long)nchunks * nts * ntl * 64 * EPP;
+  for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const int e = (int)(idx % EPP);
+    const int lane = (int)((idx / EPP) & 63);
+    long q = idx / (64 * EPP);
+    const int nt = (int)(q % ntl); q /= ntl;
+    const int ts = (int)(q % nts);
+    const int chunk = (int)(q / nts);
+    const int i = lane & 15, g = lane >> 4;
+    const int tap = ts * TPK + g / PL;
+    const int c = chunk * CK + (g % PL) * EPP + e;
+    const int n = nt * 16 + i;
+    float v = 0.f;
+    if (tap < taps && c < src_red && n < src_rows) {
+      const long tap_src = j.transpose ? taps - 1 - tap : tap;
+      v = j.transpose ? j.w[((long)c * j.Cin + c_lo + n) * taps + tap_src] : j.w[((long)n * j.Cin + c_lo + c) * taps + tap_src];
+    }
+    stf<T>(out + ((((long)(chunk0 + chunk) * nts + ts) * NT_total + nt0 + nt) * 64 + lane) * EPP + e, v);
   }
 }
 
@@ -253,8 +307,14 @@ int wsr_ct_splitk_reduce(const CtArgs& a, hipStream_t st) {
   return 0;
 }
 
-extern "C" int wsr_pack_filter_frag_multi(const wsr_pack_job_t* jobs_dev, int32_t n_jobs, void* stream) {
-  if (!jobs_dev || n_jobs <= 0 || n_jobs > 65535) return WSR_EINVAL;
+extern "C" int wsr_pack_filter_frag_multi(const wsr_pack_job_t* jobs_dev, int32_t n_jobs, int32_t dtype, void* stream) {
+  if (!jobs_dev || n_jobs <= 0 || n_jobs > 65535 || (dtype != WSR_BF16 && dtype != WSR_F32)) return WSR_EINVAL;
+  if (dtype == WSR_F32) {
+    hipLaunchKernelGGL(pack_frag_multi_gather_kernel<F32>, dim3(32, (unsigned)n_jobs), dim3(256), 0, as_stream(stream),
+                       jobs_dev);
+    WSR_LAUNCH_CHECK();
+    return 0;
+  }
   // workgroups per job: a generator's table is ~1 000 jobs of mostly 16-28 items (empty workgroups cost dispatch time),
   // a discriminator's 43 jobs of up to 512 (measured: 16 / 32 / 128 workgroups per job win at 940 / 398 / 43 jobs)
   int gx = WSR_ENV_INT("WSR_PK_GRID", n_jobs >= 512 ? 16 : (n_jobs >= 128 ? 32 : 128));
@@ -264,34 +324,40 @@ extern "C" int wsr_pack_filter_frag_multi(const wsr_pack_job_t* jobs_dev, int32_
   return 0;
 }
 
-extern "C" int wsr_conv_tile_tpk(int32_t red_channels_padded, int32_t taps) {
-  // K-step shape used by the tile kernel for a reduction over `red_channels_padded` (multiple of 8) channels
-  if (taps == 1) return red_channels_padded % 32 == 0 ? 1 : (red_channels_padded % 16 == 0 ? 2 : 4);
-  return red_channels_padded % 16 == 0 ? 2 : 4;
+extern "C" int wsr_conv_tile_tpk(int32_t red_channels_padded, int32_t taps, int32_t dtype) {
+  // K-step shape used by the tile kernel for a reduction over `red_channels_padded` stored channels
+  return ct_tpk(red_channels_padded, taps, dtype == WSR_F32 ? 4 : 8);
 }
 
-extern "C" int64_t wsr_frag_filter_elems(int32_t rows, int32_t red, int32_t taps) {
-  const int redp = (red + 7) / 8 * 8;
-  const int tpk = wsr_conv_tile_tpk(redp, taps);
-  const int ck = 32 / tpk;
+extern "C" int64_t wsr_frag_filter_elems(int32_t rows, int32_t red, int32_t taps, int32_t dtype) {
+  const int epp = dtype == WSR_F32 ? 4 : 8;
+  const int redp = (red + epp - 1) / epp * epp;
+  const int tpk = ct_tpk(redp, taps, epp);
+  const int ck = 4 * epp / tpk;
   const long nchunks = (redp + ck - 1) / ck, nts = (taps + tpk - 1) / tpk, nt = (rows + 15) / 16;
-  return nchunks * nts * nt * 512;
+  return nchunks * nts * nt * 64 * epp;
 }
 
 extern "C" int wsr_pack_filter_frag(const float* w, void* out, int32_t Cout, int32_t Cin, int32_t KX, int32_t KY,
-                                    int32_t KZ, int32_t transpose, void* stream) {
+                                    int32_t KZ, int32_t transpose, int32_t dtype, void* stream) {
   if (!w || !out || Cout <= 0 || Cin <= 0 || KX <= 0 || KY <= 0 || KZ <= 0) return WSR_EINVAL;
+  if (dtype != WSR_BF16 && dtype != WSR_F32) return WSR_EINVAL;
+  const int epp = dtype == WSR_F32 ? 4 : 8;
   const int taps = KX * KY * KZ;
   const int rows = transpose ? Cin : Cout, red = transpose ? Cout : Cin;
-  const int redp = (red + 7) / 8 * 8;
-  const int tpk = wsr_conv_tile_tpk(redp, taps);
-  const int ck = 32 / tpk;
+  const int redp = (red + epp - 1) / epp * epp;
+  const int tpk = ct_tpk(redp, taps, epp);
+  const int ck = 4 * epp / tpk;
   const int nchunks = (redp + ck - 1) / ck, nts = (taps + tpk - 1) / tpk, nt = (rows + 15) / 16;
-  const long total = (long)nchunks * nts * nt * 512;
+  const long total = (long)nchunks * nts * nt * 64 * epp;
   long grid = (total + 255) / 256;
   if (grid > 2048) grid = 2048;
-  hipLaunchKernelGGL(pack_frag_kernel, dim3((unsigned)grid), dim3(256), 0, as_stream(stream), w,
-                     (unsigned short*)out, Cout, Cin, KX, KY, KZ, transpose, tpk, nchunks, nts, nt);
+  if (dtype == WSR_F32)
+    hipLaunchKernelGGL(pack_frag_kernel<F32>, dim3((unsigned)grid), dim3(256), 0, as_stream(stream), w, (float*)out, Cout,
+                       Cin, KX, KY, KZ, transpose, tpk, nchunks, nts, nt);
+  else
+    hipLaunchKernelGGL(pack_frag_kernel<BF16>, dim3((unsigned)grid), dim3(256), 0, as_stream(stream), w,
+                       (unsigned short*)out, Cout, Cin, KX, KY, KZ, transpose, tpk, nchunks, nts, nt);
   WSR_LAUNCH_CHECK();
   return 0;
 }
@@ -300,10 +366,11 @@ extern "C" int wsr_pack_filter_frag(const float* w, void* out, int32_t Cout, int
 // as stored (multiple of 8), gather offset in = out - (px,py,pz) + tap.
 static int run_conv_tile(CtArgs& a, int red, hipStream_t st) {
   const int taps = a.KX * a.KY * a.KZ;
-  if (red % 8 || a.in_ctot % 8 || a.in_off % 8) return WSR_EUNSUPPORTED;
+  const int epp = a.f32 ? 4 : 8;
+  if (red % epp || a.in_ctot % epp || a.in_off % epp) return WSR_EUNSUPPORTED;
   if (a.KX > 8 || a.KY > 8 || a.KZ > 8) return WSR_EUNSUPPORTED;
-  const int tpk = wsr_conv_tile_tpk(red, taps);
-  const int ck = 32 / tpk;
+  const int tpk = ct_tpk(red, taps, epp);
+  const int ck = 4 * epp / tpk;
   a.nchunks = (red + ck - 1) / ck;
   a.cin_valid = red;
   {
@@ -354,9 +421,13 @@ int wsr_conv_thin3(const unsigned short* in, int in_ctot, int in_off, int red, c
 extern "C" int wsr_conv3d_fwd_tile(const wsr_conv_t* c, const void* x, const void* wfrag, void* y,
                                    const wsr_epilogue_t* ep, void* stream) {
   if (!conv_geom_ok(c) || !x || !wfrag || !y) return WSR_EINVAL;
-  if (c->dtype != WSR_BF16 || c->sx > 2 || c->sy > 2 || c->sz > 2 || c->lat == 3) return WSR_EUNSUPPORTED;
+  if (c->sx > 2 || c->sy > 2 || c->sz > 2 || c->lat == 3) return WSR_EUNSUPPORTED;
   if ((c->sx | c->sy | c->sz) != 1 && (c->upsample_xy || WSR_ENV_SET("WSR_CT_NOSTRIDE"))) return WSR_EUNSUPPORTED;
+  const bool f32 = c->dtype == WSR_F32;
+  // fp32 (the reference's own arithmetic): stride-1 convs on the same halo-tile kernel, WSR_NO_F32_TILE=1: generic kernel
+  if (f32 && ((c->sx | c->sy | c->sz) != 1 || WSR_ENV_SET("WSR_NO_F32_TILE"))) return WSR_EUNSUPPORTED;
   CtArgs a{};
+  a.f32 = f32 ? 1 : 0;
   a.sx = c->sx; a.sy = c->sy; a.sz = c->sz;
   a.in = (const unsigned short*)x;
   a.wf = (const unsigned short*)wfrag;
@@ -392,9 +463,10 @@ extern "C" int wsr_conv3d_fwd_tile(const wsr_conv_t* c, const void* x, const voi
     a.ol_m = 2; a.ol_ox = c->lat_ox; a.ol_oy = c->lat_oy;
     a.ol_mz = c->lat_mz > 1 ? c->lat_mz : 1; a.ol_oz = c->lat_oz;
     a.nphase = c->lat_phases == 4 ? 4 : 1;
-    a.ph_wstride = (long)wsr_frag_filter_elems(c->Cout, c->Cin, c->KX * c->KY * c->KZ);
+    a.ph_wstride = (long)wsr_frag_filter_elems(c->Cout, c->Cin, c->KX * c->KY * c->KZ, c->dtype);
   }
-  if (c->KX * c->KY * c->KZ == 1 && !c->lat && !a.ups && !a.out_planar && !a.chan_scale && (c->px | c->py | c->pz) == 0 &&
+  if (f32 && c->KX * c->KY * c->KZ == 1) return WSR_EUNSUPPORTED;  // (1x1x1 in fp32: the generic kernel)
+  if (!f32 && c->KX * c->KY * c->KZ == 1 && !c->lat && !a.ups && !a.out_planar && !a.chan_scale && (c->px | c->py | c->pz) == 0 &&
       (c->sx | c->sy | c->sz) == 1 && a.act <= 1 && a.act_c1 == 0x7FFFFFFF) {
     const int rc = wsr_conv1x1_bf16(a.in, a.in_ctot, a.in_off, c->Cin, a.wf, (unsigned short*)a.out, a.out_ctot,
                                     a.out_off, a.Cout, (long)c->B * c->Xo * c->Yo * c->Zo, a.bias, a.res, a.res_ctot,
@@ -406,7 +478,7 @@ extern "C" int wsr_conv3d_fwd_tile(const wsr_conv_t* c, const void* x, const voi
   if (ep && ep->res2) return WSR_EUNSUPPORTED;  // only the streaming kernel takes a second residual
   // thin z-tapless conv with a planar fp32 result (the z-folded last conv): sliding-window kernel
   const bool no_slide = WSR_ENV_SET("WSR_NO_SLIDE");  // tuning / A-B switch
-  if (!no_slide && c->KZ == 1 && c->Cout <= 16 && a.out_planar && !a.chan_scale && !a.res && a.act == 0 && !a.ups &&
+  if (!f32 && !no_slide && c->KZ == 1 && c->Cout <= 16 && a.out_planar && !a.chan_scale && !a.res && a.act == 0 && !a.ups &&
       !c->lat && (c->sx | c->sy | c->sz) == 1 && c->pz == 0 && a.alpha == 1.f && c->Xo == c->Xi && c->Yo == c->Yi &&
       zero_page()) {
     const int rc = wsr_conv_slide_fwd(a.in, a.in_ctot, a.in_off, c->Cin, a.wf, (float*)a.out, c->Cout, c->B, c->Xi, c->Yi,
@@ -414,7 +486,7 @@ extern "C" int wsr_conv3d_fwd_tile(const wsr_conv_t* c, const void* x, const voi
     if (rc != WSR_EUNSUPPORTED) return rc;
   }
   // 3x3x3 "same" conv over <= 16 stored channels (terrain convs, feature conv, the discriminator's first conv): memory-bound
-  if ((c->KX & c->KY & c->KZ) == 3 && (c->KX | c->KY | c->KZ) == 3 && (c->px & c->py & c->pz) == 1 &&
+  if (!f32 && (c->KX & c->KY & c->KZ) == 3 && (c->KX | c->KY | c->KZ) == 3 && (c->px & c->py & c->pz) == 1 &&
       (c->px | c->py | c->pz) == 1 && (c->sx | c->sy | c->sz) == 1 && !a.ups && !c->lat && !a.out_planar &&
       !a.chan_scale && !a.res && a.act <= 1 && a.act_c1 == 0x7FFFFFFF && c->Cin <= 16) {
     const int rc = wsr_conv_thin3(a.in, a.in_ctot, a.in_off, c->Cin, a.wf, (unsigned short*)a.out, a.out_ctot, a.out_off,
@@ -433,9 +505,12 @@ extern "C" int wsr_conv3d_dgrad_tile(const wsr_conv_t* c, const void* dy, const 
                mask->c0 % 4 || mask->y_ctot % 4 || mask->y_off % 4 ||
                mask->y_off + (mask->c1 - mask->c0) > mask->y_ctot))
     return WSR_EINVAL;
-  if (c->dtype != WSR_BF16 || (c->sx | c->sy | c->sz) != 1 || c->lat == 3) return WSR_EUNSUPPORTED;
+  if ((c->sx | c->sy | c->sz) != 1 || c->lat == 3) return WSR_EUNSUPPORTED;
+  const bool f32 = c->dtype == WSR_F32;
+  if (f32 && WSR_ENV_SET("WSR_NO_F32_TILE")) return WSR_EUNSUPPORTED;
   const int ux = c->upsample_xy ? 2 : 1;
   CtArgs a{};
+  a.f32 = f32 ? 1 : 0;
   a.in = (const unsigned short*)dy;
   a.wf = (const unsigned short*)wfrag_t;
   a.out = dx;
@@ -469,7 +544,8 @@ extern "C" int wsr_conv3d_dgrad_tile(const wsr_conv_t* c, const void* dy, const 
     a.il_m = 2; a.il_ox = c->lat_ox; a.il_oy = c->lat_oy;
   }
   if (mask && mask->chan_scale) a.chan_scale = mask->chan_scale;
-  if (c->KX * c->KY * c->KZ == 1 && !c->lat && ux == 1 && !a.out_planar && (c->px | c->py | c->pz) == 0 && !a.chan_scale) {
+  if (f32 && c->KX * c->KY * c->KZ == 1) return WSR_EUNSUPPORTED;  // (1x1x1 in fp32: the generic kernel)
+  if (!f32 && c->KX * c->KY * c->KZ == 1 && !c->lat && ux == 1 && !a.out_planar && (c->px | c->py | c->pz) == 0 && !a.chan_scale) {
     const int rc = wsr_conv1x1_bf16(a.in, a.in_ctot, a.in_off, c->Cout, a.wf, (unsigned short*)a.out, a.out_ctot,
                                     a.out_off, a.Cout, (long)c->B * c->Xo * c->Yo * c->Zo, nullptr, a.res, a.res_ctot,
                                     a.res_off, a.res ? a.res_c1 : 0, a.alpha, a.beta, 0, 0.f, mask, nullptr, 0, 0, 0.f,
@@ -478,14 +554,14 @@ extern "C" int wsr_conv3d_dgrad_tile(const wsr_conv_t* c, const void* dy, const 
   }
   // z-tapless conv with a thin output side and the mask of the layer below (the z-folded last conv): sliding window
   const bool no_slide = WSR_ENV_SET("WSR_NO_SLIDE");  // tuning / A-B switch
-  if (!no_slide && mask && c->KZ == 1 && c->Cout <= 16 && !accumulate && !dx_planar && !c->lat && ux == 1 && c->pz == 0 &&
+  if (!f32 && !no_slide && mask && c->KZ == 1 && c->Cout <= 16 && !accumulate && !dx_planar && !c->lat && ux == 1 && c->pz == 0 &&
       c->Xo == c->Xi && c->Yo == c->Yi && c->Zo == c->Zi && zero_page()) {
     const int rc = wsr_conv_slide_dgrad(a.in, a.in_ctot, a.in_off, c->Cout, a.wf, (unsigned short*)a.out, a.out_ctot,
                                         a.out_off, c->Cin, c->B, c->Xi, c->Yi, c->Zi, c->KX, c->KY, a.px, a.py, alpha, mask,
                                         zero_page(), as_stream(stream));
     if (rc != WSR_EUNSUPPORTED) return rc;
   }
-  if (!mask && !accumulate && !dx_planar && !c->lat && ux == 1 && (c->KX & c->KY & c->KZ) == 3 &&
+  if (!f32 && !mask && !accumulate && !dx_planar && !c->lat && ux == 1 && (c->KX & c->KY & c->KZ) == 3 &&
       (c->KX | c->KY | c->KZ) == 3 && (c->px & c->py & c->pz) == 1 && (c->px | c->py | c->pz) == 1 && c->Cout <= 16) {
     // input gradient of such a conv with a thin OUTPUT side (terrain_convs.1, 16 -> 16): the same sliding-window kernel
     const int rc = wsr_conv_thin3(a.in, a.in_ctot, a.in_off, c->Cout, a.wf, (unsigned short*)a.out, a.out_ctot, a.out_off,

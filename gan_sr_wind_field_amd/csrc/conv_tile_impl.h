@@ -26,8 +26,15 @@
 // channels of one voxel (8-byte vector stores into the NDHWC channel window).
 // The input-gradient pass is the same kernel over dy with the transposed,
 // tap-flipped filter and pad' = K-1-pad.
+//
+// Element type T (last template parameter): BF16 (above) or F32 - the reference's own arithmetic (AMP is commented
+// out there, Generator_3D_Resnet_ESRGAN.py:65).  Everything is laid out in 16-byte PIECES (8 bf16 or 4 fp32 channels
+// of one voxel), so the fp32 kernel is the same program on half as many channels per chunk (CK = 16 / TPK instead of
+// 32 / TPK): identical LDS images, DMA units and 1 KB weight fragments; one K-step is four v_mfma_f32_16x16x4_f32
+// (exact fp32 products and sums) instead of one v_mfma_f32_16x16x32_bf16; epilogue operands are 16 instead of 8 bytes.
 #pragma once
 #include <cstdlib>
+#include <type_traits>
 
 #include "common.h"
 
@@ -86,6 +93,7 @@ struct CtArgs {
   // take the next chunk; the rest is issued when the next chunk starts, whose first stage (kx = 0 only) reads planes
   // < TX.  xs_stage < 0: off (the whole image is reloaded between chunks behind an exposed wait + barrier).
   int xs_stage, xs_units;
+  int f32;     // 1: fp32 operands (the element type of in / wf / res / mask_y / out; see the kernel's T)
   int prio;    // 1: waves of the second half of the workgroup run the main loop at s_setprio 1 (tuning switch)
   int ablate;  // -DWSR_CT_STAMPS builds, timing only: skip 1 = activation prefetch, 2 = weight prefetch, 4 = LDS reads, 8 = MFMAs
   unsigned long long* stamps;  // -DWSR_CT_STAMPS builds: [workgroup][8] clock samples of wave 0 (else unused)
@@ -131,12 +139,45 @@ static inline unsigned fdiv_magic(int d) { return d <= 1 ? 0u : (unsigned)(((1ul
 constexpr int ct_xk(int waves, int tm) { return waves <= 4 ? 16 : (tm <= 2 ? 13 : 10); }
 
 // (four-wave workgroups: one wave per SIMD by construction - let the register allocator have all 512)
-template <int WM, int WN, int TM, int TN, int TPK, bool PIPE, bool MASK>
+// 4 consecutive channels as stored: 8 bytes of bf16, 16 of fp32 (epilogue operands)
+template <class T> struct ct_v4 { using type = uint2; };
+template <> struct ct_v4<F32> { using type = uint4; };
+template <class T> __device__ __forceinline__ float4 ct_cvt4(const typename ct_v4<T>::type& v);
+template <> __device__ __forceinline__ float4 ct_cvt4<BF16>(const uint2& v) {
+  return make_float4(bf2f((unsigned short)(v.x & 0xFFFFu)), bf2f((unsigned short)(v.x >> 16)),
+                     bf2f((unsigned short)(v.y & 0xFFFFu)), bf2f((unsigned short)(v.y >> 16)));
+}
+template <> __device__ __forceinline__ float4 ct_cvt4<F32>(const uint4& v) {
+  return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+}
+// (y > 0 ? 1 : slope) per element, from the stored bits (bf16: sign test on the raw halves)
+template <class T> __device__ __forceinline__ float4 ct_mask4(const typename ct_v4<T>::type& y, float slope);
+template <> __device__ __forceinline__ float4 ct_mask4<BF16>(const uint2& y, float slope) {
+  return make_float4((short)(y.x & 0xFFFFu) > 0 ? 1.f : slope, (int)y.x > 0xFFFF ? 1.f : slope,
+                     (short)(y.y & 0xFFFFu) > 0 ? 1.f : slope, (int)y.y > 0xFFFF ? 1.f : slope);
+}
+template <> __device__ __forceinline__ float4 ct_mask4<F32>(const uint4& y, float slope) {
+  return make_float4(__uint_as_float(y.x) > 0.f ? 1.f : slope, __uint_as_float(y.y) > 0.f ? 1.f : slope,
+                     __uint_as_float(y.z) > 0.f ? 1.f : slope, __uint_as_float(y.w) > 0.f ? 1.f : slope);
+}
+template <class T> __device__ __forceinline__ typename ct_v4<T>::type ct_ones4();
+template <> __device__ __forceinline__ uint2 ct_ones4<BF16>() { return make_uint2(0x3F803F80u, 0x3F803F80u); }
+template <> __device__ __forceinline__ uint4 ct_ones4<F32>() {
+  return make_uint4(0x3F800000u, 0x3F800000u, 0x3F800000u, 0x3F800000u);
+}
+template <class T> __device__ __forceinline__ typename ct_v4<T>::type ct_zero4();
+template <> __device__ __forceinline__ uint2 ct_zero4<BF16>() { return make_uint2(0u, 0u); }
+template <> __device__ __forceinline__ uint4 ct_zero4<F32>() { return make_uint4(0u, 0u, 0u, 0u); }
+
+template <int WM, int WN, int TM, int TN, int TPK, bool PIPE, bool MASK, class T = BF16>
 __global__ __launch_bounds__(WM * WN * 64) __attribute__((amdgpu_waves_per_eu(1, WM * WN <= 4 ? 1 : 8)))
 void conv_tile_kernel(const CtArgs a) {
+  using E = typename T::elem;
+  using V4 = typename ct_v4<T>::type;
+  constexpr int EPP = T::EPP;      // channels per 16-byte piece
   constexpr int WAVES = WM * WN, NT = WAVES * 64;
-  constexpr int PL = 4 / TPK;      // octet planes per chunk
-  constexpr int CK = 8 * PL;       // channels per chunk
+  constexpr int PL = 4 / TPK;      // pieces (bf16: channel octets) per chunk and voxel
+  constexpr int CK = EPP * PL;     // channels per chunk
   constexpr int NTW = WN * TN;     // n-tiles per workgroup
   constexpr bool STAGGER = true;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -198,7 +239,8 @@ void conv_tile_kernel(const CtArgs a) {
   const int UPP = VM ? (L + 31) >> 5 : (L + 63) >> 6;  // 1 KB DMA units per activation plane (VM: per chunk)
   const int HU = VM ? UPP : UPP * PL;                   // ... per chunk
   const int xs_bytes = VM ? a.P : PL * a.P;
-  const unsigned short* wbase = a.wf + (size_t)(2 * pha + phb) * a.ph_wstride + (size_t)nt0 * 512;
+  const char* wbase = reinterpret_cast<const char*>(a.wf) + (size_t)(2 * pha + phb) * a.ph_wstride * sizeof(E) +
+                      (size_t)nt0 * 1024;  // (fragments are 1 KB whatever the element type)
   typedef __attribute__((address_space(3))) char* lptr_t;
   const unsigned xs_lds = (unsigned)(unsigned long)(lptr_t)Xs;  // LDS byte addresses
   const unsigned ws_lds = (unsigned)(unsigned long)(lptr_t)Ws;
@@ -211,7 +253,7 @@ void conv_tile_kernel(const CtArgs a) {
       const int tsi = u / NTW, nl = u - tsi * NTW;
       const int ts = st * a.TS + tsi;
       if (ts < a.nts && nt0 + nl < a.NT_total) {
-        const unsigned short* src = wbase + ((size_t)((chunk + c_begin) * a.nts + ts) * a.NT_total + nl) * 512 + lane * 8;
+        const char* src = wbase + ((size_t)((chunk + c_begin) * a.nts + ts) * a.NT_total + nl) * 1024 + lane * 16;
         glds16(src, __builtin_amdgcn_readfirstlane(dst + u * 1024));
       }
     }
@@ -227,7 +269,7 @@ void conv_tile_kernel(const CtArgs a) {
   // 144-channel HR tensor) only need the halo's few planes to stay below 2^32 elements (checked on the host).
   const int gx_lo = max(x0 * a.sx - ppx, 0) >> U;  // first stored x-plane of the halo
   const long vox_base = ((long)b * a.Xi + gx_lo) * a.il_m * ((long)a.Yi * a.il_m) * a.Zi;
-  const unsigned short* in_base = a.in + vox_base * a.in_ctot;
+  const E* in_base = reinterpret_cast<const E*>(a.in) + vox_base * a.in_ctot;
   unsigned xoff[XK];
   int xo8[VM ? 1 : XK], xdst[VM ? 1 : XK];  // voxel-major rows: octet = lane & 1, unit u lands at u KB
 #pragma unroll
@@ -254,17 +296,17 @@ void conv_tile_kernel(const CtArgs a) {
           // 32-bit arithmetic on the voxel index relative to plane gx_lo (the host checked the halo's extent)
           const unsigned vox = ((((unsigned)((gx >> U) - gx_lo)) * a.il_m + a.il_ox) * (a.Yi * a.il_m) +
                                 (gy >> U) * a.il_m + a.il_oy) * a.Zi + gz;
-          off = vox * (unsigned)a.in_ctot + (unsigned)(a.in_off + 8 * pl);
+          off = vox * (unsigned)a.in_ctot + (unsigned)(a.in_off + EPP * pl);
         }
       }
     }
     xoff[k] = off;
     if constexpr (!VM) {
-      xo8[k] = 8 * pl;
+      xo8[k] = EPP * pl;
       xdst[k] = __builtin_amdgcn_readfirstlane(dsto);
     }
   }
-  if constexpr (VM) { xo8[0] = 8 * (lane & 1); xdst[0] = 0; }
+  if constexpr (VM) { xo8[0] = EPP * (lane & 1); xdst[0] = 0; }
   // units [u0, u1) of the activation chunk (with halo) -> Xs[buf]; out-of-range voxels read the zero page
   auto x_issue = [&](int chunk, int buf, int u0, int u1) __attribute__((always_inline)) {
     const unsigned dst = xs_lds + buf * xs_bytes;
@@ -273,8 +315,7 @@ void conv_tile_kernel(const CtArgs a) {
       const int u = wave + WAVES * k;
       if (u >= u0 && u < u1) {
         const bool ok = xoff[k] != 0xFFFFFFFFu && (chunk + c_begin) * CK + xo8[VM ? 0 : k] < a.cin_valid;
-        const unsigned short* src = ok ? in_base + (size_t)xoff[k] + (chunk + c_begin) * CK
-                                       : reinterpret_cast<const unsigned short*>(a.zero16);
+        const E* src = ok ? in_base + (size_t)xoff[k] + (chunk + c_begin) * CK : reinterpret_cast<const E*>(a.zero16);
         glds16(src, dst + (VM ? u * 1024 : xdst[VM ? 0 : k]));
       }
     }
@@ -384,7 +425,7 @@ void conv_tile_kernel(const CtArgs a) {
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < TN; ++j) mma_chunk<BF16>(acc[i][j], wf[j], xf[i]);
+        for (int j = 0; j < TN; ++j) mma_chunk<T>(acc[i][j], wf[j], xf[i]);
     };
     auto run_ksteps = [&](int lo, int hi) __attribute__((always_inline)) {
       if (lo >= hi) return;
@@ -426,7 +467,7 @@ void conv_tile_kernel(const CtArgs a) {
             if (i + 1 < TM) xf[(i + 1) & 1] = *reinterpret_cast<const uint4*>(xcur + hb[i + 1] + toff);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int j = 0; j < TN; ++j) mma_chunk<BF16>(acc[i][j], wf[j], xf[i & 1]);
+            for (int j = 0; j < TN; ++j) mma_chunk<T>(acc[i][j], wf[j], xf[i & 1]);
             __builtin_amdgcn_sched_barrier(0);
           }
 #if WSR_CT_XAHEAD == 2
@@ -499,20 +540,21 @@ void conv_tile_kernel(const CtArgs a) {
     return;
   }
   // row base pointers once (64-bit multiply-adds), n-tile offsets are immediates
-  unsigned short* orow[TM];
-  const unsigned short* rrow[TM];
-  const unsigned short* yrow[TM];
+  E* orow[TM];
+  const E* rrow[TM];
+  const E* yrow[TM];
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
     const long m = mrow[i] < 0 ? 0 : mrow[i];
-    orow[i] = reinterpret_cast<unsigned short*>(a.out) + m * a.out_ctot + a.out_off + cob;
-    rrow[i] = a.res ? a.res + m * a.res_ctot + a.res_off + cob : nullptr;
-    yrow[i] = MASK && a.mask_y ? a.mask_y + m * a.mask_ctot + a.mask_off + (cob - a.mask_c0) : nullptr;
+    orow[i] = reinterpret_cast<E*>(a.out) + m * a.out_ctot + a.out_off + cob;
+    rrow[i] = a.res ? reinterpret_cast<const E*>(a.res) + m * a.res_ctot + a.res_off + cob : nullptr;
+    yrow[i] = MASK && a.mask_y ? reinterpret_cast<const E*>(a.mask_y) + m * a.mask_ctot + a.mask_off + (cob - a.mask_c0)
+                               : nullptr;
   }
   constexpr int FD = TN >= 4 ? 2 : 1;  // operand sets requested ahead of the n-tile being stored
   constexpr int FS = FD + 1;
   float bb[FS][4], ss[FS][4];
-  uint2 rr[FS][TM], yy[FS][TM];
+  V4 rr[FS][TM], yy[FS][TM];
   auto fetch = [&](int j, int s) __attribute__((always_inline)) {
     const int co0 = cob + 16 * j;
     {
@@ -528,11 +570,11 @@ void conv_tile_kernel(const CtArgs a) {
     const bool masked = MASK && co0 >= a.mask_c0 && co0 < a.mask_c1;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
-      rr[s][i] = make_uint2(0u, 0u);
-      yy[s][i] = make_uint2(0x3F803F80u, 0x3F803F80u);  // +1: the derivative is 1 outside the mask window
+      rr[s][i] = ct_zero4<T>();
+      yy[s][i] = ct_ones4<T>();  // +1: the derivative is 1 outside the mask window
       if (mrow[i] < 0) continue;
-      if (a.res && co0 < a.res_c1) rr[s][i] = *reinterpret_cast<const uint2*>(rrow[i] + 16 * j);
-      if (masked) yy[s][i] = *reinterpret_cast<const uint2*>(yrow[i] + 16 * j);
+      if (a.res && co0 < a.res_c1) rr[s][i] = *reinterpret_cast<const V4*>(rrow[i] + 16 * j);
+      if (masked) yy[s][i] = *reinterpret_cast<const V4*>(yrow[i] + 16 * j);
     }
   };
 #pragma unroll
@@ -550,15 +592,15 @@ void conv_tile_kernel(const CtArgs a) {
       float v[4];
       const bool act_here = a.act && co0 < a.act_c1;  // (act_c1 is a multiple of 4)
       if (fast && a.act == 2) {  // second stage of a split conv: the partial sums in `res` join before the activation
-        const float r4[4] = {bf2f((unsigned short)(rr[s][i].x & 0xFFFFu)), bf2f((unsigned short)(rr[s][i].x >> 16)),
-                             bf2f((unsigned short)(rr[s][i].y & 0xFFFFu)), bf2f((unsigned short)(rr[s][i].y >> 16))};
+        const float4 rv = ct_cvt4<T>(rr[s][i]);
+        const float r4[4] = {rv.x, rv.y, rv.z, rv.w};
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           float x = acc[i][j][q] + bb[s][q] + a.beta * r4[q];
           x = x > 0.f ? x : x * a.slope;
           v[q] = x * ss[s][q];
         }
-        st4<BF16>(orow[i] + 16 * j, make_float4(v[0], v[1], v[2], v[3]));
+        st4<T>(orow[i] + 16 * j, make_float4(v[0], v[1], v[2], v[3]));
         continue;
       }
 #pragma unroll
@@ -570,18 +612,20 @@ void conv_tile_kernel(const CtArgs a) {
       if (fast) {
         float4 o4 = make_float4(v[0], v[1], v[2], v[3]);
         if (a.res) {
-          o4.x += a.beta * bf2f((unsigned short)(rr[s][i].x & 0xFFFFu));
-          o4.y += a.beta * bf2f((unsigned short)(rr[s][i].x >> 16));
-          o4.z += a.beta * bf2f((unsigned short)(rr[s][i].y & 0xFFFFu));
-          o4.w += a.beta * bf2f((unsigned short)(rr[s][i].y >> 16));
+          const float4 rv = ct_cvt4<T>(rr[s][i]);
+          o4.x += a.beta * rv.x;
+          o4.y += a.beta * rv.y;
+          o4.z += a.beta * rv.z;
+          o4.w += a.beta * rv.w;
         }
-        if constexpr (MASK) {  // bf16 sign test on the raw bits: y > 0 <=> sign clear and not zero
-          o4.x *= (short)(yy[s][i].x & 0xFFFFu) > 0 ? 1.f : a.mask_slope;
-          o4.y *= (int)yy[s][i].x > 0xFFFF ? 1.f : a.mask_slope;
-          o4.z *= (short)(yy[s][i].y & 0xFFFFu) > 0 ? 1.f : a.mask_slope;
-          o4.w *= (int)yy[s][i].y > 0xFFFF ? 1.f : a.mask_slope;
+        if constexpr (MASK) {  // (bf16: sign test on the raw bits: y > 0 <=> sign clear and not zero)
+          const float4 mk = ct_mask4<T>(yy[s][i], a.mask_slope);
+          o4.x *= mk.x;
+          o4.y *= mk.y;
+          o4.z *= mk.z;
+          o4.w *= mk.w;
         }
-        st4<BF16>(orow[i] + 16 * j, o4);
+        st4<T>(orow[i] + 16 * j, o4);
         continue;
       }
       // general path: planar fp32 output (network boundary), channel tails, unaligned windows
@@ -593,13 +637,14 @@ void conv_tile_kernel(const CtArgs a) {
         if (a.out_planar) {
           reinterpret_cast<float*>(a.out)[((long)b * a.Cout + co0 + q) * vox_per_b + vi] = x;
         } else {
-          if (a.res && co0 + q < a.res_c1) x += a.beta * ldf<BF16>(a.res + mrow[i] * a.res_ctot + a.res_off + co0 + q);
+          if (a.res && co0 + q < a.res_c1)
+            x += a.beta * ldf<T>(reinterpret_cast<const E*>(a.res) + mrow[i] * a.res_ctot + a.res_off + co0 + q);
           if constexpr (MASK) {
             if (co0 + q >= a.mask_c0 && co0 + q < a.mask_c1)
-              x *= ldf<BF16>(a.mask_y + mrow[i] * a.mask_ctot + a.mask_off + (co0 + q - a.mask_c0)) > 0.f
+              x *= ldf<T>(reinterpret_cast<const E*>(a.mask_y) + mrow[i] * a.mask_ctot + a.mask_off + (co0 + q - a.mask_c0)) > 0.f
                        ? 1.f : a.mask_slope;
           }
-          stf<BF16>(reinterpret_cast<unsigned short*>(a.out) + mrow[i] * a.out_ctot + a.out_off + co0 + q, x);
+          stf<T>(reinterpret_cast<E*>(a.out) + mrow[i] * a.out_ctot + a.out_off + co0 + q, x);
         }
       }
     }
@@ -618,7 +663,7 @@ void conv_tile_kernel(const CtArgs a) {
 
 static inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 
-template <int WM, int WN, int TM, int TN, int TPK, bool MASK = false>
+template <int WM, int WN, int TM, int TN, int TPK, bool MASK = false, class T = BF16>
 int launch_ct(CtArgs& a, hipStream_t st) {
   constexpr int WAVES = WM * WN, NTW = WN * TN;
   const int taps = a.KX * a.KY * a.KZ;
@@ -705,7 +750,8 @@ int launch_ct(CtArgs& a, hipStream_t st) {
   // register budget: (TM+TN)*8 fragment + TM*TN*4 accumulator VGPRs; four-wave workgroups have 512 per wave
   constexpr bool PIPE = TN <= 7 || WAVES <= 4;
   if (a.mask_y && !MASK) return WSR_EUNSUPPORTED;
-  auto kern = conv_tile_kernel<WM, WN, TM, TN, TPK, PIPE, MASK>;
+  if (std::is_same<T, F32>::value) a.ws = nullptr;  // (the split-reduction second pass writes bf16)
+  auto kern = conv_tile_kernel<WM, WN, TM, TN, TPK, PIPE, MASK, T>;
   static bool attr_done = false;
   if (!attr_done) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,

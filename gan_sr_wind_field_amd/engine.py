@@ -45,6 +45,9 @@ ZFOLD = __import__("os").environ.get("WSR_ZFOLD", "1") != "0"
 #: side stream with a ring of N dense gradient buffers (the running block gradient moves from buffer to buffer so that
 #: a filter-gradient launch may still read the previous one)
 WGRAD_STREAM = int(__import__("os").environ.get("WSR_WGRAD_STREAM", "0"))
+#: fp32 programs (the reference's own arithmetic) on the LDS halo-tile kernels too: stride-1 convs, dense-block stacking,
+#: the z-folded last conv (WSR_F32_TILE=0: generic implicit-GEMM kernels as in rounds 1-3)
+F32_TILE = __import__("os").environ.get("WSR_F32_TILE", "1") != "0"
 POISON_BUFFERS = bool(int(__import__("os").environ.get("WSR_POISON_BUFFERS", "0")))
 #: filter gradients without float atomics: every spatial split of a wgrad launch stores its partial sums to its own
 #: copy and the unpack pass adds the copies in index order - two backward passes give bit-identical gradients
@@ -80,10 +83,11 @@ class FilterCache:
     """Packed (and transposed) compute copies of the fp32 master filters, re-packed
     only when a parameter changed (optimizer step / load_state_dict)."""
 
-    def __init__(self):
+    def __init__(self, frag_dt: torch.dtype = torch.bfloat16):
         self._c: Dict[tuple, tuple] = {}
         self._tables: Dict[tuple, tuple] = {}
         self._gen = 0  # bumped by invalidate(); part of every stamp
+        self.frag_dt = frag_dt  # element type of the fragment-order copies (the program's compute dtype)
 
     def get(self, p: Tensor, dt: torch.dtype, transpose: bool, kpad: int, rows_pad: int) -> Tensor:
         key = (id(p), dt, transpose, kpad, rows_pad)
@@ -112,7 +116,7 @@ class FilterCache:
         hit = self._c.get(key)
         if hit is not None and hit[0] == stamp:
             return hit[1]
-        out = ops.pack_filter_frag(p.detach().contiguous(), transpose=transpose)
+        out = ops.pack_filter_frag(p.detach().contiguous(), transpose=transpose, dtype=self.frag_dt)
         self._c[key] = (stamp, out)
         return out
 
@@ -139,17 +143,17 @@ class FilterCache:
                 if not w.is_contiguous():
                     raise ValueError("conv filters must be contiguous")
                 hit = self._c.get((id(p), "frag", tr))
-                n = ops.frag_filter_elems(w, tr)
+                n = ops.frag_filter_elems(w, tr, self.frag_dt)
                 out = hit[1] if hit is not None and hit[1].numel() == n and hit[1].device == w.device else \
-                    torch.empty(n, dtype=torch.bfloat16, device=w.device)
+                    torch.empty(n, dtype=self.frag_dt, device=w.device)
                 jobs.append((w, out, tr))
             outs = [j[1] for j in jobs]
             for skey, parts, rows, red_total in stacked:
                 w0 = parts[0][0].detach()
-                n = ops.frag_filter_elems_for(rows, red_total, w0[0, 0].numel())
+                n = ops.frag_filter_elems_for(rows, red_total, w0[0, 0].numel(), self.frag_dt)
                 hit = self._c.get((skey, "dstack"))
                 out = hit[1] if hit is not None and hit[1].numel() == n and hit[1].device == w0.device else \
-                    torch.empty(n, dtype=torch.bfloat16, device=w0.device)
+                    torch.empty(n, dtype=self.frag_dt, device=w0.device)
                 for p, tr, c_lo, c_n, red_off, row_off in parts:
                     w = p.detach()
                     if not w.is_contiguous():
@@ -158,7 +162,7 @@ class FilterCache:
                 outs.append(out)
             cached = (key, ops.pack_job_table(jobs), outs)
             self._tables[kind] = cached
-        ops.pack_filter_frag_multi(cached[1])
+        ops.pack_filter_frag_multi(cached[1], self.frag_dt)
         for (p, tr), out in zip(wanted, cached[2]):
             self._c[(id(p), "frag", tr)] = ((p._version, p.data_ptr(), p.device, self._gen), out)
         for (skey, _, _, _), out in zip(stacked, cached[2][len(wanted):]):
@@ -249,7 +253,7 @@ class ProgramBase:
     def __init__(self, dt: torch.dtype):
         self.dt = dt
         self.e = ops.piece_elems(dt)
-        self.filters = FilterCache()
+        self.filters = FilterCache(dt)
         #: optional hook(flat_grad, lo, hi, flush) called when grad range [lo, hi) is final once flush() has run
         self.grad_ready_hook: Optional[Callable[[Tensor, int, int, Callable[[], None]], None]] = None
         #: optional hook() called at the end of backward (flush + wait for gradient collectives)
@@ -268,6 +272,7 @@ class ProgramBase:
         self._stack_specs = None
         self._stack_fwd_specs = None
         self._nparts: Dict[tuple, int] = {}
+        self._env_gen = ops.ENV_GEN[0]
         self._side: Optional[torch.cuda.Stream] = None
         self._events: List[torch.cuda.Event] = []
         self._events_used = 0
@@ -291,9 +296,13 @@ class ProgramBase:
         return (c + self.e - 1) // self.e * self.e
 
     # ---- conv helpers --------------------------------------------------------
+    def tile_dt(self) -> bool:
+        """the compute dtype has LDS halo-tile kernels: bf16, and fp32 (stride-1 convs; WSR_F32_TILE=0 turns it off)"""
+        return self.use_tile and (self.dt == torch.bfloat16 or (self.dt == torch.float32 and F32_TILE))
+
     def refresh_filters(self, backward: bool) -> None:
         """bring the fragment-order filter copies of all tile-kernel convs up to date in one launch"""
-        if not (self.use_tile and self.dt == torch.bfloat16):
+        if not self.tile_dt():
             return
         sites = [s for s in self.conv_sites() if self.tile_ok(s)]
         fstack = list(self.stacked_fwd_specs())
@@ -318,8 +327,8 @@ class ProgramBase:
         return getattr(self, "all_sites", [])
 
     def tile_ok(self, s: ConvSite) -> bool:
-        """LDS halo-tile kernels: bf16, stride 1 (everything in G; the k3 s1 convs of D)"""
-        return self.use_tile and self.dt == torch.bfloat16 and s.stride == (1, 1, 1)
+        """LDS halo-tile kernels: stride 1 (everything in G; the k3 s1 convs of D); fp32: no 1x1x1 (generic kernel)"""
+        return self.tile_dt() and s.stride == (1, 1, 1) and (self.dt == torch.bfloat16 or s.taps > 1)
 
     def tile_fwd_ok(self, s: ConvSite) -> bool:
         """forward only: also the stride-2 down-sampling convs of D"""
@@ -330,12 +339,12 @@ class ProgramBase:
         """The forward fragment filters of the four parity convs of one launch must sit in ONE buffer, parity-major
         (``wsr_conv_t.lat_phases``): seed the cache with views of it, refresh_frags re-packs into them.  True when a
         new buffer was made."""
-        n = ops.frag_filter_elems(par[0].weight, False)
+        n = ops.frag_filter_elems(par[0].weight, False, self.dt)
         hits = [self.filters._c.get((id(s.weight), "frag", False)) for s in par]
         if all(h is not None and h[1].device == torch.device(dev) and h[1].numel() == n and
-               h[1].data_ptr() == hits[0][1].data_ptr() + 2 * n * ph for ph, h in enumerate(hits)):
+               h[1].data_ptr() == hits[0][1].data_ptr() + h[1].element_size() * n * ph for ph, h in enumerate(hits)):
             return False
-        big = torch.empty(len(par) * n, dtype=torch.bfloat16, device=dev)
+        big = torch.empty(len(par) * n, dtype=self.dt, device=dev)
         for ph, s in enumerate(par):
             self.filters._c[(id(s.weight), "frag", False)] = (None, big[ph * n:(ph + 1) * n])
         self.filters.drop_tables()  # (cached job tables hold the old destinations)
@@ -345,7 +354,7 @@ class ProgramBase:
         """(fragment filters of the parity sites, whether they are contiguous parity-major)"""
         frs = [self.filters.get_frag(s.weight, False) for s in par]
         n = frs[0].numel()
-        return frs, all(f.data_ptr() == frs[0].data_ptr() + 2 * n * ph for ph, f in enumerate(frs))
+        return frs, all(f.data_ptr() == frs[0].data_ptr() + f.element_size() * n * ph for ph, f in enumerate(frs))
 
     def _w(self, s: ConvSite) -> Tensor:
         return self.filters.get(s.weight, self.dt, False, self.cp(s.cin), s.cout)
@@ -476,7 +485,7 @@ class ProgramBase:
     # arithmetic, a third of the traffic, longer reductions.  Windows go last to first because window
     # w's result (after its LeakyReLU mask) is the output gradient of conv w-1.
     def dense_stackable(self, convs: Sequence[ConvSite]) -> bool:
-        if not (self.use_tile and self.dt == torch.bfloat16 and len(convs) > 1):
+        if not (self.tile_dt() and len(convs) > 1):
             return False
         nf, gc = convs[0].cin, convs[0].cout
         return (gc % 16 == 0 and nf % 16 == 0 and gc <= 64 and nf <= 256 and convs[0].taps > 1 and all(
@@ -593,6 +602,10 @@ class ProgramBase:
         self._arena = torch.zeros(n, dtype=torch.float32, device=dev)
 
     def _wgrad_nparts(self, key, desc, tri_base: int = 0, tri_step: int = 0) -> int:
+        if self._env_gen != ops.ENV_GEN[0]:  # the tuning switches were re-read: plans and job tables start over
+            self._nparts.clear()
+            self._unpack_tables.clear()
+            self._env_gen = ops.ENV_GEN[0]
         n = self._nparts.get(key)
         if n is None:
             n = self._nparts[key] = ops.conv_wgrad_nparts(desc, tri_base, tri_step)
@@ -604,13 +617,20 @@ class ProgramBase:
         that have not been written yet)"""
         if not DETERMINISTIC:
             return
-        cap = max(ARENA_MB << 18, n_total + 64 * 64)
-        if self._arena is None or self._arena.device != torch.device(dev) or self._arena.numel() < cap:
+        need = n_total + 64 * 64
+        bound = max(ARENA_MB << 18, need)
+        if self._arena is not None and self._arena.device != torch.device(dev):
             self.flush_unpack()
             self._arena = None
-            self._arena = torch.empty(cap, dtype=torch.float32, device=dev)
+        have = 0 if self._arena is None else self._arena.numel()
+        if self._arena_off + need > have and have < bound:
+            want = min(bound, max(2 * have, self._arena_off + need, 4 << 18))
+            self.flush_unpack()
+            self._arena = None
+            self._arena = torch.empty(want, dtype=torch.float32, device=dev)
             self._arena_off = 0
-        elif self._arena_off + n_total + 64 * 64 > self._arena.numel():
+            self._unpack_tables.clear()
+        elif self._arena_off + need > self._arena.numel():
             self.flush_unpack()
             self._arena_off = 0
 
@@ -619,12 +639,20 @@ class ProgramBase:
             # bounded, persistent arena: when the next slice does not fit, everything taken so far is reduced into the
             # master gradients and the arena is recycled (stream order keeps the reduce ahead of the next writer).  The
             # sequence of slices is the same every step, so the cached device job tables stay valid.
-            cap = max(ARENA_MB << 18, (n + 63) // 64 * 64)  # (floats)
-            if self._arena is None or self._arena.device != torch.device(dev) or self._arena.numel() < cap:
+            # ... It starts at what the first slices need and doubles up to the bound (ARENA_MB) as a pass asks for more:
+            # a small-patch model (a few MB of copies per pass) no longer pins the full bound from its first backward.
+            bound = max(ARENA_MB << 18, (n + 63) // 64 * 64)  # (floats)
+            if self._arena is not None and self._arena.device != torch.device(dev):
+                self.flush_unpack()
+                self._arena = None
+            have = 0 if self._arena is None else self._arena.numel()
+            if self._arena_off + n > have and have < bound:
+                want = min(bound, max(2 * have, self._arena_off + (n + 63) // 64 * 64, 4 << 18))
                 self.flush_unpack()
                 self._arena = None  # (release before growing)
-                self._arena = torch.empty(cap, dtype=torch.float32, device=dev)
+                self._arena = torch.empty(want, dtype=torch.float32, device=dev)
                 self._arena_off = 0
+                self._unpack_tables.clear()  # (cached job tables hold the old addresses)
             if self._arena_off + n > self._arena.numel():
                 self.flush_unpack()
                 self._arena_off = 0
@@ -1406,6 +1434,7 @@ class DiscriminatorProgram(ProgramBase):
         self.dparity: Dict[int, list] = {}
         self._dparity_stamp: Dict[int, object] = {}
         self._dparity_grads: Dict[tuple, list] = {}  # class gradients of the parity form of the filter gradients
+        self._dparity_bad: set = set()               # (layer, shape) whose parity-form filter gradient has no tile plan
         for li, l in enumerate(self.layers):
             s = l.conv
             if li > 0 and s.kernel == (4, 4, 3) and s.pad == (1, 1, 1) and s.stride[:2] == (2, 2) and s.stride[2] in (1, 2) \
@@ -1426,7 +1455,7 @@ class DiscriminatorProgram(ProgramBase):
     def strided_wgrad_active(self, li: int) -> bool:
         return STRIDED_WGRAD and li in self.dparity and self.use_tile and self.dt == torch.bfloat16 and DETERMINISTIC
 
-    def strided_wgrad(self, li: int, inp: Tensor, gy: Tensor, flat: Tensor, space: "GradSpace") -> None:
+    def strided_wgrad(self, li: int, inp: Tensor, gy: Tensor, flat: Tensor, space: "GradSpace") -> bool:
         """filter gradient of down-sampling conv ``li`` (reference torch_blocks.py:372-521: kernel (4,4,3), stride
         (2,2,1|2), padding 1) in parity form: tap (2i + a, 2j + b, .) only meets input voxels of one parity, so the
         taps of class (a, b[, z class]) are a stride-1 2x2xKZ' filter gradient over a sub-lattice of ``inp`` - on the
@@ -1444,15 +1473,24 @@ class DiscriminatorProgram(ProgramBase):
                               device=inp.device) for zc in range(sz)]
             self._dparity_grads[key] = tw
         runs, jobs = [], []
-        for zc in range(sz):
-            kzp = 3 if sz == 1 else (1 if zc == 0 else 2)
-            pz, mz, oz = (1, 1, 0) if sz == 1 else ((0, 2, 0) if zc == 0 else (1, 2, 1))
-            for ph in range(4):
-                a_, b_ = ph >> 1, ph & 1
-                g = ConvGeom(s.cin, s.cout, (2, 2, kzp), (1, 1, 1), (1 - a_, 1 - b_, pz))
-                d = ops.make_desc(g, self.dt, B, oxyz, inp.shape[-1], 0, gy.shape[-1], 0, cin=cin_p,
-                                  lat=(1 - a_, 1 - b_, 0, mz, oz, True))
-                jobs.append((zc, ph, g, d, self._wgrad_nparts(("wstr", s.name, zc, ph, B) + oxyz, d)))
+        bad_key = (li, B) + oxyz
+        if bad_key in self._dparity_bad:
+            return False
+        try:  # (plan queries only: nothing is taken from the arena or queued before all of them have answered)
+            for zc in range(sz):
+                kzp = 3 if sz == 1 else (1 if zc == 0 else 2)
+                pz, mz, oz = (1, 1, 0) if sz == 1 else ((0, 2, 0) if zc == 0 else (1, 2, 1))
+                for ph in range(4):
+                    a_, b_ = ph >> 1, ph & 1
+                    g = ConvGeom(s.cin, s.cout, (2, 2, kzp), (1, 1, 1), (1 - a_, 1 - b_, pz))
+                    d = ops.make_desc(g, self.dt, B, oxyz, inp.shape[-1], 0, gy.shape[-1], 0, cin=cin_p,
+                                      lat=(1 - a_, 1 - b_, 0, mz, oz, True))
+                    jobs.append((zc, ph, g, d, self._wgrad_nparts(("wstr", s.name, zc, ph, B) + oxyz, d)))
+        except RuntimeError:
+            # the tile filter-gradient kernel declines this shape in parity form: remember it and let the caller run
+            # the generic per-tap gradient (as strided_dgrad falls back to the gather kernel)
+            self._dparity_bad.add(bad_key)
+            return False
         # (the launches are deferred: no recycling flush between the slices)
         self._arena_reserve(sum((n * s.cout * g.taps * cin_p + 63) // 64 * 64 for _, _, g, _, n in jobs), inp.device)
         for zc, ph, g, d, n in jobs:
@@ -1472,6 +1510,7 @@ class DiscriminatorProgram(ProgramBase):
         dst = space.view(flat, s.weight)
         for zc in range(sz):
             ops.strided_parity_unfold(tw[zc], dst, sz, zc)
+        return True
 
     def conv_sites(self) -> Sequence[ConvSite]:
         sites = list(self.all_sites)
@@ -1700,9 +1739,7 @@ class DiscriminatorProgram(ProgramBase):
             lattice_ok = (li in self.dparity and tuple(inp.shape[1:3]) == (2 * gy.shape[1], 2 * gy.shape[2])
                           and inp.shape[3] == s.stride[2] * gy.shape[3] and inp.shape[-1] == self.cp(s.cin))
             if need_dw:
-                if lattice_ok and self.strided_wgrad_active(li):
-                    self.strided_wgrad(li, inp, gy, flat, sp)
-                else:
+                if not (lattice_ok and self.strided_wgrad_active(li) and self.strided_wgrad(li, inp, gy, flat, sp)):
                     self.wgrad(s, inp, 0, gy, 0, flat, sp, scratch)
                 if self.grad_ready_hook is not None:
                     hi = sp.offsets[id(s.weight)][0] + (s.weight.numel() + 63) // 64 * 64

@@ -158,6 +158,17 @@ def conv_fwd(desc: ConvDesc, x: Tensor, w: Tensor, y: Tensor, *, bias: Optional[
 _tile_ws: dict = {}
 TILE_WS_BYTES = 32 << 20
 
+#: bumped by :func:`reload_env`; host-side caches of values that depend on the WSR_* tuning switches (the split counts
+#: of the filter-gradient plans, unpack job tables) compare it and start over
+ENV_GEN = [0]
+
+
+def reload_env() -> None:
+    """The process changed its WSR_* environment at run time (tests, tuning scripts): have the C side read its cached
+    switches again (``wsr_reload_env``) and invalidate what the host side cached from them."""
+    check(_lib.lib().wsr_reload_env(), "reload_env")
+    ENV_GEN[0] += 1
+
 
 def tile_workspace(dev=None):
     """(pointer, bytes) of the split-reduction workspace the tile entry points get with every call (``wsr_epilogue_t.ws``,
@@ -238,29 +249,31 @@ def conv_dgrad_tile(desc: ConvDesc, dy: Tensor, wfrag_t: Tensor, dx: Tensor, *, 
     return True
 
 
-def pack_filter_frag(w: Tensor, *, transpose: bool = False, out: Optional[Tensor] = None) -> Tensor:
-    """fp32 master ``(Cout, Cin, KX, KY, KZ)`` -> bf16 MFMA-fragment order for the tile kernels."""
+def pack_filter_frag(w: Tensor, *, transpose: bool = False, out: Optional[Tensor] = None,
+                     dtype: torch.dtype = torch.bfloat16) -> Tensor:
+    """fp32 master ``(Cout, Cin, KX, KY, KZ)`` -> MFMA-fragment order of ``dtype`` (bf16, or fp32 for the fp32 tile
+    kernels) for the tile kernels."""
     _need_cuda(w)
     if not w.is_contiguous() or w.dtype != torch.float32 or w.dim() != 5:
         raise ValueError("pack_filter_frag wants a contiguous fp32 (Cout, Cin, KX, KY, KZ) tensor")
     cout, cin, kx, ky, kz = w.shape
     rows, red = (cin, cout) if transpose else (cout, cin)
-    n = _lib.lib().wsr_frag_filter_elems(rows, red, kx * ky * kz)
+    n = _lib.lib().wsr_frag_filter_elems(rows, red, kx * ky * kz, dtype_id(dtype))
     if out is None:
-        out = torch.empty(n, dtype=torch.bfloat16, device=w.device)
-    check(_lib.lib().wsr_pack_filter_frag(_p(w), _p(out), cout, cin, kx, ky, kz, int(transpose), _stream()),
-          "pack_filter_frag")
+        out = torch.empty(n, dtype=dtype, device=w.device)
+    check(_lib.lib().wsr_pack_filter_frag(_p(w), _p(out), cout, cin, kx, ky, kz, int(transpose), dtype_id(dtype),
+                                          _stream()), "pack_filter_frag")
     return out
 
 
-def frag_filter_elems(w: Tensor, transpose: bool) -> int:
+def frag_filter_elems(w: Tensor, transpose: bool, dtype: torch.dtype = torch.bfloat16) -> int:
     cout, cin, kx, ky, kz = w.shape
     rows, red = (cin, cout) if transpose else (cout, cin)
-    return int(_lib.lib().wsr_frag_filter_elems(rows, red, kx * ky * kz))
+    return int(_lib.lib().wsr_frag_filter_elems(rows, red, kx * ky * kz, dtype_id(dtype)))
 
 
-def frag_filter_elems_for(rows: int, red: int, taps: int) -> int:
-    return int(_lib.lib().wsr_frag_filter_elems(rows, red, taps))
+def frag_filter_elems_for(rows: int, red: int, taps: int, dtype: torch.dtype = torch.bfloat16) -> int:
+    return int(_lib.lib().wsr_frag_filter_elems(rows, red, taps, dtype_id(dtype)))
 
 
 def pack_job_table(jobs) -> Tensor:
@@ -300,9 +313,10 @@ def _table_to_device(rec, dev) -> Tensor:
     return t.pin_memory().to(dev, non_blocking=True) if torch.device(dev).type == "cuda" else t.to(dev)
 
 
-def pack_filter_frag_multi(table: Tensor) -> None:
-    """One launch for all filters of a job table (see :func:`pack_job_table`)."""
-    check(_lib.lib().wsr_pack_filter_frag_multi(_p(table), table.shape[0], _stream()), "pack_filter_frag_multi")
+def pack_filter_frag_multi(table: Tensor, dtype: torch.dtype = torch.bfloat16) -> None:
+    """One launch for all filters of a job table (see :func:`pack_job_table`); ``dtype`` of the fragment filters."""
+    check(_lib.lib().wsr_pack_filter_frag_multi(_p(table), table.shape[0], dtype_id(dtype), _stream()),
+          "pack_filter_frag_multi")
 
 
 def conv_dgrad(desc: ConvDesc, dy: Tensor, wt: Tensor, dx: Tensor, *, alpha: float = 1.0,

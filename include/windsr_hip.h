@@ -131,6 +131,8 @@ int wsr_conv3d_dgrad(const wsr_conv_t* c, const void* dy, const void* wt, void* 
                      int accumulate, int dx_planar, void* stream);
 
 /* ---- LDS halo-tile path (bf16, stride 1) ------------------------------------
+ * (bf16; fp32 as well for stride-1 convs - ABI 6: the same kernel on 16-byte pieces of 4 channels, exact fp32
+ * products and sums through v_mfma_f32_16x16x4_f32; 1x1x1 and strided fp32 convs return WSR_EUNSUPPORTED.)
  * Same contracts as wsr_conv3d_fwd / wsr_conv3d_dgrad, but the activation tile
  * (with halo) is staged in LDS once per channel chunk and re-used by every tap,
  * and the filter comes in MFMA-fragment order from wsr_pack_filter_frag
@@ -165,9 +167,11 @@ typedef struct wsr_dgrad_opts {
 int wsr_conv3d_dgrad_tile(const wsr_conv_t* c, const void* dy, const void* wfrag_t, void* dx, float alpha,
                           int accumulate, int dx_planar, const wsr_lrelu_mask_t* mask, const wsr_dgrad_opts_t* opts,
                           void* stream);
-int64_t wsr_frag_filter_elems(int32_t rows, int32_t red, int32_t taps);
+/* ABI 6: `dtype` (wsr_dtype) of the fragment filter - bf16, or fp32 for the fp32 tile kernels (stride-1 convs in the
+ * reference's own arithmetic; the 16-byte pieces then hold 4 channels instead of 8).                        */
+int64_t wsr_frag_filter_elems(int32_t rows, int32_t red, int32_t taps, int32_t dtype);
 int wsr_pack_filter_frag(const float* w, void* out, int32_t Cout, int32_t Cin, int32_t KX, int32_t KY, int32_t KZ,
-                         int32_t transpose, void* stream);
+                         int32_t transpose, int32_t dtype, void* stream);
 /* The same for many filters in ONE launch (every filter changes at each optimizer step, and a
  * generator has ~300 of them): `jobs_dev` is a DEVICE array of n_jobs records.                    */
 typedef struct wsr_pack_job {
@@ -181,11 +185,11 @@ typedef struct wsr_pack_job {
    *     [red_off, red_off + Cout) and its input channels [c_lo, c_lo + c_n) the rows (rows_total = c_n);
    *   transpose = 0 (split forward conv): this conv's output channels are rows [row_off, row_off + Cout) and
    *     its input channels [c_lo, c_lo + c_n) the whole reduction axis (red_total = c_n, red_off = 0).
-   * Offsets and extents that index whole chunks / n-tiles must be multiples of 16.  red_total = 0: a plain
+   * Offsets and extents that index whole chunks / n-tiles must be multiples of 16 (fp32: 8).  red_total = 0: a plain
    * filter (the fields above).                                                                        */
   int32_t c_lo, c_n, red_off, red_total, row_off, rows_total;
 } wsr_pack_job_t;
-int wsr_pack_filter_frag_multi(const wsr_pack_job_t* jobs_dev, int32_t n_jobs, void* stream);
+int wsr_pack_filter_frag_multi(const wsr_pack_job_t* jobs_dev, int32_t n_jobs, int32_t dtype, void* stream);
 
 /* aten::convolution_backward, filter gradient: dw[Cout][taps][Cin] fp32 (packed
  * order) is ACCUMULATED into (caller zeroes it when a fresh gradient is wanted;

@@ -43,9 +43,9 @@ def hip():
 
 def reload_wsr_env():
     """the C side caches its WSR_* tuning switches per call site: have them read again after changing os.environ"""
-    from gan_sr_wind_field_amd import _lib
+    from gan_sr_wind_field_amd import hip_ops
 
-    _lib.lib().wsr_reload_env()
+    hip_ops.reload_env()  # (C side re-reads, host-side plan caches start over)
 
 
 @pytest.fixture(autouse=True)

@@ -664,11 +664,13 @@ def test_wgrad_dense_block_fused(hip, nf, gc, B, xyz):
         assert rel_l2(dw.cpu(), ref) < 2e-5, i
 
 
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float32], ids=["bf16", "fp32"])
 @pytest.mark.parametrize("case", [c for c in CONV_CASES if c[4] == (1, 1, 1)], ids=lambda c: c[0])
-def test_conv_tile_kernels_vs_golden(golden, hip, case):
-    """LDS halo-tile forward / input-gradient kernels (bf16, stride 1) on the reference's conv fixtures."""
+def test_conv_tile_kernels_vs_golden(golden, hip, case, dt):
+    """LDS halo-tile forward / input-gradient kernels (stride 1; bf16, and fp32 = the reference's own arithmetic, ABI 6)
+    on the reference's conv fixtures: channel windows, bias, activation, accumulation, planar gradient."""
     o = ops()
-    dt = torch.bfloat16
+    f32 = dt == torch.float32
     name, cin, cout, k, s, p, bias, act, xyz, B = case
     g = golden("conv_cases.npz")
     x, w, y_ref, gy, dx_ref = (T(g[f"{name}.{n}"]) for n in ("x", "w", "y", "gy", "dx"))
@@ -680,34 +682,39 @@ def test_conv_tile_kernels_vs_golden(golden, hip, case):
     wm = packed_master(w)
     d = o.make_desc(o.ConvGeom(cin_p, cout, k, s, p), dt, B, xyz, in_ctot, in_off, out_ctot, out_off)
     yb = torch.full((B, d.Xo, d.Yo, d.Zo, out_ctot), 7.0, dtype=dt, device=DEV)
-    assert o.conv_fwd_tile(d, xb, o.pack_filter_frag(wm), yb, bias=b, act=act, slope=0.2)
+    tol_ref, tol_same = (1e-5, 1e-5) if f32 else (1e-2, 4e-3)
+    if f32 and k == (1, 1, 1):  # (1x1x1 in fp32 stays on the generic kernel)
+        assert not o.conv_fwd_tile(d, xb, o.pack_filter_frag(wm, dtype=dt), yb, bias=b, act=act, slope=0.2)
+        return
+    assert o.conv_fwd_tile(d, xb, o.pack_filter_frag(wm, dtype=dt), yb, bias=b, act=act, slope=0.2)
     y = from_ndhwc(yb, out_off, cout)
-    assert rel_l2(y, y_ref) < 1e-2
+    assert rel_l2(y, y_ref) < tol_ref
     assert float((yb[..., :out_off].float() - 7.0).abs().max()) == 0.0
     assert float((yb[..., out_off + cout:].float() - 7.0).abs().max()) == 0.0
-    y2 = F.conv3d(x.bfloat16().float(), w.bfloat16().float(), b.cpu() if bias else None, s, p)
-    y2 = F.leaky_relu(y2, 0.2) if act else y2
-    assert rel_l2(y, y2) < 4e-3  # same rounded operands, fp32 accumulation, bf16 store
+    if not f32:
+        y2 = F.conv3d(x.bfloat16().float(), w.bfloat16().float(), b.cpu() if bias else None, s, p)
+        y2 = F.leaky_relu(y2, 0.2) if act else y2
+        assert rel_l2(y, y2) < tol_same  # same rounded operands, fp32 accumulation, bf16 store
     # the generic implicit-GEMM kernel computes the same thing
     yb2 = torch.full_like(yb, 7.0)
     o.conv_fwd(d, xb, o.pack_filter(wm, dt, kpad=cin_p), yb2, bias=b, act=act, slope=0.2)
-    assert rel_l2(yb.float(), yb2.float()) < 4e-3
+    assert rel_l2(yb.float(), yb2.float()) < tol_same
 
     gb = to_ndhwc(gy, out_ctot, out_off, dt)
     if act:
         o.lrelu_bwd_(gb, out_off, to_ndhwc(y_ref, out_ctot, out_off, dt), out_off, cout_p, 0.2)
-    wft = o.pack_filter_frag(wm, transpose=True)
+    wft = o.pack_filter_frag(wm, transpose=True, dtype=dt)
     dd = o.make_desc(o.ConvGeom(cin, cout_p, k, s, p), dt, B, xyz, in_ctot, in_off, out_ctot, out_off)
     dxb = torch.full((B,) + tuple(xyz) + (in_ctot,), 3.0, dtype=dt, device=DEV)
     assert o.conv_dgrad_tile(dd, gb, wft, dxb)
-    assert rel_l2(from_ndhwc(dxb, in_off, cin), dx_ref) < 1e-2
+    assert rel_l2(from_ndhwc(dxb, in_off, cin), dx_ref) < tol_ref
     assert float((dxb[..., :in_off].float() - 3.0).abs().max()) == 0.0
     assert o.conv_dgrad_tile(dd, gb, wft, dxb, accumulate=True)
-    assert rel_l2(from_ndhwc(dxb, in_off, cin), 2 * dx_ref) < 1e-2
+    assert rel_l2(from_ndhwc(dxb, in_off, cin), 2 * dx_ref) < tol_ref
     dxp = torch.zeros((B, cin) + tuple(xyz), dtype=torch.float32, device=DEV)
     dd2 = o.make_desc(o.ConvGeom(cin, cout_p, k, s, p), dt, B, xyz, cin, 0, out_ctot, out_off)
     assert o.conv_dgrad_tile(dd2, gb, wft, dxp, dx_planar=True)
-    assert rel_l2(dxp.cpu(), dx_ref) < 1e-2
+    assert rel_l2(dxp.cpu(), dx_ref) < tol_ref
 
 
 @pytest.mark.parametrize("name,cin,cout,k,xyz,B,ups", [
@@ -723,6 +730,22 @@ def test_conv_tile_shapes_vs_cpu(hip, name, cin, cout, k, xyz, B, ups):
     """Every tile-kernel configuration against an fp32 CPU conv of the same bf16-rounded operands,
     forward and input gradient (with residual epilogue on the forward pass)."""
     _check_tile_conv(name, cin, cout, k, xyz, B, ups)
+
+
+@pytest.mark.parametrize("name,cin,cout,k,xyz,B,ups", [
+    ("rdb_n32", 160, 32, (3, 3, 3), (9, 10, 19), 1, False),    # <8,1,4,2,*,F32>: 20 chunks of 8 channels
+    ("hr0_n144", 144, 144, (5, 5, 5), (9, 7, 10), 1, False),   # <8,1,4,9,2,F32>, odd tap count
+    ("up_n128", 128, 128, (3, 3, 3), (5, 6, 8), 1, True),      # nearest x(2,2,1) folded into the halo load
+    ("pre_n128", 128, 128, (3, 3, 3), (8, 16, 16), 1, False),  # production tile 4x8x16
+    ("dg_n224", 32, 224, (3, 3, 3), (6, 9, 17), 1, False),     # <4,2,4,8,2,F32>: two n-tile wave columns
+    ("n64_c20", 20, 64, (3, 3, 3), (8, 5, 6), 2, False),       # TPK=4 (20 channels = 5 pieces), N=64
+    ("n15_k551", 144, 15, (5, 5, 1), (8, 8, 10), 1, False),    # the z-folded last conv: one n-tile, flat tiles
+    ("t0_c4", 4, 16, (3, 3, 3), (8, 8, 16), 1, False),         # 1 / 3 / 4-channel inputs padded to one piece
+])
+def test_conv_tile_shapes_fp32_vs_cpu(hip, name, cin, cout, k, xyz, B, ups):
+    """the fp32 instantiations of the halo-tile kernel (ABI 6; the reference's own arithmetic, AMP is commented out in
+    Generator_3D_Resnet_ESRGAN.py:65): exact fp32 products and sums - 2e-5 against the fp32 CPU conv."""
+    _check_tile_conv(name, cin, cout, k, xyz, B, ups, dt=torch.float32)
 
 
 @pytest.mark.parametrize("name,cin,cout,k,xyz,B,ups", [
@@ -744,9 +767,9 @@ def test_conv_tile_production_geometry(hip, monkeypatch, name, cin, cout, k, xyz
     _check_tile_conv(name, cin, cout, k, xyz, B, ups)
 
 
-def _check_tile_conv(name, cin, cout, k, xyz, B, ups):
+def _check_tile_conv(name, cin, cout, k, xyz, B, ups, dt=torch.bfloat16):
     o = ops()
-    dt = torch.bfloat16
+    tol = 4e-3 if dt == torch.bfloat16 else 2e-5  # (operands are bf16-exact in both: fp32 products are exact)
     gen = torch.Generator().manual_seed(cin * 7 + cout)
     x = torch.randn((B, cin) + tuple(xyz), generator=gen).bfloat16().float()
     w = (torch.randn((cout, cin) + tuple(k), generator=gen) / math.sqrt(cin * k[0] * k[1] * k[2])).bfloat16().float()
@@ -760,19 +783,19 @@ def _check_tile_conv(name, cin, cout, k, xyz, B, ups):
     rb = to_ndhwc(res, cout_p, 0, dt)
     yb = torch.zeros((B,) + oxyz + (cout_p + 8,), dtype=dt, device=DEV)
     wm = packed_master(w)
-    assert o.conv_fwd_tile(d, xb, o.pack_filter_frag(wm), yb, res=rb, res_off=0, alpha=0.2, beta=1.0)
+    assert o.conv_fwd_tile(d, xb, o.pack_filter_frag(wm, dtype=dt), yb, res=rb, res_off=0, alpha=0.2, beta=1.0)
     xr = x.repeat_interleave(2, dim=2).repeat_interleave(2, dim=3) if ups else x
     ref = 0.2 * F.conv3d(xr, w, None, 1, p) + res
-    assert rel_l2(from_ndhwc(yb, 0, cout), ref) < 4e-3, name
+    assert rel_l2(from_ndhwc(yb, 0, cout), ref) < tol, name
     # input gradient (at the fine resolution when up-sampled; the 2x2 fold is a separate kernel)
     gy = torch.randn((B, cout) + oxyz, generator=gen).bfloat16().float()
     gb = to_ndhwc(gy, cout_p + 8, 0, dt)
     dd = o.make_desc(o.ConvGeom(cin, cout_p, k, (1, 1, 1), p, upsample=ups), dt, B, xyz, cin + 8, 8, cout_p + 8, 0)
     dxb = torch.zeros((B,) + tuple(xr.shape[2:]) + (cin + 8,), dtype=dt, device=DEV)
-    assert o.conv_dgrad_tile(dd, gb, o.pack_filter_frag(wm, transpose=True), dxb)
+    assert o.conv_dgrad_tile(dd, gb, o.pack_filter_frag(wm, transpose=True, dtype=dt), dxb)
     xg = xr.clone().requires_grad_(True)
     F.conv3d(xg, w, None, 1, p).backward(gy)
-    assert rel_l2(from_ndhwc(dxb, 8, cin), xg.grad) < 4e-3, name
+    assert rel_l2(from_ndhwc(dxb, 8, cin), xg.grad) < tol, name
 
 
 @pytest.mark.parametrize("dt,C,ctot,off,nvox", [(torch.bfloat16, 128, 128, 0, 32 * 32 * 16), (torch.bfloat16, 32, 256, 96, 1000),
