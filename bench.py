@@ -146,7 +146,7 @@ def cpu_baseline(n_threads):
     return dt, pair_flops
 
 
-TRAFFIC_JSON = "profiles/r03_hbm_traffic.json"
+TRAFFIC_JSON = "profiles/r04_hbm_traffic.json"
 
 
 def recorded_traffic(key):

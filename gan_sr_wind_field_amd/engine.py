@@ -755,7 +755,7 @@ class GeneratorProgram(ProgramBase):
         # mode="nearest") in front of a 3x3x3 conv): output parity (a, b) only ever sees 2x2 distinct un-sampled
         # voxels per z level, so the conv is four 2x2x3 convs on the un-sampled input whose filters are sums of the
         # master taps (wsr_subpixel_fold) - 12 instead of 27 taps per output voxel.  Parity sites are twins of the
-        # master filter like hr1z; they exist only for the bf16 tile path.
+        # master filter like hr1z; they serve the tile kernels (bf16; fp32: forward and input gradient).
         self.up_parity: List[Optional[List[ConvSite]]] = []
         self._up_wp: List[Optional[Tensor]] = []
         self._up_dwp: List[Optional[Tensor]] = []  # parity filter gradients (folded back by wsr_subpixel_unfold)
@@ -804,7 +804,7 @@ class GeneratorProgram(ProgramBase):
         return ZFOLD and self.hr1z is not None and self.tile_ok(self.hr1z)
 
     def subpixel_active(self, u: int) -> bool:
-        return (SUBPIXEL and self.up_parity[u] is not None and self.use_tile and self.dt == torch.bfloat16
+        return (SUBPIXEL and self.up_parity[u] is not None and self.tile_dt()
                 and self.cp(self.ups[u].cin) == self.ups[u].cin)
 
     def conv_sites(self) -> Sequence[ConvSite]:
@@ -1178,8 +1178,8 @@ class GeneratorProgram(ProgramBase):
             if not masked:
                 ops.lrelu_bwd_(gbuf, 0, outp, 0, nf, sl)
             masked = False
-            if self.subpixel_active(u) and SUBPIXEL_WGRAD:
-                self.up_wgrad(u, inp, gbuf, flat, sp)
+            if self.subpixel_active(u) and SUBPIXEL_WGRAD and self.dt == torch.bfloat16:
+                self.up_wgrad(u, inp, gbuf, flat, sp)  # (fp32: the direct 27-tap gradient - its tile kernel has no lattice form)
             else:
                 self.wgrad(site, inp, 0, gbuf, 0, flat, sp, scratch)
             gin = self._empty(inp.shape, g_out)

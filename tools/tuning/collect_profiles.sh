@@ -2,7 +2,7 @@
 # usage (in the build container, after tools/tuning/final_batch.sh TAG ran on the GPU box): copies the judged artefacts
 # from gpurun_out/ into profiles/ and prints the per-kernel tables
 set -e
-tag=${1:-r03_h}
+tag=${1:-r04_h}
 r=${tag%_h}
 cd /root/repo
 for n in $tag ${r}_c2 ${tag}_c1b; do

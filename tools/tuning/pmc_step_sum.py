@@ -1,7 +1,8 @@
 #!/usr/bin/env python
 """Per-kernel HBM traffic and MFMA occupancy of one train step from the three counter passes of pmc_step.sh.
 
-    python tools/tuning/pmc_step_sum.py NAME STATS_CSV > profiles/NAME_hbm_kernels.txt   (+ profiles/r03_hbm_traffic.json)
+    python tools/tuning/pmc_step_sum.py NAME STATS_CSV > profiles/NAME_hbm_kernels.txt   (+ profiles/<round>_hbm_traffic.json,
+                                                                                         <round> = NAME up to its first "_")
 
 Durations come from the un-instrumented ``rocprofv3 --kernel-trace --stats`` run (STATS_CSV): counter passes
 serialise dispatches and run at a lower clock.  FETCH_SIZE is doubled (gfx950 tallies 128-byte requests of wide
@@ -51,6 +52,11 @@ def main(name, stats_csv):
         "physics_adjoint_kernel": V * (9 + 7 + 3) * 4,
         "plane_sum_kernel": V * 3 * 4,
         "zfold_kernel": V * (15 + 3) * 4,
+        # conv_thin.hip (round 4): terrain convs, feature conv, the discriminator's first conv (two samples per launch)
+        "conv_thin3_kernel<8, 1, 1, 2, 32, 8>": V * 17 * 2,
+        "conv_thin3_kernel<16, 1, 1, 2, 32, 8>": V * 32 * 2,
+        "conv_thin3_kernel<8, 8, 1, 4, 16, 8>": v * 132 * 2,
+        "conv_thin3_kernel<8, 1, 2, 2, 32, 4>": 2 * V * 35 * 2,
     }
     rows = []
     for k, (us, calls) in dur.items():
@@ -73,12 +79,17 @@ def main(name, stats_csv):
         print(f"{k[:58]:58s} {calls:6d} {us:9.1f} {f / 1e6:10.1f} {w / 1e6:10.1f} {rate:6.2f} {util:6.2f} {wait:6.2f} {a}")
     traffic = {}
     for key, k in (("hr0", "conv_tile_kernel<8, 1, 4, 9, 2, false, false>"), ("lff_fwd", "conv1x1_v2_kernel<8, 8, false, true>"),
-                   ("hr1_fwd", "conv_slide_fwd_kernel<5, 5, 18>"), ("hr1_dgrad", "conv_slide_dgrad_kernel<5, 5, 9>")):
+                   ("hr1_fwd", "conv_slide_fwd_kernel<5, 5, 18>"), ("hr1_dgrad", "conv_slide_dgrad_kernel<5, 5, 9>"),
+                   ("terrain0_fwd", "conv_thin3_kernel<8, 1, 1, 2, 32, 8>"),
+                   # (forward and input gradient of terrain_convs.1 are launches of ONE kernel: their mean)
+                   ("terrain1_fwd", "conv_thin3_kernel<16, 1, 1, 2, 32, 8>"),
+                   ("terrain1_dgrad", "conv_thin3_kernel<16, 1, 1, 2, 32, 8>"),
+                   ("feature_fwd", "conv_thin3_kernel<8, 8, 1, 4, 16, 8>"), ("d0_fwd", "conv_thin3_kernel<8, 1, 2, 2, 32, 4>")):
         r = [x for x in rows if x[1] == k]
         if r:
             traffic[key] = r[0][4] + r[0][5]
     traffic["source"] = f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes '{name}', 2 x FETCH + WRITE, bytes per launch"
-    json.dump(traffic, open("profiles/r03_hbm_traffic.json", "w"), indent=1)
+    json.dump(traffic, open(f"profiles/{name.split('_')[0]}_hbm_traffic.json", "w"), indent=1)
 
 
 if __name__ == "__main__":
