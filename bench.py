@@ -488,6 +488,38 @@ def main():
         out["comm"] = dp.stats.summary(args.steps)
         out["comm"]["bucket_mb"] = cfg.dist.bucket_mb
         out["comm"]["sync_bn"] = bool(cfg.dist.sync_bn)
+    if world == 1 and not args.no_fp32_side and args.dtype == "bf16" and kind == "gan" and args.config == "C3p":
+        # The reference computes in fp32 (its AMP lines are commented out, Generator_3D_Resnet_ESRGAN.py:65): the same
+        # workload in that arithmetic, a few steps, reported beside the bf16 line (never as `value`).
+        del step
+        gan.G.program().launch_probe = None
+        gan.D.features.program().launch_probe = None
+        del gan
+        torch.cuda.empty_cache()
+        gan32, _ = make_gan(args, dev, "fp32")
+        gan32.feed_xy_niter(x, y, torch.tensor(cfg.training.niter, device=dev), 1, 1)
+
+        def step32(i):
+            gan32.optimize_parameters(LR, HR, Z, 2 * i)
+            gan32.optimize_parameters(LR, HR, Z, 2 * i + 1)
+            gan32.update_learning_rate()
+
+        n32 = 3
+        for i in range(2):
+            step32(i)
+        torch.cuda.synchronize()
+        t32 = time.perf_counter()
+        for i in range(2, 2 + n32):
+            step32(i)
+        torch.cuda.synchronize()
+        ms32 = (time.perf_counter() - t32) / n32 * 1e3
+        tf32 = step_flops / 1e12 / (ms32 * 1e-3)
+        out["fp32_reference_arithmetic"] = {
+            "ms_per_step": round(ms32, 2), "steps": n32, "warmup": 2, "train_steps_per_s": round(1e3 / ms32, 4),
+            "achieved_tflops": round(tf32, 1), "peak": 157.3, "frac": round(tf32 / 157.3, 4),
+            "note": "same workload with compute_dtype fp32 (v_mfma_f32_16x16x4_f32 tile kernels): the reference's own arithmetic"}
+        del gan32
+        torch.cuda.empty_cache()
     if world == 1 and not args.no_cpu_baseline:
         # all cores this process may run on ("all physical cores, count stated")
         cores = granted_cores()
