@@ -17,7 +17,7 @@ import sys
 
 def short(n):
     n = n.replace("void (anonymous namespace)::", "").replace("(anonymous namespace)::", "")
-    return n.split("(")[0]
+    return n.split("(")[0].replace(", BF16>", ">")  # (round 4: the tile kernel's element type is a template parameter)
 
 
 def load(path, counters):
