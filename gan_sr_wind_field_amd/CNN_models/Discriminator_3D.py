@@ -32,7 +32,7 @@ class FeaturePyramid(nn.Sequential):
 
         def add(prefix, seq):
             conv = seq[0]
-            bn = seq[1] if len(seq) > 1 and isinstance(seq[1], nn.BatchNorm3d) else None
+            bn = seq[1] if len(seq) > 1 and isinstance(seq[1], (nn.BatchNorm3d, nn.InstanceNorm3d)) else None
             act = isinstance(seq[-1], nn.LeakyReLU)
             out.append(engine.DLayer(engine.site_from_conv(prefix + ".0", conv), bn, act))
 

@@ -38,8 +38,8 @@ def create_conv_lrelu_layer(in_channels, out_channels, kernel_size, stride=1, pa
     if normalization_type:
         if normalization_type == "batch":
             layers.append(nn.BatchNorm3d(out_channels))
-        elif normalization_type == "instance":
-            raise NotImplementedError("instance norm is not on the MI355X path (no shipped config uses it)")
+        elif normalization_type == "instance":  # (reference :26-30: no affine parameters, no running statistics)
+            layers.append(nn.InstanceNorm3d(out_channels))
         else:
             raise NotImplementedError(f"Unknown norm type {normalization_type}")
     if lrelu:

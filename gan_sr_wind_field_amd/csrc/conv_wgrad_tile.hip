@@ -111,7 +111,12 @@ __device__ __forceinline__ void dma_wait_upto(int n) {
 #define WG_STAMP(k) do {} while (0)
 #endif
 
-template <int TN> __device__ __forceinline__ int ysw(int v) { return TN <= 4 ? (v >> 1) & 3 : v & 7; }
+// (TN = 1: 32-byte rows like the x image - one block per row, 8 consecutive voxels are 256 contiguous bytes: no swizzle)
+template <int TN> __device__ __forceinline__ int ysw(int v) { return TN == 1 ? 0 : (TN <= 4 ? (v >> 1) & 3 : v & 7); }
+// bytes per dy row in LDS.  One n-tile (the thin convs: the z-folded last conv, the terrain convs) used to take the
+// 128-byte rows of the 2..4-tile form, three quarters of them zeros fetched from the zero page: 32 KB of a 68 KB tile
+// DMA on the last conv's gradient, which is bound by exactly that stream.
+constexpr int wgt_rby(int tn) { return tn == 1 ? 32 : (tn <= 4 ? 128 : 256); }
 
 // DMA units (1 KB) a wave may have to issue per tile for the x / dy image: registers of the resolved source geometry.
 // The accumulator-heavy instantiations (5x5x5, 192 accumulators) get what their 4x4x16 tile needs and no more.
@@ -123,7 +128,7 @@ __global__ __launch_bounds__(512) void wgrad_tile_kernel(const WgtArgs a) {
   constexpr int WAVES = 8, NT = 512;
   constexpr int XRPU = 32;            // x rows (32 B) per 1 KB DMA unit
   constexpr int XK = wgt_xk(SPW, TN), YK = wgt_yk(SPW, TN);  // DMA units per wave per tile (checked on the host)
-  constexpr int RBY = TN <= 4 ? 128 : 256;  // bytes per dy row
+  constexpr int RBY = wgt_rby(TN);          // bytes per dy row
   constexpr int YRPU = 1024 / RBY;          // dy rows per 1 KB DMA unit
   static_assert(TN <= 8, "dy rows hold at most 128 channels");
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -573,7 +578,7 @@ int launch_tile(WgtArgs& a, hipStream_t st) {
       if ((M & 31) || M > mmax) continue;
       if (a.ups && ((tx | ty) & 1)) continue;  // the x0 - px parity must not depend on the tile
       const int L = (tx + a.KX - 1) * (ty + a.KY - 1) * (tz + a.KZ - 1);
-      const int xs = CT * round_up(L * 32, 1024), ys = round_up(M * (TN <= 4 ? 128 : 256), 1024);
+      const int xs = CT * round_up(L * 32, 1024), ys = round_up(M * wgt_rby(TN), 1024);
       if (xs / 1024 > wgt_xk(SPW, TN) * WAVES || ys / 1024 > wgt_yk(SPW, TN) * WAVES || L > 65535) continue;
       if (round_up(M * 2, 1024) + nbuf * (xs + ys) > 160 * 1024) continue;
       best = ci;
@@ -588,7 +593,7 @@ int launch_tile(WgtArgs& a, hipStream_t st) {
   const int L = (a.TX + a.KX - 1) * (a.TY + a.KY - 1) * (a.TZ + a.KZ - 1);
   a.xp_bytes = round_up(L * 32, 1024);
   a.xs_bytes = CT * a.xp_bytes;
-  a.buf_bytes = a.xs_bytes + round_up(M * (TN <= 4 ? 128 : 256), 1024);
+  a.buf_bytes = a.xs_bytes + round_up(M * wgt_rby(TN), 1024);
   a.off_buf = round_up(M * 2, 1024);
   const size_t lds = (size_t)a.off_buf + (size_t)a.nbuf * a.buf_bytes;
   a.n_chunks = (a.Cout + 16 * TN - 1) / (16 * TN);

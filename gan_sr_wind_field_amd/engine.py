@@ -1393,8 +1393,12 @@ def run_generator(prog: GeneratorProgram, x: Tensor, Z: Tensor, training: bool,
 @dataclass
 class DLayer:
     conv: ConvSite
-    bn: Optional[nn.BatchNorm3d]
+    bn: Optional[nn.Module]  # nn.BatchNorm3d, or nn.InstanceNorm3d (normalization_type "instance": no parameters)
     act: bool
+
+    @property
+    def inorm(self) -> bool:
+        return isinstance(self.bn, nn.InstanceNorm3d)
 
 
 class DiscriminatorProgram(ProgramBase):
@@ -1414,9 +1418,10 @@ class DiscriminatorProgram(ProgramBase):
         self.slope = slope
         order: List[nn.Parameter] = []
         for l in reversed(self.layers):
-            if l.bn is not None:
+            if l.bn is not None and not l.inorm:
                 order += [l.bn.weight, l.bn.bias]
             order.append(l.conv.weight)
+        self._unit_affine: Dict[tuple, Tuple[Tensor, Tensor]] = {}
         self.space = GradSpace(order)
         self.param_list = order
         self._scratch_elems = self.wgrad_scratch_elems([l.conv for l in self.layers], self.e)
@@ -1448,6 +1453,14 @@ class DiscriminatorProgram(ProgramBase):
                                     (1 - (ph >> 1), 1 - (ph & 1), 1 if sz == 1 else 0), fwd_only=True) for ph in range(4)]
                     groups.append([zc, wp, par])
                 self.dparity[li] = groups
+
+    def _unit(self, C_: int, dev) -> Tuple[Tensor, Tensor]:
+        """(ones, zeros) of C_ floats: the affine of a normalisation layer that has none"""
+        key = (C_, str(dev))
+        if key not in self._unit_affine:
+            self._unit_affine[key] = (torch.ones(C_, dtype=torch.float32, device=dev),
+                                      torch.zeros(C_, dtype=torch.float32, device=dev))
+        return self._unit_affine[key]
 
     def strided_dgrad_active(self, li: int) -> bool:
         return STRIDED_DGRAD and li in self.dparity and self.use_tile and self.dt == torch.bfloat16
@@ -1607,6 +1620,27 @@ class DiscriminatorProgram(ProgramBase):
             bn = l.bn
             C_ = s.cout
             a = self._empty(y.shape, x)
+            if l.inorm:
+                # nn.InstanceNorm3d (reference torch_blocks.py:26-30; defaults: no affine, no running statistics): every
+                # SAMPLE is normalised with its own per-channel statistics, in training and in eval mode alike - the
+                # BatchNorm kernels on one-sample slices with unit scale, nothing to synchronise between ranks
+                n = y[:1].numel() // y.shape[-1]
+                one, zero = self._unit(C_, x.device)
+                st = torch.empty((B, 4 * C_), dtype=torch.float32, device=x.device)
+                work = torch.empty((B, 2 * C_), dtype=torch.float32, device=x.device)
+                means, invstds = [], []
+                for b in range(B):
+                    yb = y[b:b + 1]
+                    ops.bn_stats(yb, st[b, :2 * C_])
+                    ops.bn_mean(st[b, :2 * C_], work[b, :C_], float(n), None)
+                    ops.bn_stats(yb, st[b, 2 * C_:4 * C_], shift=work[b, :C_])
+                    ops.bn_finalize(st[b, 2 * C_:4 * C_], work[b, :C_], work[b, C_:], float(n), bn.eps, 0.0, None, None, None)
+                    ops.bn_apply_lrelu(yb, a[b:b + 1], work[b, :C_], work[b, C_:], one, zero, l.act, sl)
+                    means.append(work[b, :C_])
+                    invstds.append(work[b, C_:])
+                recs.append(dict(inp=h, y=y, a=a, mean=means, invstd=invstds, count=[float(n)] * B, inorm=True))
+                h = a
+                continue
             if not training:
                 mean = bn.running_mean.detach().float()
                 invstd = torch.rsqrt(bn.running_var.detach().float() + bn.eps)
@@ -1695,7 +1729,15 @@ class DiscriminatorProgram(ProgramBase):
                 bn = l.bn
                 y_o = r["y"][lo:]
                 gy = self._empty(y_o.shape, g)
-                if r["training"]:
+                if r.get("inorm"):  # per-sample statistics, unit scale, no parameter gradients
+                    one, _ = self._unit(C_, dev)
+                    for b in range(g.shape[0]):
+                        sums = torch.empty(2 * C_, dtype=torch.float32, device=dev)
+                        ops.bn_bwd_reduce(g[b:b + 1], act_o[b:b + 1], y_o[b:b + 1], r["mean"][lo + b], r["invstd"][lo + b],
+                                          l.act, sl, sums)
+                        ops.bn_bwd_apply(g[b:b + 1], y_o[b:b + 1], gy[b:b + 1], r["mean"][lo + b], r["invstd"][lo + b], one,
+                                         sums, 1.0 / r["count"][lo + b])
+                elif r["training"]:
                     G = r["groups"]
                     g0 = lo // Bg
                     # the two per-channel sums of every group of the pass, side by side: one collective per layer

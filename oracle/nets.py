@@ -65,6 +65,7 @@ class DSpec:
     bn_eps: float = 1e-5
     bn_momentum: float = 0.1
     bf16_storage: bool = False  # test aid, see GSpec.bf16_storage
+    norm: str = "batch"         # normalization_type of the blocks: "batch" | "instance" (torch_blocks.py:20-30)
 
 
 @dataclass
@@ -77,6 +78,7 @@ class ConvDesc:
     pad: Tuple[int, int, int]
     bn: Optional[str] = None  # state_dict prefix of the BatchNorm3d that follows
     act: bool = True
+    inorm: bool = False       # an nn.InstanceNorm3d follows instead (no parameters, no buffers: torch_blocks.py:26-30)
 
 
 # --------------------------------------------------------------------------- #
@@ -234,15 +236,19 @@ def d_layers(s: DSpec) -> List[ConvDesc]:
     bf = s.bf
     L: List[ConvDesc] = []
 
+    if s.norm not in ("batch", "instance"):
+        raise NotImplementedError(f"Unknown norm type {s.norm}")
+    inorm = s.norm == "instance"  # (the blocks only: the slicing tail below is always "batch", Discriminator_3D.py:158,167)
+
     def block(idx: int, cin: int, cout: int, first_norm: bool, halve_z: bool):
         L.append(
             ConvDesc(f"features.{idx}.0.0", cin, cout, (k, k, k), (1, 1, 1), (p, p, p),
-                     bn=f"features.{idx}.0.1" if first_norm else None)
+                     bn=f"features.{idx}.0.1" if first_norm and not inorm else None, inorm=first_norm and inorm)
         )
         stride = (2, 2, 2) if halve_z else (2, 2, 1)
         L.append(
             ConvDesc(f"features.{idx}.1.0", cout, cout, (4, 4, k), stride, (1, 1, 1),
-                     bn=f"features.{idx}.1.1")
+                     bn=None if inorm else f"features.{idx}.1.1", inorm=inorm)
         )
 
     block(0, s.in_channels, bf, False, s.nz > 19)
@@ -305,6 +311,8 @@ def discriminator_features(
                 s.bn_momentum,
                 s.bn_eps,
             )
+        if l.inorm:  # nn.InstanceNorm3d defaults: no affine, no running statistics, instance statistics in every mode
+            x = F.instance_norm(_st(x, s), eps=s.bn_eps)
         if l.act:
             x = _lrelu(x, s.slope)
         x = _st(x, s)

@@ -138,7 +138,7 @@ def build_ref_G(spec: onets.GSpec):
 
 def build_ref_D(spec: onets.DSpec):
     return RefD(spec.in_channels, spec.bf, feat_kern_size=spec.feat_kern, number_of_z_layers=spec.nz,
-                enable_slicing=spec.enable_slicing, dropout_probability=spec.dropout_p)
+                enable_slicing=spec.enable_slicing, dropout_probability=spec.dropout_p, normalization_type=spec.norm)
 
 
 def gen_generators():
@@ -162,9 +162,9 @@ def gen_generators():
         save(f"g_small_s{scale}.npz", **arrays)
 
 
-def gen_discriminators():
-    for slicing, xy, nz in ((True, 64, 4), (False, 128, 3), (False, 128, 21)):
-        spec = onets.DSpec(bf=4, nz=nz, enable_slicing=slicing)
+def gen_discriminators(cases=((True, 64, 4, "batch"), (False, 128, 3, "batch"), (False, 128, 21, "batch"))):
+    for slicing, xy, nz, norm in cases:
+        spec = onets.DSpec(bf=4, nz=nz, enable_slicing=slicing, norm=norm)
         D = build_ref_D(spec)
         shapes = onets.d_param_shapes(spec)
         ref_shapes = {k: tuple(v.shape) for k, v in D.state_dict().items()}
@@ -189,7 +189,7 @@ def gen_discriminators():
         for k, v in D.state_dict().items():
             if "running_" in k or "num_batches" in k:
                 arrays[f"after.{k}"] = np_(v)
-        tag = ("slice" if slicing else "full") + f"_z{nz}"
+        tag = ("slice" if slicing else "full") + f"_z{nz}" + ("" if norm == "batch" else f"_{norm}")
         save(f"d_small_{tag}.npz", **arrays)
 
 
@@ -430,7 +430,7 @@ def gen_config_golden():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["conv", "blocks", "G", "D", "physics", "trace", "init", "config", "c1", "data"]
+    which = sys.argv[1:] or ["conv", "blocks", "G", "D", "physics", "trace", "init", "config", "c1", "data", "Dinst"]
     if "config" in which:
         gen_config_golden()
     if "conv" in which:
@@ -441,6 +441,8 @@ if __name__ == "__main__":
         gen_generators()
     if "D" in which:
         gen_discriminators()
+    if "Dinst" in which:  # normalization_type = "instance" (torch_blocks.py:26-30), both slicing modes (the tail stays "batch")
+        gen_discriminators(((False, 128, 3, "instance"), (True, 64, 4, "instance")))
     if "physics" in which:
         gen_physics()
     if "trace" in which:

@@ -35,7 +35,7 @@ def build_D(spec, dtype, seed):
 
     D = Discriminator_3D(spec.in_channels, spec.bf, feat_kern_size=spec.feat_kern, number_of_z_layers=spec.nz,
                          enable_slicing=spec.enable_slicing, dropout_probability=spec.dropout_p,
-                         use_mixed_precision=dtype == torch.bfloat16)
+                         use_mixed_precision=dtype == torch.bfloat16, normalization_type=spec.norm)
     sd = onets.deterministic_state(onets.d_param_shapes(spec), seed=seed, scale=1.0)
     D.load_state_dict(sd)
     return D.to(DEV), sd
@@ -122,7 +122,7 @@ def test_generator_dropout_mask_and_train_mode(hip):
     assert torch.isfinite(out2).all() and not torch.equal(out2, out)
 
 
-def _d_grads_fp64(spec, seed, x_seed, xy, nz):
+def _d_grads_fp64(spec, seed, x_seed, xy, nz):  # (spec carries the normalisation type)
     """fp64 oracle gradients of the D test graph (train-mode BN), on the CPU."""
     sd = onets.deterministic_state(onets.d_param_shapes(spec), seed=seed, scale=1.0)
     sd = {k: (v.double() if v.is_floating_point() else v).clone() for k, v in sd.items()}
@@ -136,11 +136,14 @@ def _d_grads_fp64(spec, seed, x_seed, xy, nz):
     return {k: v.grad for k, v in sd.items() if v.is_floating_point() and v.grad is not None}
 
 
-@pytest.mark.parametrize("slicing,xy,nz", [(True, 64, 4), (False, 128, 3), (False, 128, 21)])
-def test_discriminator_fp32_vs_reference(golden, hip, slicing, xy, nz):
-    tag = ("slice" if slicing else "full") + f"_z{nz}"
+@pytest.mark.parametrize("slicing,xy,nz,norm", [(True, 64, 4, "batch"), (False, 128, 3, "batch"), (False, 128, 21, "batch"),
+                                                (False, 128, 3, "instance"), (True, 64, 4, "instance")])
+def test_discriminator_fp32_vs_reference(golden, hip, slicing, xy, nz, norm):
+    """(norm = "instance": the reference's ``normalization_type="instance"``, torch_blocks.py:26-30 - nn.InstanceNorm3d
+    layers in the blocks, fixtures recorded from the reference; the slicing tail keeps its BatchNorm3d layers)"""
+    tag = ("slice" if slicing else "full") + f"_z{nz}" + ("" if norm == "batch" else f"_{norm}")
     g = golden(f"d_small_{tag}.npz")
-    spec = onets.DSpec(bf=4, nz=nz, enable_slicing=slicing)
+    spec = onets.DSpec(bf=4, nz=nz, enable_slicing=slicing, norm=norm)
     D, _ = build_D(spec, torch.float32, 31 + nz)
     gen = torch.Generator().manual_seed(int(g["x_seed"]))
     x = (torch.rand((2, 3, xy, xy, nz), generator=gen) * 2 - 1).to(DEV).requires_grad_(True)

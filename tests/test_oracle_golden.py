@@ -75,11 +75,14 @@ def test_generator_small(golden, scale, n, nz):
         assert rel_l2(v.grad, T(g[f"grad.{k}"])) < 2e-4, k
 
 
-@pytest.mark.parametrize("slicing,xy,nz", [(True, 64, 4), (False, 128, 3), (False, 128, 21)])
-def test_discriminator_small(golden, slicing, xy, nz):
-    tag = ("slice" if slicing else "full") + f"_z{nz}"
+@pytest.mark.parametrize("slicing,xy,nz,norm", [(True, 64, 4, "batch"), (False, 128, 3, "batch"), (False, 128, 21, "batch"),
+                                                (False, 128, 3, "instance"), (True, 64, 4, "instance")])
+def test_discriminator_small(golden, slicing, xy, nz, norm):
+    """(norm = "instance": normalization_type of the reference's blocks, torch_blocks.py:26-30 - nn.InstanceNorm3d
+    without parameters or running statistics; the slicing tail keeps its BatchNorm3d layers)"""
+    tag = ("slice" if slicing else "full") + f"_z{nz}" + ("" if norm == "batch" else f"_{norm}")
     g = golden(f"d_small_{tag}.npz")
-    spec = onets.DSpec(bf=4, nz=nz, enable_slicing=slicing)
+    spec = onets.DSpec(bf=4, nz=nz, enable_slicing=slicing, norm=norm)
     sd = onets.deterministic_state(onets.d_param_shapes(spec), seed=31 + nz, scale=1.0)
     params = [v for k, v in sd.items() if v.is_floating_point() and "running_" not in k]
     for p in params:
