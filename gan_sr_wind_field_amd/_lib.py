@@ -56,7 +56,8 @@ class LreluMask(C.Structure):
 class DgradOpts(C.Structure):
     """``wsr_dgrad_opts_t`` (ABI 6)."""
 
-    _fields_ = [("acc_src", C.c_void_p), ("ws", C.c_void_p), ("ws_bytes", C.c_int64)]
+    _fields_ = [("acc_src", C.c_void_p), ("ws", C.c_void_p), ("ws_bytes", C.c_int64), ("acc_beta", C.c_float),
+                ("beta2", C.c_float), ("res2", C.c_void_p), ("res2_ctot", C.c_int32), ("res2_off", C.c_int32)]
 
 
 _lib: Optional[C.CDLL] = None

@@ -206,6 +206,7 @@ int wsr_conv1x1_v1_bf16(const unsigned short* in, int in_ctot, int in_off, int r
   a.res_ctot = res_ctot; a.res_off = res_off; a.res_c1 = res_c1;
   a.res2 = res2; a.res2_ctot = res2_ctot; a.res2_off = res2_off; a.beta2 = beta2;
   if (res2 && (res2_ctot % 4 || res2_off % 4)) return WSR_EUNSUPPORTED;
+  if (res2 && res && res_c1 < n_out) return WSR_EUNSUPPORTED;  // (partial second residual: the 16-wave form only)
   a.alpha = alpha; a.beta = beta; a.slope = slope; a.act = act;
   a.nvox = nvox;
   a.in_ctot = in_ctot; a.in_off = in_off; a.out_ctot = out_ctot; a.out_off = out_off; a.Cout = n_out;

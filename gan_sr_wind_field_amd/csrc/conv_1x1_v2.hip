@@ -29,6 +29,7 @@ struct C2Args {
   int res_ctot, res_off, res_c1;  // residual on produced channels < res_c1 only (multiple of 8)
   const unsigned short* res2;
   int res2_ctot, res2_off;
+  int res2_c1;  // second residual on produced channels < res2_c1 (= res_c1 when the first one is partial, else all)
   float beta2;
   float alpha, beta, slope;
   int act;
@@ -132,7 +133,7 @@ __global__ __launch_bounds__(512, 4) void conv1x1_v2_kernel(const C2Args a) {
 #pragma unroll
           for (int q = 0; q < 8; ++q) f[q] += rs1 * r[q];
         }
-        if (a.res2) {
+        if (a.res2 && co < a.res2_c1) {
           float r[8];
           unpack8(*reinterpret_cast<const uint4*>(a.res2 + vc * a.res2_ctot + a.res2_off + co), r);
 #pragma unroll
@@ -247,6 +248,9 @@ static int wsr_conv1x1_v2_bf16(const unsigned short* in, int in_ctot, int in_off
   a.in = in; a.wf = wfrag; a.out = out; a.bias = bias; a.res = res;
   a.res_ctot = res_ctot; a.res_off = res_off; a.res_c1 = res_c1;
   a.res2 = res2; a.res2_ctot = res2_ctot; a.res2_off = res2_off; a.beta2 = beta2;
+  // (a partial first residual - the accumulating input gradient of a dense block's LFF: the first nf channels only -
+  // limits the second one to the same channels: it is the RRDB-level shortcut gradient joining the running one)
+  a.res2_c1 = (res && res_c1 < n_out) ? res_c1 : 0x7FFFFFFF;
   a.alpha = alpha; a.beta = beta; a.slope = slope; a.act = act;
   a.nvox = nvox;
   a.in_ctot = in_ctot; a.in_off = in_off; a.out_ctot = out_ctot; a.out_off = out_off;

@@ -525,8 +525,10 @@ extern "C" int wsr_conv3d_dgrad_tile(const wsr_conv_t* c, const void* dy, const 
     a.res_ctot = c->in_ctot;
     a.res_off = c->in_off;
     a.res_c1 = accumulate > 1 ? accumulate : 0x7FFFFFFF;
-    a.beta = 1.f;
+    a.beta = (opts && opts->acc_beta != 0.f) ? opts->acc_beta : 1.f;
   }
+  const unsigned short* res2 = opts ? (const unsigned short*)opts->res2 : nullptr;
+  if (res2 && (!accumulate || opts->res2_off < 0 || opts->res2_ctot <= 0)) return WSR_EINVAL;
   if (opts) {
     a.ws = opts->ws;
     a.ws_bytes = (long)opts->ws_bytes;
@@ -548,10 +550,12 @@ extern "C" int wsr_conv3d_dgrad_tile(const wsr_conv_t* c, const void* dy, const 
   if (!f32 && c->KX * c->KY * c->KZ == 1 && !c->lat && ux == 1 && !a.out_planar && (c->px | c->py | c->pz) == 0 && !a.chan_scale) {
     const int rc = wsr_conv1x1_bf16(a.in, a.in_ctot, a.in_off, c->Cout, a.wf, (unsigned short*)a.out, a.out_ctot,
                                     a.out_off, a.Cout, (long)c->B * c->Xo * c->Yo * c->Zo, nullptr, a.res, a.res_ctot,
-                                    a.res_off, a.res ? a.res_c1 : 0, a.alpha, a.beta, 0, 0.f, mask, nullptr, 0, 0, 0.f,
+                                    a.res_off, a.res ? a.res_c1 : 0, a.alpha, a.beta, 0, 0.f, mask, res2,
+                                    res2 ? opts->res2_ctot : 0, res2 ? opts->res2_off : 0, res2 ? opts->beta2 : 0.f,
                                     as_stream(stream));
     if (rc != WSR_EUNSUPPORTED) return rc;
   }
+  if (res2) return WSR_EUNSUPPORTED;  // only the streaming kernel takes a second residual
   // z-tapless conv with a thin output side and the mask of the layer below (the z-folded last conv): sliding window
   const bool no_slide = WSR_ENV_SET("WSR_NO_SLIDE");  // tuning / A-B switch
   if (!f32 && !no_slide && mask && c->KZ == 1 && c->Cout <= 16 && !accumulate && !dx_planar && !c->lat && ux == 1 && c->pz == 0 &&

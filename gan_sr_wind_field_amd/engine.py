@@ -38,6 +38,10 @@ STACK_FWD = __import__("os").environ.get("WSR_STACK_FWD", "1") != "0"
 #: keep the running gradient of a dense block's output in channels [0, nf) of the dense gradient buffer
 #: (WSR_GD_INPLACE=0: separate tensor + one add per block)
 GD_INPLACE = __import__("os").environ.get("WSR_GD_INPLACE", "1") != "0"
+#: the gradient of an RRDB's output stays in one dense gradient buffer while its chain runs in a second one and joins
+#: the chain's result as a second residual of the last LFF input gradient: no copy / scale / add passes at the RRDB
+#: boundaries (WSR_GD_PINGPONG=0: one buffer + two channel-window passes per RRDB)
+GD_PINGPONG = __import__("os").environ.get("WSR_GD_PINGPONG", "1") != "0"
 #: run the last conv of the generator in its z-folded form (WSR_ZFOLD=0: plain 5x5x5 conv with 3 outputs)
 ZFOLD = __import__("os").environ.get("WSR_ZFOLD", "1") != "0"
 #: filter gradients of the generator's dense blocks on a second HIP stream (they depend only on saved activations and the
@@ -389,7 +393,8 @@ class ProgramBase:
             run()
 
     def dgrad(self, s: ConvSite, g: Tensor, g_off: int, dx: Tensor, dx_off: int, in_xyz, *, alpha: float = 1.0,
-              accumulate: bool = False, dx_planar: bool = False, mask=None, acc_src: Optional[Tensor] = None) -> None:
+              accumulate: bool = False, dx_planar: bool = False, mask=None, acc_src: Optional[Tensor] = None,
+              acc_beta: float = 1.0, res2: Optional[Tensor] = None) -> None:
         """dx[window] (+)= alpha * conv^T(g[window]);  in_xyz = stored input extent of the conv.
         ``mask`` = (y, y_off, c0, c1[, chan_scale]): afterwards multiply channels [c0, c1) of the window by the
         LeakyReLU derivative taken from channels [y_off, ...) of ``y`` - and by the Dropout3d keep factors
@@ -404,9 +409,9 @@ class ProgramBase:
             m = None if mask is None else (mask[0], mask[1], mask[2], mask[3], self.slope) + tuple(mask[4:5])
             if self.tile_ok(s) and ops.conv_dgrad_tile(d, g, self.filters.get_frag(s.weight, True), dx, alpha=alpha,
                                                        accumulate=accumulate, dx_planar=dx_planar, mask=m,
-                                                       acc_src=acc_src):
+                                                       acc_src=acc_src, acc_beta=acc_beta, res2=res2):
                 return
-            if acc_src is not None:
+            if acc_src is not None or res2 is not None or acc_beta != 1.0:
                 raise RuntimeError("accumulating from another buffer needs the tile kernels (set WSR_WGRAD_STREAM=0)")
             if int(accumulate) > 1:
                 raise RuntimeError("partial accumulation needs the tile kernels (set WSR_GD_INPLACE=0)")
@@ -1201,18 +1206,20 @@ class GeneratorProgram(ProgramBase):
             gbuf = gs
         del ghcat
         gs = gbuf  # grad of s = f + lr_conv(t_last)
-        # ---- lr_conv
-        self.wgrad(self.lr_conv, saved["t_last"], 0, gs, 0, flat, sp, scratch)
-        g = self._empty((B, X, Y, nz, nf), g_out)
-        self.dgrad(self.lr_conv, gs, 0, g, 0, (X, Y, nz))
-        ready(self.lr_conv.weight)
-        # ---- trunk
+        # ---- lr_conv (its input gradient is the gradient of the last RRDB's output: written straight into channels
+        # [0, nf) of the dense gradient buffer when the trunk's chain starts there, see `pingpong` below)
         bufs = saved["bufs"]
         bi = len(bufs)
         dense = bufs[0].shape[-1] if bufs else nf
         gd = self._empty((B, X, Y, nz, dense), g_out) if bufs else None
         inplace = (GD_INPLACE and gd is not None and self.dt == torch.bfloat16 and self.use_tile
                    and ops.conv1x1_covers(nf, dense, True))
+        pingpong = bool(GD_PINGPONG and inplace and WGRAD_STREAM < 2 and DETERMINISTIC and bufs)
+        self.wgrad(self.lr_conv, saved["t_last"], 0, gs, 0, flat, sp, scratch)
+        g = gd if pingpong else self._empty((B, X, Y, nz, nf), g_out)
+        self.dgrad(self.lr_conv, gs, 0, g, 0, (X, Y, nz))
+        ready(self.lr_conv.weight)
+        # ---- trunk
         # Filter gradients on a second stream (WSR_WGRAD_STREAM = ring size): they read the saved dense buffer and the
         # block's output gradients and feed nothing in the input-gradient chain.  The running gradient then MOVES through
         # a ring of dense gradient buffers - block j reads its output gradient in ring[slot][..., :nf] and writes its
@@ -1225,7 +1232,48 @@ class GeneratorProgram(ProgramBase):
             ring = [gd] + [self._empty(gd.shape, g_out) for _ in range(WGRAD_STREAM - 1)]
             free_ev: List[Optional[torch.cuda.Event]] = [None] * len(ring)
             slot = 0
+        if pingpong:
+            # Two dense gradient buffers alternate per RRDB.  `cur[..., :nf]` holds g_r, the gradient of RRDB r's output,
+            # UNSCALED and untouched while the chain runs in `oth`: the first LFF input gradient of the RRDB reads it
+            # there (alpha = rdb_scale * rr_scale, identity shortcut weighted rr_scale - the RRDB's residual scaling rides
+            # on the launch), the last one adds it as a second residual, so that after the last block's window 0
+            # oth[..., :nf] = g_r + chain gradient = g_{r-1}.  (Was: gd[:nf] = rr_scale * g and g += gd[:nf], two
+            # channel-window passes per RRDB, 0.5 ms per step.)
+            cur, oth = gd, self._empty(gd.shape, g_out)
+            for rdbs, rr_scale in zip(reversed(self.rrdbs), reversed(self.rrdb_scales)):
+                nb = len(rdbs)
+                for j, (convs, lff, rdb_scale) in enumerate(reversed(rdbs)):
+                    bi -= 1
+                    buf = bufs[bi]
+                    first, lastb = j == 0, j == nb - 1
+                    go = cur if first else oth               # the block's output gradient sits in go[..., :nf]
+                    sc = rdb_scale * (rr_scale if first else 1.0)
+                    self.wgrad(lff, buf, 0, go, 0, flat, sp, scratch, scale=sc)
+                    rows = ops.chan_sum_rows(nf, go.numel() // go.shape[-1])
+                    if not rows:
+                        raise RuntimeError("LFF bias gradient outside the two-pass sum (set WSR_GD_PINGPONG=0)")
+                    pr = self._arena_take(rows * nf, dev).view(rows, nf)
+                    ops.chan_sum_partials(go, 0, nf, pr)
+                    self._pending_unpack.append((pr[0].view(1, 1, nf), sp.view(flat, lff.bias).view(1, nf, 1), sc, rows, nf))
+                    nc = len(convs)
+                    last = nf + (nc - 1) * gc
+                    self.dgrad(lff, go, 0, oth, 0, (X, Y, nz), alpha=sc, accumulate=nf, acc_src=go if first else None,
+                               acc_beta=rr_scale if first else 1.0, res2=cur if lastb else None,
+                               mask=(buf, last, last, last + gc) if nc else None)
+                    if STACK_DGRAD and self.dense_stackable(convs):
+                        self.dgrad_dense(convs, oth, buf, (X, Y, nz))
+                    else:
+                        for i in reversed(range(nc)):
+                            off = nf + i * gc
+                            m = (buf, off - gc, off - gc, off) if i > 0 else None
+                            self.dgrad(convs[i], oth, off, oth, 0, (X, Y, nz), accumulate=True, mask=m)
+                    self.wgrad_dense(convs, buf, oth, flat, sp, scratch)
+                    ready(lff.weight, lff.bias, *[c.weight for c in convs])
+                cur, oth = oth, cur
+            g = cur  # (channels [0, nf) of a dense buffer: the feature conv's filter gradient reads that window)
         for rdbs, rr_scale in zip(reversed(self.rrdbs), reversed(self.rrdb_scales)):
+            if pingpong:
+                break
             g_skip = g  # d(out)/d(x_rr) through the RRDB shortcut
             if side is not None:
                 ops.chan_axpby(ring[slot], 0, g, 0, nf, alpha=rr_scale)

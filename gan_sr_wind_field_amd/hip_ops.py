@@ -221,7 +221,8 @@ def conv1x1_covers(red: int, n_out: int, masked: bool) -> bool:
 
 def conv_dgrad_tile(desc: ConvDesc, dy: Tensor, wfrag_t: Tensor, dx: Tensor, *, alpha: float = 1.0,
                     accumulate: bool = False, dx_planar: bool = False, mask=None, acc_src: Optional[Tensor] = None,
-                    use_ws: bool = True) -> bool:
+                    use_ws: bool = True, acc_beta: float = 1.0, res2: Optional[Tensor] = None, res2_off: int = 0,
+                    beta2: float = 1.0) -> bool:
     """``mask`` = (y, y_off, c0, c1, slope): fold ``leaky_relu_backward`` of produced channels [c0, c1) into
     the epilogue, the mask taken from channels [y_off, y_off + c1 - c0) of the saved output ``y``.
     ``acc_src``: with ``accumulate``, the tensor (same layout as ``dx``) whose values are added instead of dx's own."""
@@ -230,6 +231,10 @@ def conv_dgrad_tile(desc: ConvDesc, dy: Tensor, wfrag_t: Tensor, dx: Tensor, *, 
         raise ValueError("acc_src must have dx's layout")
     opts = _lib.DgradOpts()
     opts.acc_src = _p(acc_src)
+    opts.acc_beta = acc_beta
+    if res2 is not None:  # (streaming 1x1x1 kernel only: the RRDB-level gradient joining the running one)
+        _need_cuda(res2)
+        opts.res2, opts.res2_ctot, opts.res2_off, opts.beta2 = _p(res2), res2.shape[-1], res2_off, beta2
     if use_ws:
         opts.ws, opts.ws_bytes = tile_workspace()
     mp = None

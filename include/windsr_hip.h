@@ -163,6 +163,15 @@ typedef struct wsr_dgrad_opts {
   const void* acc_src;
   void* ws;
   int64_t ws_bytes;
+  /* The running gradient of a residual-in-residual block (torch_blocks.py:293-330: out = x + scale * chain(x)) without
+   * copy / add passes - streaming 1x1x1 kernel only (WSR_EUNSUPPORTED elsewhere when res2 is set):
+   *   acc_beta : weight of the accumulated values (0 = 1): dx = alpha * conv^T(dy) + acc_beta * acc_src (first n channels);
+   *   res2     : a second tensor added to the same first n channels, dx += beta2 * res2[..., res2_off + c] - the gradient
+   *              of the RRDB's output, which joins the chain's gradient where the chain ends.                     */
+  float acc_beta;
+  float beta2;
+  const void* res2;
+  int32_t res2_ctot, res2_off;
 } wsr_dgrad_opts_t;
 int wsr_conv3d_dgrad_tile(const wsr_conv_t* c, const void* dy, const void* wfrag_t, void* dx, float alpha,
                           int accumulate, int dx_planar, const wsr_lrelu_mask_t* mask, const wsr_dgrad_opts_t* opts,
