@@ -403,7 +403,7 @@ int wsr_bn_bwd_reduce(void* dy, const void* y, const void* x, const float* mean,
  * dx = gamma*invstd*g (sums == NULL).  ABI 6 - act_y != NULL: g is first multiplied by the LeakyReLU derivative
  * (act_y > 0 ? 1 : slope) of the layer's saved OUTPUT act_y (same shape) - an eval-mode layer in a pass that wants
  * no parameter gradients (D inside a generator iteration, wind_field_GAN_3D.py:570-583) needs no separate
- * leaky_relu_backward pass; bf16 with C a multiple of 8 only (WSR_EUNSUPPORTED otherwise).                  */
+ * leaky_relu_backward pass.                                                                                 */
 int wsr_bn_bwd_apply(const void* g, const void* x, void* dx, const float* mean, const float* invstd,
                      const float* gamma, const float* sums, float inv_n, const void* act_y, float slope, int32_t C,
                      int64_t nvox, int32_t dtype, void* stream);
