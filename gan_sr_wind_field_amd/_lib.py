@@ -43,6 +43,7 @@ class Epilogue(C.Structure):
         ("act", C.c_int32), ("slope", C.c_float), ("out_planar", C.c_int32), ("act_c1", C.c_int32),
         ("ws", C.c_void_p), ("ws_bytes", C.c_int64),
         ("res2", C.c_void_p), ("res2_ctot", C.c_int32), ("res2_off", C.c_int32), ("beta2", C.c_float),
+        ("mask", C.c_void_p),
     ]
 
 

@@ -450,6 +450,17 @@ extern "C" int wsr_conv3d_fwd_tile(const wsr_conv_t* c, const void* x, const voi
     if (a.res && (a.res_off < 0 || a.res_off + c->Cout > a.res_ctot)) return WSR_EINVAL;
     a.ws = ep->ws;
     a.ws_bytes = (long)ep->ws_bytes;
+    if (ep->mask) {  // LeakyReLU-backward mask on a forward-form launch (parity input gradients of strided convs)
+      const wsr_lrelu_mask_t* mk = ep->mask;
+      if (!mk->y || ep->out_planar || mk->c0 < 0 || mk->c1 > c->Cout || mk->c0 >= mk->c1 || mk->c0 % 4 || mk->y_ctot % 4 ||
+          mk->y_off % 4 || mk->y_off + (mk->c1 - mk->c0) > mk->y_ctot || mk->chan_scale)
+        return WSR_EINVAL;
+      if (f32) return WSR_EUNSUPPORTED;
+      a.mask_y = (const unsigned short*)mk->y;
+      a.mask_ctot = mk->y_ctot; a.mask_off = mk->y_off;
+      a.mask_c0 = mk->c0; a.mask_c1 = mk->c1;
+      a.mask_slope = mk->slope;
+    }
   }
   a.B = c->B; a.Xi = c->Xi; a.Yi = c->Yi; a.Zi = c->Zi;
   a.Xo = c->Xo; a.Yo = c->Yo; a.Zo = c->Zo;
@@ -466,7 +477,7 @@ extern "C" int wsr_conv3d_fwd_tile(const wsr_conv_t* c, const void* x, const voi
     a.ph_wstride = (long)wsr_frag_filter_elems(c->Cout, c->Cin, c->KX * c->KY * c->KZ, c->dtype);
   }
   if (f32 && c->KX * c->KY * c->KZ == 1) return WSR_EUNSUPPORTED;  // (1x1x1 in fp32: the generic kernel)
-  if (!f32 && c->KX * c->KY * c->KZ == 1 && !c->lat && !a.ups && !a.out_planar && !a.chan_scale && (c->px | c->py | c->pz) == 0 &&
+  if (!f32 && !a.mask_y && c->KX * c->KY * c->KZ == 1 && !c->lat && !a.ups && !a.out_planar && !a.chan_scale && (c->px | c->py | c->pz) == 0 &&
       (c->sx | c->sy | c->sz) == 1 && a.act <= 1 && a.act_c1 == 0x7FFFFFFF) {
     const int rc = wsr_conv1x1_bf16(a.in, a.in_ctot, a.in_off, c->Cin, a.wf, (unsigned short*)a.out, a.out_ctot,
                                     a.out_off, a.Cout, (long)c->B * c->Xo * c->Yo * c->Zo, a.bias, a.res, a.res_ctot,
@@ -488,7 +499,7 @@ extern "C" int wsr_conv3d_fwd_tile(const wsr_conv_t* c, const void* x, const voi
   // 3x3x3 "same" conv over <= 16 stored channels (terrain convs, feature conv, the discriminator's first conv): memory-bound
   if (!f32 && (c->KX & c->KY & c->KZ) == 3 && (c->KX | c->KY | c->KZ) == 3 && (c->px & c->py & c->pz) == 1 &&
       (c->px | c->py | c->pz) == 1 && (c->sx | c->sy | c->sz) == 1 && !a.ups && !c->lat && !a.out_planar &&
-      !a.chan_scale && !a.res && a.act <= 1 && a.act_c1 == 0x7FFFFFFF && c->Cin <= 16) {
+      !a.chan_scale && !a.res && !a.mask_y && a.act <= 1 && a.act_c1 == 0x7FFFFFFF && c->Cin <= 16) {
     const int rc = wsr_conv_thin3(a.in, a.in_ctot, a.in_off, c->Cin, a.wf, (unsigned short*)a.out, a.out_ctot, a.out_off,
                                   a.Cout, c->B, c->Xi, c->Yi, c->Zi, a.bias, a.alpha, a.act, a.slope, as_stream(stream));
     if (rc != WSR_EUNSUPPORTED) return rc;

@@ -52,6 +52,10 @@ WGRAD_STREAM = int(__import__("os").environ.get("WSR_WGRAD_STREAM", "0"))
 #: fp32 programs (the reference's own arithmetic) on the LDS halo-tile kernels too: stride-1 convs, dense-block stacking,
 #: the z-folded last conv (WSR_F32_TILE=0: generic implicit-GEMM kernels as in rounds 1-3)
 F32_TILE = __import__("os").environ.get("WSR_F32_TILE", "1") != "0"
+#: the LeakyReLU backward of the discriminator's first conv in the epilogue of the strided input gradient above it
+#: (WSR_FOLD_D_MASK=1; default off: measured equal - same-device A/B 97.5 / 97.5 against 97.5 / 98.0 ms per step - the
+#: masked 32-wide parity launches grow by what the pass over the 128^3 x 32 tensor costs; parity-tested either way)
+FOLD_D_MASK = __import__("os").environ.get("WSR_FOLD_D_MASK", "0") != "0"
 POISON_BUFFERS = bool(int(__import__("os").environ.get("WSR_POISON_BUFFERS", "0")))
 #: filter gradients without float atomics: every spatial split of a wgrad launch stores its partial sums to its own
 #: copy and the unpack pass adds the copies in index order - two backward passes give bit-identical gradients
@@ -1604,8 +1608,10 @@ class DiscriminatorProgram(ProgramBase):
                     self._dparity_stamp[li] = stamp
         super().refresh_filters(backward)
 
-    def strided_dgrad(self, li: int, gy: Tensor, gin: Tensor) -> None:
-        """gin (B, X, Y, Z, cin) = input gradient of down-sampling conv ``li`` from gy (B, X/2, Y/2, Z/s, cout)"""
+    def strided_dgrad(self, li: int, gy: Tensor, gin: Tensor, mask=None) -> None:
+        """gin (B, X, Y, Z, cin) = input gradient of down-sampling conv ``li`` from gy (B, X/2, Y/2, Z/s, cout).
+        ``mask`` = (y, y_off, c0, c1, slope): the LeakyReLU derivative of the layer below (whose output ``y`` is this
+        conv's input) rides on the epilogues - every voxel of gin is written by exactly one parity launch."""
         s = self.layers[li].conv
         sz = s.stride[2]
         B, oxyz = gy.shape[0], tuple(gy.shape[1:4])
@@ -1617,13 +1623,13 @@ class DiscriminatorProgram(ProgramBase):
                 if batched:
                     d = ops.make_desc(g, self.dt, B, oxyz, gy.shape[-1], 0, gin.shape[-1], 0, cin=self.cp(s.cout),
                                       cout=self.cp(s.cin), lat=(0, 0, 4, sz, zc))
-                    if ops.conv_fwd_tile(d, gy, frs[0], gin):
+                    if ops.conv_fwd_tile(d, gy, frs[0], gin, mask=mask):
                         continue
                 for ph, ps in enumerate(par):
                     d = ops.make_desc(ConvGeom(s.cout, s.cin, ps.kernel, (1, 1, 1), ps.pad), self.dt, B, oxyz,
                                       gy.shape[-1], 0, gin.shape[-1], 0, cin=self.cp(s.cout), cout=self.cp(s.cin),
                                       lat=(ph >> 1, ph & 1, 0, sz, zc))
-                    if not ops.conv_fwd_tile(d, gy, frs[ph], gin):
+                    if not ops.conv_fwd_tile(d, gy, frs[ph], gin, mask=mask):
                         raise RuntimeError("strided input gradient outside the tile kernels (set WSR_STRIDED_DGRAD=0)")
 
         if self.launch_probe is not None:
@@ -1762,6 +1768,7 @@ class DiscriminatorProgram(ProgramBase):
         if lo and (need_dw or lo % Bg):
             raise ValueError("a partial backward pass starts at a group boundary and has no parameter gradients")
         g = g_feat.contiguous()  # (covers samples [lo, B) only)
+        premasked = False  # g already carries the LeakyReLU derivative of the layer it is the output gradient of
         dx = None
         recs = saved["recs"]
         for li in reversed(range(len(self.layers))):
@@ -1770,8 +1777,9 @@ class DiscriminatorProgram(ProgramBase):
             C_ = s.cout
             act_o = r["a"][lo:]
             if l.bn is None:
-                if l.act:
+                if l.act and not premasked:
                     ops.lrelu_bwd_(g, 0, act_o, 0, g.shape[-1], sl)
+                premasked = False
                 gy = g
             else:
                 bn = l.bn
@@ -1838,7 +1846,13 @@ class DiscriminatorProgram(ProgramBase):
             if li > 0:
                 gin = self._empty(inp.shape, g)
                 if self.strided_dgrad_active(li) and lattice_ok:
-                    self.strided_dgrad(li, gy, gin)
+                    # the layer below has no BatchNorm (the first conv: conv + LeakyReLU): its leaky_relu_backward rides on
+                    # the epilogues of this input gradient instead of a pass of its own over the largest tensor of D
+                    below = self.layers[li - 1]
+                    premasked = (below.bn is None and below.act and inp.shape[-1] == below.conv.cout
+                                 and below.conv.cout <= 32 and FOLD_D_MASK)
+                    self.strided_dgrad(li, gy, gin, mask=(recs[li - 1]["a"][lo:], 0, 0, below.conv.cout, sl)
+                                       if premasked else None)
                 else:
                     self.dgrad(s, gy, 0, gin, 0, tuple(inp.shape[1:4]))
                 g = gin

@@ -187,7 +187,7 @@ def conv_fwd_tile(desc: ConvDesc, x: Tensor, wfrag: Tensor, y: Tensor, *, bias: 
                   chan_scale: Optional[Tensor] = None, res: Optional[Tensor] = None, res_off: int = 0,
                   alpha: float = 1.0, beta: float = 0.0, act=False, slope: float = 0.2,
                   out_planar: bool = False, act_c1: int = 0, res2: Optional[Tensor] = None, res2_off: int = 0,
-                  beta2: float = 0.0, use_ws: bool = True) -> bool:
+                  beta2: float = 0.0, use_ws: bool = True, mask=None) -> bool:
     """LDS halo-tile forward conv (bf16, stride 1).  Returns False when the shape is outside
     the tile kernels (the caller then uses :func:`conv_fwd`).  ``act`` = 2 / ``act_c1``: the two stages of a
     split dense-block conv (see ``wsr_epilogue_t``)."""
@@ -205,6 +205,12 @@ def conv_fwd_tile(desc: ConvDesc, x: Tensor, wfrag: Tensor, y: Tensor, *, bias: 
         ep.res2, ep.res2_ctot, ep.res2_off, ep.beta2 = _p(res2), res2.shape[-1], res2_off, beta2
     if use_ws:
         ep.ws, ep.ws_bytes = tile_workspace()
+    if mask is not None:  # (y, y_off, c0, c1, slope): LeakyReLU-backward mask on a forward-form launch (wsr_epilogue_t.mask)
+        my, my_off, mc0, mc1, mslope = mask
+        _need_cuda(my)
+        mk = _lib.LreluMask()
+        mk.y, mk.y_ctot, mk.y_off, mk.c0, mk.c1, mk.slope = my.data_ptr(), my.shape[-1], my_off, mc0, mc1, mslope
+        ep.mask = C.addressof(mk)
     rc = _lib.lib().wsr_conv3d_fwd_tile(C.byref(desc), _p(x), _p(wfrag), _p(y), C.byref(ep), _stream())
     if rc == _lib.WSR_EUNSUPPORTED:
         return False

@@ -75,6 +75,7 @@ typedef struct wsr_conv {
   int32_t lat_mz, lat_oz;
 } wsr_conv_t;
 
+struct wsr_lrelu_mask;
 /* Fused epilogue:  v = conv (+ bias[c]);  v = lrelu(v, slope) if act;
  *                  v *= chan_scale[b*Cout + c] if chan_scale (Dropout3d mask);
  *                  y = alpha*v (+ beta*res[...,res_off + c] if res).          */
@@ -105,6 +106,12 @@ typedef struct wsr_epilogue {
                                RRDB's shortcut at once (torch_blocks.py:290,330)                                */
   int32_t res2_ctot, res2_off;
   float beta2;
+  /* ABI 6 (tile entry point only, NULL = none): the LeakyReLU-backward mask of wsr_conv3d_dgrad_tile on a FORWARD-form
+   * launch - the parity input gradients of the discriminator's strided convs are forward convs over dy (wsr_conv_t.lat):
+   * with the mask of the layer below (Discriminator_3D.py:67-75: conv + LeakyReLU, no BatchNorm) in their epilogue
+   * that layer's leaky_relu_backward needs no pass of its own.  bf16, <= 32 or 65..224 produced channels
+   * (WSR_EUNSUPPORTED otherwise).                                                                           */
+  const struct wsr_lrelu_mask* mask;
 } wsr_epilogue_t;
 
 int wsr_abi_version(void);
