@@ -95,7 +95,7 @@ struct CtArgs {
   int xs_stage, xs_units;
   int f32;     // 1: fp32 operands (the element type of in / wf / res / mask_y / out; see the kernel's T)
   int prio;    // 1: waves of the second half of the workgroup run the main loop at s_setprio 1 (tuning switch)
-  int ablate;  // -DWSR_CT_STAMPS builds, timing only: skip 1 = activation prefetch, 2 = weight prefetch, 4 = LDS reads, 8 = MFMAs
+  int ablate;  // -DWSR_CT_STAMPS builds, timing only: skip 1 = activation prefetch, 2 = weight prefetch, 4 = LDS reads, 8 = MFMAs; 32 = paired 16-byte epilogue stores
   unsigned long long* stamps;  // -DWSR_CT_STAMPS builds: [workgroup][8] clock samples of wave 0 (else unused)
 };
 
@@ -625,6 +625,25 @@ void conv_tile_kernel(const CtArgs a) {
           o4.z *= mk.z;
           o4.w *= mk.w;
         }
+#ifdef WSR_CT_STAMPS
+        // (tuning build, ablate & 32: the store pattern of pair-interleaved n-tiles - one 16-byte store per lane for two
+        // n-tiles, 64 contiguous bytes per voxel and instruction - with the wrong values: timing only)
+        if constexpr (sizeof(E) == 2) {
+          if (a.ablate & 32) {
+            if (!(j & 1) && j + 1 < TN) {
+              float4 d4 = o4;
+              d4.x += acc[i][j + 1][0];
+              d4.y += acc[i][j + 1][1];
+              union { uint4 u; unsigned short h[8]; } pk;
+              pk.h[0] = f2bf(o4.x); pk.h[1] = f2bf(o4.y); pk.h[2] = f2bf(o4.z); pk.h[3] = f2bf(o4.w);
+              pk.h[4] = f2bf(d4.x); pk.h[5] = f2bf(d4.y); pk.h[6] = f2bf(d4.z); pk.h[7] = f2bf(d4.w);
+              *reinterpret_cast<uint4*>(orow[i] + 16 * j + 4 * fg) = pk.u;
+              continue;
+            }
+            if ((j & 1)) continue;
+          }
+        }
+#endif
         st4<T>(orow[i] + 16 * j, o4);
         continue;
       }

@@ -12,6 +12,8 @@ def load(f):
     return d
 name = sys.argv[1]
 d1, d2 = load(f"gpurun_out/{name}_pmc1.csv"), load(f"gpurun_out/{name}_pmc2.csv")
+import os
+d3 = load(f"gpurun_out/{name}_pmc3.csv") if os.path.exists(f"gpurun_out/{name}_pmc3.csv") else {}
 m = lambda v: sum(v) / len(v)
 for key in d1:
     a, b = d1[key], d2.get(key, {})
@@ -22,6 +24,13 @@ for key in d1:
     busy = m(a["SQ_BUSY_CYCLES"])
     print("   busy_cycles %.3g  lds_idx_active %.3g  lds_bank_conflict %.3g (%.1f%% of active)" % (
         busy, m(a["SQ_LDS_IDX_ACTIVE"]), m(a["SQ_LDS_BANK_CONFLICT"]), 100*m(a["SQ_LDS_BANK_CONFLICT"])/max(m(a["SQ_LDS_IDX_ACTIVE"]),1)))
+    # LDS_IDX_ACTIVE / BUSY_CYCLES: share of the SQ-busy cycles in which the LDS index pipe was working (both summed over the
+    # chip's SQs, so the quotient is per CU); the guide's MI355X note: effective clock = GRBM_GUI_ACTIVE / 8 / wall time
+    print("   lds_idx_active / busy_cycles %.2f" % (m(a["SQ_LDS_IDX_ACTIVE"]) / max(busy, 1)))
+    c = d3.get(key)
+    if c:
+        print("   effective clock %.2f GHz (GRBM_GUI_ACTIVE / 8 / duration; reads high below 0.3 ms)" % (
+            m(c["GRBM_GUI_ACTIVE"]) / 8 / m(c["_dur"])))
     if b:
         print("   mfma_busy %.3g  insts_mfma %.3g  active: lds %.3g vmem %.3g valu %.3g  insts_lds %.3g  lds_data_fifo_full %.3g cmd_fifo_full %.3g" % (
             m(b["SQ_VALU_MFMA_BUSY_CYCLES"]), m(b["SQ_INSTS_MFMA"]), m(b["SQ_ACTIVE_INST_LDS"]), m(b["SQ_ACTIVE_INST_VMEM"]),
