@@ -720,6 +720,13 @@ int run_tile(WgtArgs& a, int taps, int Cout, int Cin, hipStream_t st) {
     const int rc = launch_tile<4, 6, 4>(a, st);
     if (rc != WSR_EUNSUPPORTED) return rc;
   }
+  // one 16-channel c-tile against many output channels (the z-folded last conv's gradient with its operands' roles
+  // exchanged, engine.py SWAP_THIN_WGRAD: 16 -> 144, 5x5x1): 4 slots per wave = 32 taps x 1 c-tile, 48 output channels
+  // per workgroup - the generic choice below would pad the c-chunk to 32 channels and the n-chunk to 64 (37 % useful MFMAs)
+  if (c->Cin <= 16 && c->Cout % 48 == 0 && a.tri_step == 0 && !WSR_ENV_SET("WSR_WG_NO341")) {
+    const int rc = launch_tile<3, 4, 1>(a, st);
+    if (rc != WSR_EUNSUPPORTED) return rc;
+  }
   // <= 28 taps (3x3x3): 7 slots per wave = 28 taps x 2 c-tiles (32 input channels per chunk)
   if (c->Cout <= 16) return launch_tile<1, 7, 2>(a, st);
   if (c->Cout <= 32) return launch_tile<2, 7, 2>(a, st);

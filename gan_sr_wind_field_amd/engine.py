@@ -56,6 +56,9 @@ F32_TILE = __import__("os").environ.get("WSR_F32_TILE", "1") != "0"
 #: (WSR_FOLD_D_MASK=1; default off: measured equal - same-device A/B 97.5 / 97.5 against 97.5 / 98.0 ms per step - the
 #: masked 32-wide parity launches grow by what the pass over the 128^3 x 32 tensor costs; parity-tested either way)
 FOLD_D_MASK = __import__("os").environ.get("WSR_FOLD_D_MASK", "0") != "0"
+# Filter gradient of the z-folded last conv with the operands' roles exchanged (GeneratorProgram.backward): the 16-channel
+# output gradient is the image that is shifted per tap, the 144-channel activation the one that is read once
+SWAP_THIN_WGRAD = __import__("os").environ.get("WSR_THIN_WGRAD_SWAP", "1") != "0"
 POISON_BUFFERS = bool(int(__import__("os").environ.get("WSR_POISON_BUFFERS", "0")))
 #: filter gradients without float atomics: every spatial split of a wgrad launch stores its partial sums to its own
 #: copy and the unpack pass adds the copies in index order - two backward passes give bit-identical gradients
@@ -760,6 +763,19 @@ class GeneratorProgram(ProgramBase):
             wz = torch.empty((self.hr1.cout * k[2], self.hr1.cin, k[0], k[1], 1), dtype=torch.float32, device=w.device)
             self.hr1z = ConvSite("hr_convs.2.zfold", wz, None, (k[0], k[1], 1), (1, 1, 1),
                                  (self.hr1.pad[0], self.hr1.pad[1], 0))
+        # ... and its filter gradient with the roles of the two operands exchanged:
+        #   dW[n, t, c] = sum_v dy[v, n] x[v + t - p, c] = sum_u x[u, c] dy[u + (K-1-t) - p, n]     (p = (K-1)/2)
+        # is the filter gradient of a conv 16 -> 144 whose "input" is dy and whose "output gradient" is x, taps flipped.
+        # As stated the 144-channel activation is the halo image, fetched (K+7)^2/64 = 2.25 times per chunk of 32 of its
+        # channels, against ONE 16-wide n-tile: two transposing reads per MFMA.  Exchanged, the activation is read once, the
+        # 16-channel image carries the halo and every fragment meets three or four others.
+        self._hr1z_t: Optional[ConvSite] = None
+        self._hr1z_grad_t: Optional[Tensor] = None
+        if self.hr1z is not None and SWAP_THIN_WGRAD and k[0] % 2 == 1 and k[1] % 2 == 1 and \
+                self.hr1.pad[:2] == (k[0] // 2, k[1] // 2):
+            wt = torch.empty((self.hr1.cin, (self.hr1.cout * k[2] + 7) // 8 * 8, k[0], k[1], 1), device="meta")
+            self._hr1z_t = ConvSite("hr_convs.2.zfold.T", wt, None, (k[0], k[1], 1), (1, 1, 1),
+                                    (self.hr1.pad[0], self.hr1.pad[1], 0))
         # Sub-pixel form of the up-sampling convs (reference torch_blocks.py:345-347: nn.Upsample(scale_factor=(2,2,1),
         # mode="nearest") in front of a 3x3x3 conv): output parity (a, b) only ever sees 2x2 distinct un-sampled
         # voxels per z level, so the conv is four 2x2x3 convs on the un-sampled input whose filters are sums of the
@@ -1150,11 +1166,21 @@ class GeneratorProgram(ProgramBase):
             ops.zunfold(g_out, g3, kz, self.hr1.pad[2], 0, cz_p)
             if self._hr1z_grad is None or self._hr1z_grad.device != dev:
                 self._hr1z_grad = torch.empty_like(self.hr1z.weight, device=dev)
-            self.wgrad(self.hr1z, h, 0, g3, 0, flat, sp, scratch, dst=self._hr1z_grad)
+            swap = self._hr1z_t is not None and self.dt == torch.bfloat16 and cat_c == self.hr1.cin and DETERMINISTIC
+            if swap:
+                if self._hr1z_grad_t is None or self._hr1z_grad_t.device != dev:
+                    self._hr1z_grad_t = torch.empty(self._hr1z_t.weight.shape, dtype=torch.float32, device=dev)
+                self.wgrad(self._hr1z_t, g3, 0, h, 0, flat, sp, scratch, dst=self._hr1z_grad_t)
+            else:
+                self.wgrad(self.hr1z, h, 0, g3, 0, flat, sp, scratch, dst=self._hr1z_grad)
             self.dgrad(self.hr1z, g3, 0, gh, 0, (sX, sY, nz), mask=hr0_mask)
             self.flush_unpack()
-            sp.view(flat, self.hr1.weight).copy_(
-                self._hr1z_grad.view(self.hr1.cout, kz, self.hr1.cin, kx, ky).permute(0, 2, 3, 4, 1))
+            if swap:  # [ci][co*KZ + kz (padded)][K-1-kx][K-1-ky][0] -> hr1's [co][ci][kx][ky][kz]
+                gt = self._hr1z_grad_t[:, :cz, :, :, 0].flip(2, 3).view(self.hr1.cin, self.hr1.cout, kz, kx, ky)
+                sp.view(flat, self.hr1.weight).copy_(gt.permute(1, 0, 3, 4, 2))
+            else:
+                sp.view(flat, self.hr1.weight).copy_(
+                    self._hr1z_grad.view(self.hr1.cout, kz, self.hr1.cin, kx, ky).permute(0, 2, 3, 4, 1))
         else:
             co_p = self.cp(self.hr1.cout)
             g3 = self._empty((B, sX, sY, nz, co_p), g_out)

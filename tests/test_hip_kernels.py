@@ -608,6 +608,10 @@ def _cpu_wgrad(x, gy, k, p):
     ("k3_up_z16", 32, 64, (3, 3, 3), (4, 4, 16), 1, True),     # Z16 with the up-sampled x tile
     ("lff_z48", 256, 128, (1, 1, 1), (4, 8, 48), 1, False),    # <8,1,8,Z16>, 3 z tiles
     ("hr1z_z16", 144, 15, (5, 5, 1), (8, 8, 16), 1, False),    # z-folded last conv: (5,5,1) taps, 15 outputs
+    # the same gradient with the operands' roles exchanged (engine.SWAP_THIN_WGRAD): 16 -> 144, <3,4,1>: one c-tile,
+    # three n-chunks of 48, flat 8x8x4 tiles; and the instantiation on 3x3x3 taps with a ragged volume
+    ("hr1z_T", 16, 144, (5, 5, 1), (16, 8, 16), 1, False),
+    ("thin_T_k3", 8, 48, (3, 3, 3), (5, 9, 10), 2, False),
 ])
 def test_wgrad_tile_kernel_bf16(hip, name, cin, cout, k, xyz, B, ups):
     """LDS-tile filter-gradient kernel (bf16) vs an fp32 CPU wgrad of the same rounded operands."""

@@ -614,17 +614,20 @@ def test_generator_bf16_zfolded_last_conv(hip, monkeypatch):
     LR, HR, Z, x, y = ogan.synthetic_batch(2, 6, 5, 4, seed=12)
     gy = torch.randn(2, 3, 24, 24, 5, generator=torch.Generator().manual_seed(4)).to(DEV)
     res = {}
-    for zf in (True, False):
-        monkeypatch.setattr(engine, "ZFOLD", zf)
+    for zf in (True, "stated", False):
+        monkeypatch.setattr(engine, "ZFOLD", bool(zf))
+        # (the folded conv's filter gradient: operands' roles exchanged by default, "stated": x the halo image)
+        monkeypatch.setattr(engine, "SWAP_THIN_WGRAD", zf is True)
         G, _ = build_G(spec, torch.bfloat16, 33)
         G.eval()
         seen = []
         G.program().launch_probe = lambda tag, fn: (seen.append(tag), fn())
         out = G(LR.to(DEV), Z.to(DEV))
         (out * gy).sum().backward()
-        assert any("zfold" in t for t in seen) == zf
+        assert any("zfold" in t for t in seen) == bool(zf)
+        assert ("wgrad:hr_convs.2.zfold.T" in seen) == (zf is True)
         res[zf] = (out.detach(), {k: p.grad.clone() for k, p in G.named_parameters()})
-        if zf:  # the folded filter follows a parameter update
+        if zf is True:  # the folded filter follows a parameter update
             with torch.no_grad():
                 G.hr_convs[2].weight.mul_(2.0)
             assert rel_l2(G(LR.to(DEV), Z.to(DEV)) - G.hr_convs[2].bias.view(1, 3, 1, 1, 1),
@@ -632,6 +635,8 @@ def test_generator_bf16_zfolded_last_conv(hip, monkeypatch):
     assert rel_l2(res[True][0], res[False][0]) < 1e-5
     for k in res[True][1]:
         assert rel_l2(res[True][1][k], res[False][1][k]) < 2e-2, k
+    # exchanged vs stated: the same bf16 products, another summation order
+    assert rel_l2(res[True][1]["hr_convs.2.weight"], res["stated"][1]["hr_convs.2.weight"]) < 1e-5
 
 
 @pytest.mark.parametrize("nf,gc,n_rrdb", [(32, 16, 1), (128, 32, 1)])

@@ -155,6 +155,22 @@ def hr1z_case():
     ms = timeit(lambda: o.conv_dgrad_tile(dd, gy, wft, dx, mask=(x, 0, 0, c, 0.2, drop)))
     nb = vox * (16 * 2 + 2 * c * 2)
     print(f"{'hr1z dgrad 16->144 +mask':28s} {'dgrad':12s} {ms * 1e3:9.1f} us  {nb / ms / 1e6:8.1f} GB/s algorithmic")
+    # filter gradient, as stated (x the halo image, one n-tile) and with the operands' roles exchanged (engine.py
+    # SWAP_THIN_WGRAD: dy the halo image, 48 of x's channels per workgroup); the two must agree after the tap flip
+    dw = o.make_desc(o.ConvGeom(c, 16, (5, 5, 1), (1, 1, 1), (2, 2, 0)), DT, B, xyz, c, 0, 16, 0)
+    n1 = o.conv_wgrad_nparts(dw)
+    p1 = torch.empty((n1, 16, 25, c), dtype=torch.float32, device=DEV)
+    ms1 = timeit(lambda: o.conv_wgrad_parts(dw, x, gy, p1, n1))
+    ds = o.make_desc(o.ConvGeom(16, c, (5, 5, 1), (1, 1, 1), (2, 2, 0)), DT, B, xyz, 16, 0, c, 0)
+    n2 = o.conv_wgrad_nparts(ds)
+    p2 = torch.empty((n2, c, 25, 16), dtype=torch.float32, device=DEV)
+    ms2 = timeit(lambda: o.conv_wgrad_parts(ds, gy, x, p2, n2))
+    nb = vox * (16 * 2 + c * 2)
+    print(f"{'hr1z wgrad as stated':28s} {'wgrad':12s} {ms1 * 1e3:9.1f} us  {nb / ms1 / 1e6:8.1f} GB/s algorithmic ({n1} copies)")
+    print(f"{'hr1z wgrad roles exchanged':28s} {'wgrad':12s} {ms2 * 1e3:9.1f} us  {nb / ms2 / 1e6:8.1f} GB/s algorithmic ({n2} copies)")
+    g1 = p1.double().sum(0)                                   # [n][tap][c]
+    g2 = p2.double().sum(0).flip(1).permute(2, 1, 0)          # [c][K-1-tap][n] -> [n][tap][c]
+    print(f"   exchanged vs stated: rel-L2 {float((g1 - g2).norm() / g1.norm()):.2e}")
 
 
 CASES["hr1z"] = hr1z_case
