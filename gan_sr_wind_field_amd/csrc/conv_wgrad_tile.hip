@@ -569,7 +569,9 @@ int launch_tile(WgtArgs& a, hipStream_t st) {
   // comment - measured SLOWER, 55 us against 46 at four buffers of 64 voxels.  Ablation stamps of that launch: tile
   // loop 34 us; without LDS reads and MFMAs still 27.6 us - the LDS-DMA stream itself, 134 MB at 5.3 TB/s, dy once per
   // c-chunk - and without the DMA 21.5 us: it is bound by DMA THROUGHPUT, not by the latency of one tile in flight)
-  const int nbuf_want = taps == 1 ? WSR_ENV_INT("WSR_WG_NBUF", 2) : 2;
+  // (<3,4,1>, the exchanged thin gradient: 50 KB per buffer, a ring of three fits - WSR_WG_NBUF_THIN=3 measured equal,
+  // 390 us either way: that launch is not waiting for one tile's DMA either)
+  const int nbuf_want = taps == 1 ? WSR_ENV_INT("WSR_WG_NBUF", 2) : ((SPW == 4 && CT == 1) ? WSR_ENV_INT("WSR_WG_NBUF_THIN", 2) : 2);
   const int mmax = taps == 1 && nbuf_want > 2 ? WSR_ENV_INT("WSR_WG_MMAX", 64) : 1 << 30;
   for (int nbuf = nbuf_want; nbuf >= 2 && best < 0; --nbuf) {
     for (int ci = 0; ci < 7; ++ci) {
