@@ -520,7 +520,11 @@ struct CdArgs {
   int nty, ntz, nseg, XS, blk;
 };
 
-template <int KX, int KY, int NT>
+// AH: rounds of DMA kept in flight beyond the one being issued (0: what round 3 shipped - a plane's DMA has one round,
+// 2.2 us, to land; 1: two rounds - the mask ring grows to five planes, the dy ring is used to its eighth slot).
+// Measured (round 4, WSR_CS_AH=1, same device, tools/bench_conv.py hr1z): 370.5 / 373.8 us against 359.8 / 355.3 - the
+// launch is not waiting for its reads; twice the reads in flight only get in the way of the result stores.  Default 0.
+template <int KX, int KY, int NT, int AH>
 struct CdGeom {
   static constexpr int TY = 16, TZ = 4;
   static constexpr int PY = TY + KY - 1;
@@ -533,7 +537,7 @@ struct CdGeom {
   static constexpr int M_NP = TY * TZ * OC;                 // pieces of a mask / result plane
   static constexpr int M_NU = (M_NP + 63) / 64;
   static constexpr int M_B = M_NP * 16;
-  static constexpr int RM = 4;                              // mask ring slots (power of two)
+  static constexpr int RM = 4 + AH;                         // mask ring slots: planes i - 1 .. i + 2 + AH
   static constexpr int NKS = (KX * KY + 1) / 2;             // K-steps: tap pairs x 16 channels
   static constexpr int TN = NT / 4;                         // n-tiles per wave held in registers (four N groups)
   static constexpr int NX = NT - 4 * TN;                    // left-over n-tile (0 or 1): N group 0, filter in LDS
@@ -544,9 +548,9 @@ struct CdGeom {
   static constexpr int LDS_B = OFF_WX + NX * NKS * 1024;
 };
 
-template <int KX, int KY, int NT>
+template <int KX, int KY, int NT, int AH>
 __global__ __launch_bounds__(512) void conv_slide_dgrad_kernel(const CdArgs a) {
-  using G = CdGeom<KX, KY, NT>;
+  using G = CdGeom<KX, KY, NT, AH>;
   constexpr int TY = G::TY, TZ = G::TZ, DY_NP = G::DY_NP, DY_NU = G::DY_NU, DY_B = G::DY_B, RD = G::RD, OC = G::OC;
   constexpr int ROWB = G::ROWB, M_NP = G::M_NP, M_NU = G::M_NU, M_B = G::M_B, RM = G::RM, NKS = G::NKS, TN = G::TN;
   constexpr int NU = G::NU, NX = G::NX;
@@ -642,7 +646,7 @@ __global__ __launch_bounds__(512) void conv_slide_dgrad_kernel(const CdArgs a) {
   auto issue_unit = [&](int k, const cs_srd_t& sm, int xm, const cs_srd_t& sd, int xd) __attribute__((always_inline)) {
     const int u = w4 + 4 * k;
     if (u < M_NU)
-      cs_bufdma16(sm, uoff[k], __builtin_amdgcn_readfirstlane(lds0 + G::OFF_MASK + (unsigned)(xm & (RM - 1)) * M_B + udst[k]));
+      cs_bufdma16(sm, uoff[k], __builtin_amdgcn_readfirstlane(lds0 + G::OFF_MASK + ((unsigned)(xm + RM) % (unsigned)RM) * M_B + udst[k]));
     else if (u < NU)
       cs_bufdma16(sd, uoff[k], __builtin_amdgcn_readfirstlane(lds0 + G::OFF_DY + (unsigned)(xd & (RD - 1)) * DY_B + udst[k]));
   };
@@ -672,19 +676,19 @@ __global__ __launch_bounds__(512) void conv_slide_dgrad_kernel(const CdArgs a) {
   const int lane_extra = (ng - 2 * mh) * 16 * 32;                  // (voxel tile ng of the left-over n-tile, from lane_base)
   const bool tap_hi = (fg >> 1) != 0;
 
-  // ---- prologue: dy planes 0 .. KX, mask planes 0 and 1 -----------------------------------------------------------
+  // ---- prologue: dy planes 0 .. KX + AH, mask planes 0 .. 1 + AH ---------------------------------------------------
   const int last_dy = nplanes + KX - 2;
   if (dma_wave) {
     const cs_srd_t none = cs_make_srd(a.mask, 0u);
 #pragma unroll
-    for (int d = 0; d <= KX; ++d) {
+    for (int d = 0; d <= KX + AH; ++d) {
       const cs_srd_t sd = dy_srd(d, d <= last_dy);
 #pragma unroll
       for (int k = 0; k < UPW; ++k)
         if (w4 + 4 * k >= M_NU) issue_unit(k, none, 0, sd, d);
     }
 #pragma unroll
-    for (int m = 0; m < 2; ++m) {
+    for (int m = 0; m < 2 + AH; ++m) {
       const cs_srd_t sm = mask_srd(m, m < nplanes);
 #pragma unroll
       for (int k = 0; k < UPW; ++k)
@@ -712,7 +716,7 @@ __global__ __launch_bounds__(512) void conv_slide_dgrad_kernel(const CdArgs a) {
 
   auto round = [&](int i, auto dmaw_c) __attribute__((always_inline)) {
     constexpr bool DMAW = decltype(dmaw_c)::value;  // waves 0-3: DMA + the left-over n-tile; waves 4-7: stores
-    const cs_srd_t sm = mask_srd(i + 2, i + 2 < nplanes), sd = dy_srd(i + KX + 1, i + KX + 1 <= last_dy);
+    const cs_srd_t sm = mask_srd(i + 2 + AH, i + 2 + AH < nplanes), sd = dy_srd(i + KX + 1 + AH, i + KX + 1 + AH <= last_dy);
     // rows staged in round i - 1 (plane i - 2) leave now
     const int ip = i - 2;
     char* const st_base = reinterpret_cast<char*>(a.dx + ((long)b * a.X + x_begin + (ip > 0 ? ip : 0)) * dx_plane);
@@ -720,7 +724,7 @@ __global__ __launch_bounds__(512) void conv_slide_dgrad_kernel(const CdArgs a) {
     const bool st_ok = ip >= 0 && ip < nplanes;
     uint4 sreg = make_uint4(0u, 0u, 0u, 0u);
     // plane i - 1 is masked / staged now
-    const char* const mk = mkr + ((i - 1) & (RM - 1)) * M_B;
+    const char* const mk = mkr + ((unsigned)(i - 1 + RM) % (unsigned)RM) * M_B;
     char* const sg_in = stg + ((i - 1) & 1) * M_B;
     f32x4_t acc[2][TN + NX];
 #pragma unroll
@@ -760,7 +764,7 @@ __global__ __launch_bounds__(512) void conv_slide_dgrad_kernel(const CdArgs a) {
       __builtin_amdgcn_sched_barrier(0);
       // (a) one DMA instruction
       if constexpr (DMAW) {
-        if (ks < UPW) issue_unit(ks, sm, i + 2, sd, i + KX + 1);
+        if (ks < UPW) issue_unit(ks, sm, i + 2 + AH, sd, i + KX + 1 + AH);
       }
       // (b) one (voxel tile, n-tile) of plane i - 1: mask, scale, round, stage as [voxel][ROWB] rows
       if (ks < 2 * (TN + NX)) {
@@ -800,10 +804,11 @@ __global__ __launch_bounds__(512) void conv_slide_dgrad_kernel(const CdArgs a) {
     for (int m = 0; m < 2; ++m)
 #pragma unroll
       for (int j = 0; j < TN + NX; ++j) accp[m][j] = acc[m][j];
-    // the DMA issued one round ago has landed; this round's stays in flight
+    // the DMA issued 1 + AH rounds ago has landed; the younger rounds' stay in flight (every round issues the same
+    // number of instructions per wave: planes past the end go out with zero-record descriptors)
     if constexpr (DMAW) {
-      if (nw == NWMAX) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NWMAX) : "memory");
-      else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NWMAX - 1) : "memory");
+      if (nw == NWMAX) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((1 + AH) * NWMAX) : "memory");
+      else asm volatile("s_waitcnt vmcnt(%0)" ::"n"((1 + AH) * (NWMAX - 1)) : "memory");
     }
     __syncthreads();
   };
@@ -816,14 +821,15 @@ __global__ __launch_bounds__(512) void conv_slide_dgrad_kernel(const CdArgs a) {
   cs_dma_wait();  // (zero-record DMA issued for planes past the end must not outlive the workgroup)
 }
 
-template <int KX, int KY, int NT>
+template <int KX, int KY, int NT, int AH>
 int launch_slide_dgrad(CdArgs& a, hipStream_t st) {
-  using G = CdGeom<KX, KY, NT>;
+  using G = CdGeom<KX, KY, NT, AH>;
   static_assert(G::LDS_B <= 160 * 1024, "rings + staging exceed the LDS");
   static_assert(G::DY_NP >= 64 && G::M_NP >= 64, "plane smaller than one DMA unit");
   static_assert((G::NU + 3) / 4 <= 6, "the counted DMA wait covers at most six instructions per plane and wave");
-  static_assert(KX + 2 <= G::RD, "dy ring too short");
-  auto kern = conv_slide_dgrad_kernel<KX, KY, NT>;
+  static_assert(KX + 2 + AH <= G::RD, "dy ring too short");
+  static_assert((1 + AH) * ((G::NU + 3) / 4) < 64, "vmcnt is a 6-bit counter");
+  auto kern = conv_slide_dgrad_kernel<KX, KY, NT, AH>;
   static bool attr_done = false;
   if (!attr_done) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -867,7 +873,8 @@ int wsr_conv_slide_dgrad(const unsigned short* dy, int dy_ctot, int dy_off, int 
   a.dy_ctot = dy_ctot; a.dy_off = dy_off; a.dx_ctot = dx_ctot; a.dx_off = dx_off;
   a.mask_ctot = mask->y_ctot; a.mask_off = mask->y_off;
   a.px = px; a.py = py; a.alpha = alpha; a.slope = mask->slope;
-  if (KX == 5 && KY == 5 && C == 144) return launch_slide_dgrad<5, 5, 9>(a, st);
+  if (KX == 5 && KY == 5 && C == 144)
+    return WSR_ENV_INT("WSR_CS_AH", 0) ? launch_slide_dgrad<5, 5, 9, 1>(a, st) : launch_slide_dgrad<5, 5, 9, 0>(a, st);
   // (other filter extents - no shipped configuration has them - stay on the halo-tile kernel)
   return WSR_EUNSUPPORTED;
 }
