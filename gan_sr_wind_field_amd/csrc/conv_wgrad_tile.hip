@@ -258,6 +258,12 @@ __global__ __launch_bounds__(512) void wgrad_tile_kernel(const WgtArgs a) {
 #pragma unroll
       for (int k = 0; k < XK; ++k) {
         const int u = wave + WAVES * k;
+#ifdef WSR_CT_STAMPS
+        // (tuning build, ablate & 64 / & 128: every second / three of four x-image units are not fetched - the timing of a
+        // launch whose halo image costs half / a quarter of the DMA, e.g. x-planes shared between neighbouring tiles)
+        if ((a.ablate & 64) && (k & 1)) continue;
+        if ((a.ablate & 128) && (k & 3)) continue;
+#endif
         if (u < XU) {
           const unsigned geo = xgeo[k];
           bool ok = (geo >> 24) & 1;
