@@ -728,6 +728,19 @@ int run_tile(WgtArgs& a, int taps, int Cout, int Cin, hipStream_t st) {
     const int rc = launch_tile<4, 6, 4>(a, st);
     if (rc != WSR_EUNSUPPORTED) return rc;
   }
+  const bool small = a.tri_step == 0 && !WSR_ENV_SET("WSR_WG_NOSMALL");
+  // ... with at most 32 output channels (the parity launches of the discriminator's first strided conv, 32 -> 32): 3 slots
+  // per wave = 12 taps x 2 c-tiles exactly - on <2,7,2> four of a wave's seven slots were padding
+  if (small && taps <= 12 && c->Cout > 16 && c->Cout <= 32) {
+    const int rc = launch_tile<2, 3, 2>(a, st);
+    if (rc != WSR_EUNSUPPORTED) return rc;
+  }
+  // one 16-channel c-tile, at most 32 output channels (terrain convs 16 -> 16, the discriminator's first conv 3 -> 32):
+  // 4 slots per wave = 32 taps x 1 c-tile - the 32-channel chunk of <.,7,2> was half (or three quarters) zeros
+  if (small && c->Cin <= 16 && c->Cout <= 32) {
+    const int rc = c->Cout <= 16 ? launch_tile<1, 4, 1>(a, st) : launch_tile<2, 4, 1>(a, st);
+    if (rc != WSR_EUNSUPPORTED) return rc;
+  }
   // one 16-channel c-tile against many output channels (the z-folded last conv's gradient with its operands' roles
   // exchanged, engine.py SWAP_THIN_WGRAD: 16 -> 144, 5x5x1): 4 slots per wave = 32 taps x 1 c-tile, 48 output channels
   // per workgroup - the generic choice below would pad the c-chunk to 32 channels and the n-chunk to 64 (37 % useful MFMAs)

@@ -612,6 +612,10 @@ def _cpu_wgrad(x, gy, k, p):
     # three n-chunks of 48, flat 8x8x4 tiles; and the instantiation on 3x3x3 taps with a ragged volume
     ("hr1z_T", 16, 144, (5, 5, 1), (16, 8, 16), 1, False),
     ("thin_T_k3", 8, 48, (3, 3, 3), (5, 9, 10), 2, False),
+    # one c-tile, few output channels: <1,4,1> (terrain 16 -> 16), <2,4,1> (discriminator 3 -> 32, channels padded to 8)
+    ("terrain1_like", 16, 16, (3, 3, 3), (8, 8, 16), 1, False),
+    ("d0_like", 8, 32, (3, 3, 3), (6, 10, 16), 2, False),
+    ("d0_ragged", 8, 24, (3, 3, 3), (5, 7, 9), 1, False),
 ])
 def test_wgrad_tile_kernel_bf16(hip, name, cin, cout, k, xyz, B, ups):
     """LDS-tile filter-gradient kernel (bf16) vs an fp32 CPU wgrad of the same rounded operands."""
