@@ -77,10 +77,80 @@ __global__ void unpack_wgrad_multi_kernel(const wsr_unpack_job_t* __restrict__ j
 // layout in one pass.  One workgroup per (job, output channel n, 64 input channels): the packed rows
 // [tap][c0 .. c0+63] of every part are read coalesced, summed, transposed through LDS and written as the
 // contiguous run dst[n][c0 .. c0+63][taps].
-__global__ __launch_bounds__(512) void unpack_reduce_multi_kernel(const wsr_unpack_job_t* __restrict__ jobs) {
-  __shared__ float sh[64][129];  // [c][tap], taps <= 128
+// sixteen / eight / four copies in flight per thread (the copies are megabytes apart: every load is an HBM round
+// trip), added in index order
+__device__ __forceinline__ float4 ur_sum_parts(const float* p, int nparts, long part_stride) {
+  float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+  int s = 0;
+  for (; s + 16 <= nparts; s += 16) {
+    float4 v[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) v[u] = *reinterpret_cast<const float4*>(p + (long)(s + u) * part_stride);
+#pragma unroll
+    for (int u = 0; u < 16; ++u) { a.x += v[u].x; a.y += v[u].y; a.z += v[u].z; a.w += v[u].w; }
+  }
+  if (s + 8 <= nparts) {
+    float4 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const float4*>(p + (long)(s + u) * part_stride);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) { a.x += v[u].x; a.y += v[u].y; a.z += v[u].z; a.w += v[u].w; }
+    s += 8;
+  }
+  if (s + 4 <= nparts) {
+    float4 v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const float4*>(p + (long)(s + u) * part_stride);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { a.x += v[u].x; a.y += v[u].y; a.z += v[u].z; a.w += v[u].w; }
+    s += 4;
+  }
+  for (; s < nparts; ++s) {
+    const float4 v = *reinterpret_cast<const float4*>(p + (long)s * part_stride);
+    a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+  }
+  return a;
+}
+
+constexpr int UR_SH = 12288;  // floats of LDS per workgroup (48 KB)
+
+__global__ __launch_bounds__(512) void unpack_reduce_multi_kernel(const wsr_unpack_job_t* __restrict__ jobs, int rows_ok) {
+  __shared__ float shf[UR_SH];
+  float (*sh)[129] = reinterpret_cast<float (*)[129]>(shf);  // chunk form: [c 64][tap], taps <= 128
   const wsr_unpack_job_t j = jobs[blockIdx.y];
   const int cchunks = (j.Cin + 63) / 64;
+  // Row form (round 4): one workgroup per output channel n takes the WHOLE packed row [tap][0 .. Cin) of every copy -
+  // runs of Cin * 4 bytes (the rows of consecutive taps touch when kpad = Cin) instead of the chunk form's 256-byte
+  // pieces, which held the pass at 2.5 TB/s - and turns it through LDS as [c][tap | 1].  Same additions in the same
+  // order: bit-identical results.  Jobs whose [Cin][taps] image does not fit 48 KB (the 5x5x5 conv) keep the chunk form.
+  {
+    const int tp = j.taps | 1;
+    const bool vec = (j.kpad & 3) == 0 && (j.part_stride & 3) == 0 && (((size_t)j.src) & 15) == 0;
+    if (rows_ok && vec && j.n_parts > 0 && (long)j.Cin * tp <= UR_SH) {
+      const int cq = (j.Cin + 3) >> 2;        // float4 pieces per tap (inside the row: kpad is a multiple of 4)
+      const int nq = j.taps * cq;
+      for (int n = blockIdx.x; n < j.Cout; n += gridDim.x) {
+        __syncthreads();
+        const float* base = j.src + (long)n * j.taps * j.kpad;
+        for (int q = threadIdx.x; q < nq; q += 512) {
+          const int tap = q / cq, c = (q - tap * cq) * 4;
+          const float4 a = ur_sum_parts(base + (long)tap * j.kpad + c, j.n_parts, j.part_stride);
+          shf[c * tp + tap] = a.x;
+          if (c + 1 < j.Cin) shf[(c + 1) * tp + tap] = a.y;
+          if (c + 2 < j.Cin) shf[(c + 2) * tp + tap] = a.z;
+          if (c + 3 < j.Cin) shf[(c + 3) * tp + tap] = a.w;
+        }
+        __syncthreads();
+        float* d = j.dst + (long)n * j.Cin * j.taps;
+        for (int idx = threadIdx.x; idx < j.Cin * j.taps; idx += 512) {
+          const int c = idx / j.taps, tap = idx - c * j.taps;
+          const float v = j.scale * shf[c * tp + tap];
+          d[idx] = j.accumulate ? d[idx] + v : v;
+        }
+      }
+      return;
+    }
+  }
   // 16 lanes x float4 = 64 channels, 32 taps at a time (a 3x3x3 filter: one pass); a thread's chain is
   // ceil(n_parts / 16) dependent round trips - at 8 in flight and 16 taps per pass the 64-copy jobs were latency-bound
   const int c4 = (threadIdx.x & 15) * 4, tl = threadIdx.x >> 4;
@@ -94,36 +164,7 @@ __global__ __launch_bounds__(512) void unpack_reduce_multi_kernel(const wsr_unpa
       const float* p = j.src + ((long)n * j.taps + tap) * j.kpad + c0 + c4;
       float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
       if (vec && c0 + c4 + 4 <= j.kpad) {  // (the row is kpad long: reading past Cin inside it is harmless)
-        // sixteen copies in flight per thread (the copies are megabytes apart: every load is an HBM round trip),
-        // added in index order
-        int s = 0;
-        for (; s + 16 <= nparts; s += 16) {
-          float4 v[16];
-#pragma unroll
-          for (int u = 0; u < 16; ++u) v[u] = *reinterpret_cast<const float4*>(p + (long)(s + u) * j.part_stride);
-#pragma unroll
-          for (int u = 0; u < 16; ++u) { a.x += v[u].x; a.y += v[u].y; a.z += v[u].z; a.w += v[u].w; }
-        }
-        if (s + 8 <= nparts) {
-          float4 v[8];
-#pragma unroll
-          for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const float4*>(p + (long)(s + u) * j.part_stride);
-#pragma unroll
-          for (int u = 0; u < 8; ++u) { a.x += v[u].x; a.y += v[u].y; a.z += v[u].z; a.w += v[u].w; }
-          s += 8;
-        }
-        if (s + 4 <= nparts) {
-          float4 v[4];
-#pragma unroll
-          for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const float4*>(p + (long)(s + u) * j.part_stride);
-#pragma unroll
-          for (int u = 0; u < 4; ++u) { a.x += v[u].x; a.y += v[u].y; a.z += v[u].z; a.w += v[u].w; }
-          s += 4;
-        }
-        for (; s < nparts; ++s) {
-          const float4 v = *reinterpret_cast<const float4*>(p + (long)s * j.part_stride);
-          a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
-        }
+        a = ur_sum_parts(p, nparts, j.part_stride);
       } else {
         for (int s = 0; s < nparts; ++s) {
           const float* q = p + (long)s * j.part_stride;
@@ -904,7 +945,8 @@ extern "C" int wsr_unpack_wgrad_reduce_multi(const wsr_unpack_job_t* jobs_dev, i
   if (!jobs_dev || n_jobs <= 0 || n_jobs > 65535) return WSR_EINVAL;
   int gx = WSR_ENV_INT("WSR_UNPACK_GRID", 128);  // (tuning aid: workgroups per job)
   gx = gx < 1 ? 1 : (gx > 1024 ? 1024 : gx);
-  hipLaunchKernelGGL(unpack_reduce_multi_kernel, dim3((unsigned)gx, (unsigned)n_jobs), dim3(512), 0, as_stream(stream), jobs_dev);
+  hipLaunchKernelGGL(unpack_reduce_multi_kernel, dim3((unsigned)gx, (unsigned)n_jobs), dim3(512), 0, as_stream(stream), jobs_dev,
+                     WSR_ENV_INT("WSR_UNPACK_ROWS", 1));
   WSR_LAUNCH_CHECK();
   return 0;
 }

@@ -1285,3 +1285,44 @@ def test_syncbn_shard_algebra_vs_float64(hip, world, G, C_):
     assert torch.equal(st[:, 2 * C_:3 * C_].cpu(), torch.zeros((G, C_)))
     np.testing.assert_allclose(st[:, 3 * C_:].cpu().double().numpy(), m2.numpy(), rtol=2e-5)
     assert torch.isnan(work[:, C_:]).all() and torch.isnan(st[:, :2 * C_]).all()  # nothing else is written
+
+
+@pytest.mark.gpu
+def test_ordered_reduce_row_form_is_bit_identical(hip, monkeypatch):
+    """wsr_unpack_wgrad_reduce_multi: the row form (one workgroup per output channel, whole packed rows of every
+    split copy) against the chunk form (64 input channels per workgroup, WSR_UNPACK_ROWS=0) - the same additions in
+    the same order, so the master-layout gradients are bit-identical, and equal to the plain ordered sum."""
+    from conftest import reload_wsr_env
+
+    o = ops()
+    gen = torch.Generator().manual_seed(11)
+    shapes = [  # (n_parts, Cout, taps, kpad, Cin, scale)
+        (21, 32, 27, 224, 160, 1.0),    # a growth conv of a stacked dense-block gradient (its window of the row)
+        (21, 32, 27, 224, 224, 1.0),
+        (32, 128, 1, 256, 256, 0.2),    # LFF
+        (85, 144, 25, 16, 16, 1.0),     # the z-folded last conv, roles exchanged
+        (9, 48, 125, 144, 144, 1.0),    # 5x5x5: the [Cin][taps] image does not fit the row form's LDS -> chunk form
+        (5, 8, 27, 8, 3, 1.0),          # 3 of 8 stored channels
+        (3, 16, 12, 20, 18, 0.5),       # channel tail inside a float4
+    ]
+    jobs, refs = [], []
+    for n, cout, taps, kpad, cin, scale in shapes:
+        parts = torch.randn((n, cout, taps, kpad), generator=gen).to(DEV)
+        dst = torch.full((cout, cin, taps), float("nan"), device=DEV)
+        jobs.append((parts[0], dst, scale, n, parts[0].numel()))
+        acc = torch.zeros((cout, taps, kpad), device=DEV)
+        for s_ in range(n):  # the kernel's order: ((0 + p0) + p1) + ...
+            acc = acc + parts[s_]
+        refs.append((scale * acc[:, :, :cin]).permute(0, 2, 1).contiguous())
+        jobs[-1] += (parts,)  # (keeps the copies alive)
+    outs = {}
+    for rows in ("0", "1"):
+        monkeypatch.setenv("WSR_UNPACK_ROWS", rows)
+        reload_wsr_env()
+        for j in jobs:
+            j[1].fill_(float("nan"))
+        o.unpack_wgrad_reduce_multi(o.unpack_job_table([j[:5] for j in jobs]))
+        outs[rows] = [j[1].clone() for j in jobs]
+    for a, b, r, sh in zip(outs["0"], outs["1"], refs, shapes):
+        assert torch.equal(a, b), sh
+        assert torch.equal(b, r), sh
