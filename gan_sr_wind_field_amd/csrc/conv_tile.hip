@@ -203,7 +203,7 @@ __device__ __forceinline__ PkGeom pk_geom(const wsr_pack_job_t j) {
   return g;
 }
 
-__global__ __launch_bounds__(256) void pack_frag_multi_kernel(const wsr_pack_job_t* __restrict__ jobs) {
+__global__ __launch_bounds__(256) void pack_frag_multi_kernel(const wsr_pack_job_t* __restrict__ jobs, int vec_on) {
   __shared__ float sh[512 * 17 > 256 * (PK_TRMAX + 1) ? 512 * 17 : 256 * (PK_TRMAX + 1)];
   const wsr_pack_job_t jrec = jobs[blockIdx.y];
   const PkGeom g = pk_geom(jrec);
@@ -226,6 +226,41 @@ __global__ __launch_bounds__(256) void pack_frag_multi_kernel(const wsr_pack_job
     const bool tap_ok = tx < TR && tap < taps;
     const long tap_src = j.transpose ? taps - 1 - tap : tap;
     __syncthreads();
+    // Round 4, 16-byte loads: the LDS rows in source order are O runs of R rows x taps floats, each run CONTIGUOUS in the
+    // master filter (forward: the CK reduction channels of one output channel; transposed: the 16 rows of one reduction
+    // channel) - read as float4 by 16 threads per run and kept in LDS as they are, [row][tap] without padding and without
+    // the tap flip (one 16-byte LDS write per load; scattered into the padded, flipped image of the one-float form the
+    // 4-byte writes' bank conflicts cost more than the loads saved); the fragment pass below indexes accordingly.  The
+    // one-float form moved 0.7 TB/s.  Needs all taps in one range and 16-byte aligned runs whose valid part is whole
+    // float4s (else: the one-float form, per item).
+    const int R = j.transpose ? 16 : CK, O = nrow / R;
+    const int inner0 = j.transpose ? nt * 16 : chunk * CK, inner_lim = j.transpose ? g.src_rows : g.src_red;
+    const int outer0 = j.transpose ? chunk * CK : nt * 16, outer_lim = j.transpose ? g.src_red : g.src_rows;
+    int vin = inner_lim - inner0;
+    vin = vin < 0 ? 0 : (vin > R ? R : vin);  // valid rows of a run
+    const bool vec = vec_on && g.ntr == 1 && taps > 1 && ((vin * taps) & 3) == 0 && (((long)j.Cin * taps) & 3) == 0 &&
+                     ((g.c_lo * taps) & 3) == 0 && (((size_t)w) & 15) == 0;
+    if (vec) {
+      const int q4 = (vin * taps) >> 2, rt4 = (R * taps) >> 2;  // float4s of a run: valid, whole (R is 8, 16 or 32)
+      for (int o = t >> 4; o < O; o += 16) {
+        const bool ook = outer0 + o < outer_lim;
+        const float* run = w + ((long)(outer0 + o) * j.Cin + g.c_lo + inner0) * taps;
+        for (int f0 = t & 15; f0 < rt4; f0 += 16 * 8) {
+          float4 v[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            const int f4 = f0 + 16 * u;
+            v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (ook && f4 < q4) v[u] = *reinterpret_cast<const float4*>(run + 4 * f4);
+          }
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            const int f4 = f0 + 16 * u;
+            if (f4 < rt4) *reinterpret_cast<float4*>(sh + (o * rt4 + f4) * 4) = v[u];
+          }
+        }
+      }
+    } else
     // (sixteen loads in flight per thread: left as a plain loop the compiler waits for every float before the next)
     for (int r0 = ty; r0 < nrow; r0 += RP * 16) {
       float v[16];
@@ -255,7 +290,8 @@ __global__ __launch_bounds__(256) void pack_frag_multi_kernel(const wsr_pack_job
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         const int r = j.transpose ? (clb + e) * 16 + i : (i << cks) + clb + e;
-        f[e] = sh[r * pitch + tt];
+        // (16-byte-load form: rows of `taps` floats in source tap order, nothing stored for the padded taps)
+        f[e] = !vec ? sh[r * pitch + tt] : (tt < taps ? sh[r * taps + (j.transpose ? taps - 1 - tt : tt)] : 0.f);
       }
       uint4 u;
       u.x = (unsigned)f2bf(f[0]) | ((unsigned)f2bf(f[1]) << 16);
@@ -319,7 +355,8 @@ extern "C" int wsr_pack_filter_frag_multi(const wsr_pack_job_t* jobs_dev, int32_
   // a discriminator's 43 jobs of up to 512 (measured: 16 / 32 / 128 workgroups per job win at 940 / 398 / 43 jobs)
   int gx = WSR_ENV_INT("WSR_PK_GRID", n_jobs >= 512 ? 16 : (n_jobs >= 128 ? 32 : 128));
   gx = gx < 1 ? 1 : (gx > 1024 ? 1024 : gx);
-  hipLaunchKernelGGL(pack_frag_multi_kernel, dim3((unsigned)gx, (unsigned)n_jobs), dim3(256), 0, as_stream(stream), jobs_dev);
+  hipLaunchKernelGGL(pack_frag_multi_kernel, dim3((unsigned)gx, (unsigned)n_jobs), dim3(256), 0, as_stream(stream), jobs_dev,
+                     WSR_ENV_INT("WSR_PK_VEC", 1));
   WSR_LAUNCH_CHECK();
   return 0;
 }
