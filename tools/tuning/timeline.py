@@ -12,7 +12,7 @@ seq = rows[idx[-1]:] if idx else rows
 t0 = int(seq[0]["Start_Timestamp"])
 tot, prev = 0, None
 for r in seq:
-    n = r["Kernel_Name"].replace("void (anonymous namespace)::", "").replace("void ", "").split("(")[0][:70]
+    n = r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0][:70]
     s, e = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
     gap = (s - prev) / 1e3 if prev else 0.0
     prev = e
