@@ -20,6 +20,7 @@ from __future__ import annotations
 
 import copy
 import math
+import os
 
 import numpy as np
 import torch
@@ -103,12 +104,17 @@ class wind_field_GAN_3D(BaseGAN):
         # time per step than the foreach default).  It updates parameters without bumping their version
         # counters, so the programs' packed-filter caches are invalidated from a post-step hook.
         fused = {"fused": True} if torch.device(self.device).type == "cuda" else {}
-        self.optimizer_G = torch.optim.Adam(self.G.parameters(), lr=cfg_t.learning_rate_g,
-                                            weight_decay=cfg_t.adam_weight_decay_g,
-                                            betas=(cfg_t.adam_beta1_g, 0.999), **fused)
-        self.optimizer_D = torch.optim.Adam(self.D.parameters(), lr=cfg_t.learning_rate_d,
-                                            weight_decay=cfg_t.adam_weight_decay_d,
-                                            betas=(cfg_t.adam_beta1_d, 0.999), **fused)
+        # (round 4: the same optimizer with its step as ONE launch over a device table of tensor chunks - torch's fused
+        # form needs 8 + 1 launches of ~78 workgroups for the generator's 297 tensors; WSR_TABLE_ADAM=0 restores it)
+        Adam = torch.optim.Adam
+        if fused and os.environ.get("WSR_TABLE_ADAM", "1") != "0":
+            from ..tools.table_adam import TableAdam as Adam
+        self.optimizer_G = Adam(self.G.parameters(), lr=cfg_t.learning_rate_g,
+                                weight_decay=cfg_t.adam_weight_decay_g,
+                                betas=(cfg_t.adam_beta1_g, 0.999), **fused)
+        self.optimizer_D = Adam(self.D.parameters(), lr=cfg_t.learning_rate_d,
+                                weight_decay=cfg_t.adam_weight_decay_d,
+                                betas=(cfg_t.adam_beta1_d, 0.999), **fused)
         if fused:
             self.optimizer_G.register_step_post_hook(lambda *_: self.G.program().filters.invalidate())
             self.optimizer_D.register_step_post_hook(lambda *_: self.D.features.program().filters.invalidate())

@@ -21,7 +21,7 @@ EXPORTS = [
     "wsr_frag_filter_elems", "wsr_pack_filter_frag", "wsr_pack_filter_frag_multi",
     "wsr_pack_filter", "wsr_unpack_wgrad", "wsr_unpack_wgrad_multi", "wsr_lrelu_bwd_inplace", "wsr_chan_axpby", "wsr_chan_sum", "wsr_chan_sum_rows", "wsr_chan_sum_partials", "wsr_upsample2_bwd", "wsr_subpixel_fold", "wsr_subpixel_unfold", "wsr_strided_parity_filters", "wsr_strided_parity_unfold",
     "wsr_planar_to_ndhwc", "wsr_ndhwc_to_planar", "wsr_zfold", "wsr_zunfold", "wsr_wind_gradient", "wsr_wind_gradient_bwd", "wsr_plane_sum", "wsr_linear_rows", "wsr_physics_loss_workspace_floats", "wsr_physics_loss_stats", "wsr_physics_loss_bwd", "wsr_bn_stats", "wsr_bn_mean", "wsr_bn_shard_stats", "wsr_bn_combine_shards", "wsr_bn_finalize", "wsr_bn_apply_lrelu", "wsr_bn_bwd_reduce",
-    "wsr_bn_bwd_apply", "wsr_adam_step",
+    "wsr_bn_bwd_apply", "wsr_adam_step", "wsr_adam_multi",
 ]
 
 
@@ -130,6 +130,7 @@ def lib() -> C.CDLL:
         "wsr_bn_bwd_reduce": [vp, vp, vp, vp, vp, i32, i64, i32, f32, vp, vp, i32, vp],
         "wsr_bn_bwd_apply": [vp, vp, vp, vp, vp, vp, vp, f32, vp, f32, i32, i64, i32, vp],
         "wsr_adam_step": [vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, i32, vp],
+        "wsr_adam_multi": [vp, i32, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, i32, vp],
     }
     for name, argtypes in sig.items():
         fn = getattr(L, name)
@@ -139,7 +140,7 @@ def lib() -> C.CDLL:
     L.wsr_frag_filter_elems.restype = C.c_int64
     L.wsr_physics_loss_workspace_floats.argtypes = []
     L.wsr_physics_loss_workspace_floats.restype = C.c_int64
-    if L.wsr_abi_version() != 6:
+    if L.wsr_abi_version() != 7:
         raise RuntimeError("libwindsr_hip.so ABI version mismatch")
     _lib = L
     return L

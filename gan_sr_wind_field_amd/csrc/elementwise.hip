@@ -590,6 +590,45 @@ __global__ void adam_kernel(float* p, const float* __restrict__ g, float* m, flo
   }
 }
 
+// one workgroup per job (a chunk of one tensor); the arithmetic of adam_kernel, element for element
+struct AdamK { float step_size, beta1, omb1, beta2, omb2, eps, wd, bc2_sqrt; };
+__device__ __forceinline__ void adam_one(float& p, float g, float& m, float& v, const AdamK& k) {
+  if (k.wd != 0.f) g += k.wd * p;
+  m = k.beta1 * m + k.omb1 * g;
+  v = k.beta2 * v + k.omb2 * g * g;
+  const float denom = sqrtf(v) / k.bc2_sqrt + k.eps;
+  p = p - k.step_size * (m / denom);
+}
+
+__global__ __launch_bounds__(256) void adam_multi_kernel(const wsr_adam_job_t* __restrict__ jobs, const AdamK k) {
+  const wsr_adam_job_t j = jobs[blockIdx.x];
+  const long n = j.n;
+  const bool vec = ((((size_t)j.p) | ((size_t)j.g) | ((size_t)j.m) | ((size_t)j.v)) & 15) == 0;
+  long done = 0;
+  if (vec) {
+    const long n4 = n >> 2;
+    float4* p4 = reinterpret_cast<float4*>(j.p);
+    const float4* g4 = reinterpret_cast<const float4*>(j.g);
+    float4* m4 = reinterpret_cast<float4*>(j.m);
+    float4* v4 = reinterpret_cast<float4*>(j.v);
+    for (long i = threadIdx.x; i < n4; i += 256) {
+      float4 p = p4[i], m = m4[i], v = v4[i];
+      const float4 g = g4[i];
+      adam_one(p.x, g.x, m.x, v.x, k);
+      adam_one(p.y, g.y, m.y, v.y, k);
+      adam_one(p.z, g.z, m.z, v.z, k);
+      adam_one(p.w, g.w, m.w, v.w, k);
+      p4[i] = p; m4[i] = m; v4[i] = v;
+    }
+    done = n4 << 2;
+  }
+  for (long i = done + threadIdx.x; i < n; i += 256) {
+    float p = j.p[i], m = j.m[i], v = j.v[i];
+    adam_one(p, j.g[i], m, v, k);
+    j.p[i] = p; j.m[i] = m; j.v[i] = v;
+  }
+}
+
 
 // per-channel sum over voxels of an NDHWC window, pass 1: thread = (voxel lane, 4-channel group); the
 // workgroup's partial sums go to row blockIdx.x of `part` (no atomics: C addresses would serialise them)
@@ -1219,6 +1258,21 @@ extern "C" int wsr_adam_step(float* p, const float* g, float* m, float* v, int64
   const double bc2 = 1.0 - pow((double)beta2, (double)step);
   hipLaunchKernelGGL(adam_kernel, dim3(ew_grid(n)), dim3(EW_BLOCK), 0, as_stream(stream), p, g, m, v, (long)n,
                      (float)(lr / bc1), beta1, beta2, eps, weight_decay, (float)sqrt(bc2));
+  WSR_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int wsr_adam_multi(const wsr_adam_job_t* jobs_dev, int32_t n_jobs, double lr, double beta1, double beta2, double eps,
+                              double weight_decay, int32_t step, void* stream) {
+  if (!jobs_dev || n_jobs <= 0 || step < 1) return WSR_EINVAL;
+  const double bc1 = 1.0 - pow(beta1, (double)step);
+  const double bc2 = 1.0 - pow(beta2, (double)step);
+  AdamK k;
+  k.step_size = (float)(lr / bc1);
+  k.beta1 = (float)beta1; k.omb1 = (float)(1.0 - beta1);
+  k.beta2 = (float)beta2; k.omb2 = (float)(1.0 - beta2);
+  k.eps = (float)eps; k.wd = (float)weight_decay; k.bc2_sqrt = (float)sqrt(bc2);
+  hipLaunchKernelGGL(adam_multi_kernel, dim3((unsigned)n_jobs), dim3(256), 0, as_stream(stream), jobs_dev, k);
   WSR_LAUNCH_CHECK();
   return 0;
 }

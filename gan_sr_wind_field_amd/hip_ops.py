@@ -810,3 +810,31 @@ def adam_step(p: Tensor, g: Tensor, m: Tensor, v: Tensor, lr: float, beta1: floa
             raise ValueError("adam_step wants flat contiguous fp32 buffers")
     check(_lib.lib().wsr_adam_step(_p(p), _p(g), _p(m), _p(v), p.numel(), lr, beta1, beta2, eps, weight_decay, step,
                                    _stream()), "adam_step")
+
+
+ADAM_CHUNK = 32768  # elements per job of wsr_adam_multi (one workgroup each)
+
+
+def adam_job_table(tensors) -> Tensor:
+    """Device table of ``wsr_adam_job_t`` records for ``tensors`` = [(param, grad, exp_avg, exp_avg_sq)] (contiguous fp32,
+    one device), large tensors cut into chunks of :data:`ADAM_CHUNK` elements."""
+    import numpy as np
+
+    rows = []
+    for quad in tensors:
+        n = quad[0].numel()
+        for t in quad:
+            if t.dtype != torch.float32 or not t.is_contiguous() or t.numel() != n or t.device != quad[0].device:
+                raise ValueError("adam_job_table wants contiguous fp32 tensors of one size on one device")
+        ptrs = [t.data_ptr() for t in quad]
+        for off in range(0, n, ADAM_CHUNK):
+            rows.append([q + 4 * off for q in ptrs] + [min(ADAM_CHUNK, n - off)])
+    rec = np.asarray(rows, dtype=np.int64).reshape(-1, 5)
+    return _table_to_device(rec, tensors[0][0].device)
+
+
+def adam_multi(table: Tensor, lr: float, beta1: float, beta2: float, eps: float, weight_decay: float, step: int) -> None:
+    """torch.optim.Adam's update of every tensor in ``table`` (:func:`adam_job_table`) in ONE launch; ``step`` >= 1 is the
+    step count after this update (shared by all tensors, as in one param group)."""
+    check(_lib.lib().wsr_adam_multi(_p(table), table.shape[0], lr, beta1, beta2, eps, weight_decay, step, _stream()),
+          "adam_multi")

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define WSR_ABI_VERSION 6
+#define WSR_ABI_VERSION 7
 
 enum wsr_dtype { WSR_F32 = 0, WSR_BF16 = 1 };
 
@@ -420,6 +420,21 @@ int wsr_bn_bwd_apply(const void* g, const void* x, void* dx, const float* mean, 
  * (wind_field_GAN_3D.py:151-162,460,566), bias-corrected, L2 weight decay.     */
 int wsr_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
                   float beta2, float eps, float weight_decay, int32_t step, void* stream);
+/* ABI 7 - the same update for MANY tensors in one launch (an optimizer's whole parameter list:
+ * wind_field_GAN_3D.py:460 `optimizer_G.step()`, :566 `optimizer_D.step()`): `jobs_dev` is a DEVICE array of n_jobs
+ * records, one workgroup each - the caller cuts large tensors into chunks (32 768 elements is a good size).  All
+ * tensors of a call share the hyper-parameters and the step count, as the parameters of one param group do.     */
+typedef struct wsr_adam_job {
+  float* p;       /* parameter chunk, updated in place */
+  const float* g; /* its gradient                      */
+  float* m;       /* exp_avg                           */
+  float* v;       /* exp_avg_sq                        */
+  int64_t n;      /* elements                          */
+} wsr_adam_job_t;
+/* (hyper-parameters as doubles, the way torch.optim.Adam holds them: 1 - beta is taken in double and rounded once, so
+ *  exp_avg / exp_avg_sq follow torch's to the last bits instead of to 1e-5)                                           */
+int wsr_adam_multi(const wsr_adam_job_t* jobs_dev, int32_t n_jobs, double lr, double beta1, double beta2, double eps,
+                   double weight_decay, int32_t step, void* stream);
 
 #ifdef __cplusplus
 }

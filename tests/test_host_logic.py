@@ -83,7 +83,7 @@ def test_abi_library_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(lib, name), f"{name} declared in windsr_hip.h but not exported"
     assert set(_lib.EXPORTS) == declared
-    assert _lib.lib().wsr_abi_version() == 6
+    assert _lib.lib().wsr_abi_version() == 7
     assert b"invalid" in _lib.lib().wsr_error_string(-1)
 
 
@@ -240,3 +240,20 @@ def test_graft_entry_build_compiles_and_checks_the_library():
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     mod.build()
+
+
+def test_table_adam_on_cpu_is_torch_adam():
+    """TableAdam away from the HIP path (CPU tensors) is torch.optim.Adam: same updates, same state_dict keys."""
+    from gan_sr_wind_field_amd.tools.table_adam import TableAdam
+
+    torch.manual_seed(0)
+    a = [torch.randn(7, 3, requires_grad=True)]
+    b = [a[0].detach().clone().requires_grad_(True)]
+    oa, ob = TableAdam(a, lr=1e-3, fused=False), torch.optim.Adam(b, lr=1e-3)
+    for _ in range(3):
+        g = torch.randn(7, 3)
+        a[0].grad, b[0].grad = g.clone(), g.clone()
+        oa.step()
+        ob.step()
+    assert torch.equal(a[0], b[0])
+    assert set(oa.state_dict()["state"][0]) == set(ob.state_dict()["state"][0])
