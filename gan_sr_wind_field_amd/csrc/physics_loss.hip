@@ -142,6 +142,10 @@ __global__ __launch_bounds__(PL_BLOCK) void physics_residual_kernel(const float*
                                                                    float* __restrict__ res, int B, int X, int Y, int Z) {
   const long plane = (long)Y * Z, vol = (long)X * plane, total = (long)B * vol;
   const float g0 = 2.f * coef[0], g1 = 2.f * coef[1], g2 = 2.f * coef[2], g3 = 2.f * coef[3];
+  // A coefficient that is EXACTLY zero means the term is not in the loss (the reference drops the four physics terms
+  // from the total when one of them is not finite, wind_field_GAN_3D.py:434-445: autograd then never visits them) - it
+  // must not turn a non-finite Jacobian entry into 0 * inf = NaN in the generator's gradient.
+  const bool on0 = g0 != 0.f, on1 = g1 != 0.f, on2 = g2 != 0.f, on3 = g3 != 0.f;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     const int z = (int)(i % Z);
     long r = i / Z;
@@ -155,11 +159,12 @@ __global__ __launch_bounds__(PL_BLOCK) void physics_residual_kernel(const float*
     const Jac js = jacobian(sr + b * 3 * vol + sp, vol, plane, Z, x, y, z, X, Y, wx, wy, wz);
     float o[9];
 #pragma unroll
-    for (int c = 0; c < 9; ++c) o[c] = (c < 6 ? g0 : g1) * (js.j[c] - jh.j[c]);
+    for (int c = 0; c < 9; ++c) o[c] = (c < 6 ? on0 : on1) ? (c < 6 ? g0 : g1) * (js.j[c] - jh.j[c]) : 0.f;
     const float d2 = (js.j[0] + js.j[4]) - (jh.j[0] + jh.j[4]);
     const float d3 = d2 + (js.j[8] - jh.j[8]);
-    const float t = g2 * d3 + g3 * d2;
-    o[0] += t; o[4] += t; o[8] += g2 * d3;
+    const float t3 = on2 ? g2 * d3 : 0.f;
+    const float t = t3 + (on3 ? g3 * d2 : 0.f);
+    o[0] += t; o[4] += t; o[8] += t3;
     float* rp = res + b * 9 * vol + sp;
 #pragma unroll
     for (int c = 0; c < 9; ++c) rp[(long)c * vol] = o[c];
@@ -174,6 +179,9 @@ __global__ __launch_bounds__(PL_BLOCK) void physics_adjoint_kernel(const float* 
                                                                   int B, int X, int Y, int Z) {
   const long plane = (long)Y * Z, vol = (long)X * plane, total = (long)B * 3 * vol;
   const float c1 = coef[4], c2 = 2.f * coef[5];
+  // (no physics term in the loss: the residuals are zeros, and the stencil weights - 1 / dz of two equal levels - must not
+  // meet them)
+  const bool phys = coef[0] != 0.f || coef[1] != 0.f || coef[2] != 0.f || coef[3] != 0.f;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     const int z = (int)(i % Z);
     long r = i / Z;
@@ -183,6 +191,7 @@ __global__ __launch_bounds__(PL_BLOCK) void physics_adjoint_kernel(const float* 
     const long b = r / 3;
     const long gb = ((b * 9) * vol) + (long)x * plane + (long)y * Z + z;
     float acc = 0.f;
+    if (phys) {
     {
       const float* gp = res + gb + (long)(0 + c) * vol;
       const Lin co{xs, 1};
@@ -204,8 +213,9 @@ __global__ __launch_bounds__(PL_BLOCK) void physics_adjoint_kernel(const float* 
       if (z > 0) acc += deriv_row(co, z - 1, Z).c * gp[-1];
       if (z < Z - 1) acc += deriv_row(co, z + 1, Z).a * gp[1];
     }
+    }
     const float d = sr[i] - hr[i];
-    acc += c1 * (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f)) + c2 * d;
+    acc += (c1 != 0.f ? c1 * (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f)) : 0.f) + (c2 != 0.f ? c2 * d : 0.f);
     dsr[i] = acc;
   }
 }

@@ -336,3 +336,65 @@ def test_gan_train_step_trace_bf16_vs_reference(golden, hip):
         if k.startswith("final_D."):  # (running statistics of bf16-stored activations: 2e-2)
             assert rel_l2(gan.D.state_dict()[k[8:]], T(g[k])) < (2e-2 if "running_" in k else 2e-3), k
     _report("trace_bf16", rep)
+
+
+@pytest.mark.parametrize("case", ["plain", "physics_nonfinite", "total_nonfinite", "sr_normaliser"])
+def test_generator_iteration_guards_vs_oracle(hip, case):
+    """The reference's non-finite guards of a generator iteration (wind_field_GAN_3D.py:434-460) on the HIP path, fp32,
+    against the oracle on the same batch and weights:
+
+    * ``physics_nonfinite`` - two equal z levels in Z: the terrain-following derivative divides by zero, the four physics
+      terms are dropped from the total and the step runs on adversarial + pixel loss alone;
+    * ``total_nonfinite`` - an infinite HR value: the total is not finite, backward still runs, the Adam step is skipped
+      (weights and optimizer state untouched);
+    * ``sr_normaliser`` - a generator whose output is far more than 100 x HR: the gradient normalisers come from SR and
+      the reference differentiates through their maxima (the fused loss kernels hand over to the composed ops).
+
+    Loss entries (finite ones rtol 1e-3, the others by class), gradients of three generator tensors, and whether the
+    step was taken."""
+    gs = onets.GSpec(in_channels=4, nf=16, n_rrdb=1, gc=8, tf=8, hr_kern=5, upscale=4)
+    ds = onets.DSpec(bf=8, nz=4, enable_slicing=True)
+    sdG = onets.deterministic_state(onets.g_param_shapes(gs), seed=41, scale=0.5)
+    sdD = onets.deterministic_state(onets.d_param_shapes(ds), seed=43, scale=1.0)
+    LR, HR, Z, x, y = ogan.synthetic_batch(2, 16, 4, 4, seed=2001)
+    if case == "physics_nonfinite":
+        Z[..., 2] = Z[..., 1]
+    elif case == "total_nonfinite":
+        HR[0, 1, 3, 4, 1] = float("inf")
+    elif case == "sr_normaliser":
+        sdG["hr_convs.2.weight"] = sdG["hr_convs.2.weight"] * 3e4
+    gan, cfg = _gan("fp32", generator__num_features=16, generator__num_RRDB=1, generator__RDB_growth_chan=8,
+                    generator__terrain_number_of_features=8, discriminator__num_features=8,
+                    gan_config__number_of_z_layers=4, training__d_g_train_period=1)
+    gan.G.load_state_dict(sdG)
+    gan.D.load_state_dict(sdD)
+    gan.feed_xy_niter(x.to(DEV), y.to(DEV), torch.tensor(cfg.training.niter, device=DEV), 1, 1)
+    w0 = {k: v.detach().clone() for k, v in gan.G.state_dict().items()}
+    it = 2  # (period 1: even iterations are generator iterations)
+    gan.optimize_parameters(LR.to(DEV), HR.to(DEV), Z.to(DEV), it)
+
+    ref = ogan.OracleGAN({k: v.clone() for k, v in sdG.items()}, {k: v.clone() for k, v in sdD.items()}, gs, ds,
+                         ogan.TrainSpec(use_instance_noise=False, d_g_train_period=1))
+    ref.feed_xy(x, y)
+    assert ref.optimize_parameters(LR, HR, Z, it) == "G"
+
+    got = {k: float(gan.get_G_train_loss_dict_ref()[k].detach()) for k in LOSS_KEYS}
+    want = {k: float(ref.G_losses[k]) for k in LOSS_KEYS}
+    for k in LOSS_KEYS:
+        if np.isfinite(want[k]):
+            assert got[k] == pytest.approx(want[k], rel=1e-3, abs=1e-7), (case, k, got, want)
+        else:
+            assert not np.isfinite(got[k]), (case, k, got, want)
+    if case == "physics_nonfinite":
+        assert not all(np.isfinite(want[k]) for k in ("z_gradient", "divergence")) and np.isfinite(want["total"])
+    stepped = bool(np.isfinite(want["total"]))
+    assert stepped == (case != "total_nonfinite")
+    names = dict(gan.G.named_parameters())
+    for k in ("model.0.0.weight", "hr_convs.2.weight", "model.1.module.0.RDBs.1.LFF.bias"):
+        if stepped:  # the gradients that drove the step
+            assert rel_l2(names[k].grad.cpu(), ref.sdG[k].grad) < 2e-3, (case, k)
+            assert not torch.equal(names[k].detach(), w0[k])
+        else:
+            assert torch.equal(names[k].detach(), w0[k]), (case, k)
+    st = gan.optimizer_G.state_dict()["state"]
+    assert (len(st) > 0 and float(st[0]["step"]) == 1.0) if stepped else all(float(s["step"]) == 0.0 for s in st.values())
