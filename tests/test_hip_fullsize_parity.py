@@ -398,3 +398,43 @@ def test_generator_iteration_guards_vs_oracle(hip, case):
             assert torch.equal(names[k].detach(), w0[k]), (case, k)
     st = gan.optimizer_G.state_dict()["state"]
     assert (len(st) > 0 and float(st[0]["step"]) == 1.0) if stepped else all(float(s["step"]) == 0.0 for s in st.values())
+
+
+@pytest.mark.parametrize("gan_type,pix", [("relativistic", "l2"), ("relativisticavg", "l2"), ("relativistic", "l1")])
+def test_loss_variants_vs_oracle(hip, gan_type, pix):
+    """The configuration branches the shipped ini does not take - ``gan_type = relativistic`` (reference
+    wind_field_GAN_3D.py:358-359, 545-547: no batch means in the adversarial terms) and ``pixel_criterion = l2`` (the
+    squared-error sum of the fused content-loss pass) - one discriminator and one generator iteration in fp32 against
+    the oracle: loss entries rtol 1e-3, gradients of three tensors of each network."""
+    gs = onets.GSpec(in_channels=4, nf=16, n_rrdb=1, gc=8, tf=8, hr_kern=5, upscale=4)
+    ds = onets.DSpec(bf=8, nz=4, enable_slicing=True)
+    sdG = onets.deterministic_state(onets.g_param_shapes(gs), seed=41, scale=0.5)
+    sdD = onets.deterministic_state(onets.d_param_shapes(ds), seed=43, scale=1.0)
+    LR, HR, Z, x, y = ogan.synthetic_batch(2, 16, 4, 4, seed=2001)
+    gan, cfg = _gan("fp32", generator__num_features=16, generator__num_RRDB=1, generator__RDB_growth_chan=8,
+                    generator__terrain_number_of_features=8, discriminator__num_features=8,
+                    gan_config__number_of_z_layers=4, training__d_g_train_period=1, training__gan_type=gan_type,
+                    training__pixel_criterion=pix)
+    gan.G.load_state_dict(sdG)
+    gan.D.load_state_dict(sdD)
+    gan.feed_xy_niter(x.to(DEV), y.to(DEV), torch.tensor(cfg.training.niter, device=DEV), 1, 1)
+    ref = ogan.OracleGAN({k: v.clone() for k, v in sdG.items()}, {k: v.clone() for k, v in sdD.items()}, gs, ds,
+                         ogan.TrainSpec(use_instance_noise=False, d_g_train_period=1, gan_type=gan_type, pixel_criterion=pix))
+    ref.feed_xy(x, y)
+    dev = [t.to(DEV) for t in (LR, HR, Z)]
+    for it in (1, 2):
+        gan.optimize_parameters(*dev, it)
+        kind = ref.optimize_parameters(LR, HR, Z, it)
+        if kind == "D":
+            assert float(gan.get_D_loss_dict_ref()["train_loss"].detach()) == pytest.approx(float(ref.D_loss), rel=1e-3)
+            names = dict(gan.D.named_parameters())
+            for k in ("features.0.0.0.weight", "features.1.1.0.weight", "classifier.2.weight"):
+                # (train-mode BatchNorm at batch 2 amplifies fp32 rounding: the bound of the other fp32 D tests)
+                assert rel_l2(names[k].grad.cpu(), ref.sdD[k].grad) < 2.5e-2, (it, k)
+        else:
+            for k in LOSS_KEYS:
+                assert float(gan.get_G_train_loss_dict_ref()[k].detach()) == pytest.approx(float(ref.G_losses[k]), rel=1e-3,
+                                                                                          abs=1e-7), (it, k)
+            names = dict(gan.G.named_parameters())
+            for k in ("model.0.0.weight", "hr_convs.2.weight", "model.1.module.0.RDBs.1.LFF.bias"):
+                assert rel_l2(names[k].grad.cpu(), ref.sdG[k].grad) < 2e-3, (it, k)
