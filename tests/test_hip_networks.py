@@ -821,3 +821,53 @@ def test_full_size_c3_discriminator_properties(hip, monkeypatch):
     D(xg).sum().backward()
     assert torch.isfinite(xg.grad).all() and float(xg.grad.abs().sum()) > 0
     assert all(torch.isfinite(p.grad).all() for p in D.parameters())
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16], ids=["fp32", "bf16"])
+@pytest.mark.parametrize("variant", ["lff3", "convs3", "hr3", "relu", "scales"])
+def test_generator_constructor_variants_vs_oracle(hip, dt, variant):
+    """Constructor arguments of Generator_3D the shipped configurations leave at their values (reference
+    Generator_3D_Resnet_ESRGAN.py:24-46, torch_blocks.py:270-330): a 3x3x3 local-feature-fusion conv
+    (``lff_kern_size=3``), three growth convs per dense block, a 3x3x3 HR conv pair, ReLU (``act_type='relu'``: slope 0)
+    and other residual scalings - forward and all parameter gradients against the oracle's functional generator.
+    fp32: 2e-5 / 2e-4 as for the shipped shapes; bf16: the storage format's distance (5e-2 outputs, per-tensor bounds
+    from the oracle's bf16-storage emulation for the gradients)."""
+    from gan_sr_wind_field_amd.CNN_models.Generator_3D_Resnet_ESRGAN import Generator_3D
+
+    kw = dict(upscale=4, in_channels=4, out_channels=3, nf=16, n_rrdb=1, hr_kern=5, gc=8, tf=8, n_rdb_convs=5)
+    kw.update({"lff3": dict(lff_kern=3), "convs3": dict(n_rdb_convs=3), "hr3": dict(hr_kern=3), "relu": dict(slope=0.0),
+               "scales": dict(rdb_scale=0.5, rrdb_scale=1.0)}[variant])
+    spec = onets.GSpec(**kw)
+    G = Generator_3D(spec.in_channels, spec.out_channels, spec.nf, spec.n_rrdb, upscale=spec.upscale,
+                     hr_kern_size=spec.hr_kern, number_of_RDB_convs=spec.n_rdb_convs, RDB_gc=spec.gc,
+                     lff_kern_size=spec.lff_kern, RDB_residual_scaling=spec.rdb_scale,
+                     RRDB_residual_scaling=spec.rrdb_scale, act_type="relu" if spec.slope == 0.0 else "leakyrelu",
+                     terrain_number_of_features=spec.tf, dropout_probability=0.0, use_mixed_precision=dt == torch.bfloat16)
+    sd = onets.deterministic_state(onets.g_param_shapes(spec), seed=61, scale=0.7)
+    assert set(sd) == set(G.state_dict())
+    G.load_state_dict(sd)
+    G = G.to(DEV).eval()
+    LR, HR, Z, x, y = ogan.synthetic_batch(2, 6, 5, 4, seed=13)
+    gy = torch.randn(2, 3, 24, 24, 5, generator=torch.Generator().manual_seed(3))
+
+    def oracle(s):
+        ref = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+        o = onets.generator_forward(ref, LR, Z, s)
+        (o * gy).sum().backward()
+        return o.detach(), {k: v.grad for k, v in ref.items()}
+
+    want, gw = oracle(spec)
+    out = G(LR.to(DEV), Z.to(DEV))
+    (out * gy.to(DEV)).sum().backward()
+    got = {k: p.grad for k, p in G.named_parameters()}
+    if dt == torch.float32:
+        assert rel_l2(out, want) < 2e-5
+        for k in gw:
+            assert rel_l2(got[k], gw[k]) < 2e-4, k
+    else:
+        em_spec = onets.GSpec(**{**kw, "bf16_storage": True})
+        _, ge = oracle(em_spec)
+        assert rel_l2(out, want) < 5e-2
+        lim = _emulated_bf16_bounds(gw, ge)
+        for k in gw:
+            assert rel_l2(got[k], gw[k]) < lim[k], (k, lim[k])
