@@ -871,3 +871,37 @@ def test_generator_constructor_variants_vs_oracle(hip, dt, variant):
         lim = _emulated_bf16_bounds(gw, ge)
         for k in gw:
             assert rel_l2(got[k], gw[k]) < lim[k], (k, lim[k])
+
+
+@pytest.mark.parametrize("variant", ["relu"])
+def test_discriminator_constructor_variants_vs_oracle(hip, variant):
+    """Discriminator_3D with ReLU (``act_type='relu'``, reference Discriminator_3D.py:23-38), fp32, train mode (a 5-tap
+    feature kernel shrinks z by two levels per down-sampling conv in the reference and needs its own depths: not a
+    variant of these shapes): logits, parameter gradients and the input gradient against the oracle's functional
+    discriminator (fp64 for the gradients: train-mode BatchNorm at batch 2, see test_discriminator_fp32_vs_reference)."""
+    from gan_sr_wind_field_amd.CNN_models.Discriminator_3D import Discriminator_3D
+
+    kw = dict(bf=4, nz=4, enable_slicing=True)
+    kw.update({"relu": dict(slope=0.0)}[variant])
+    spec = onets.DSpec(**kw)
+    D = Discriminator_3D(spec.in_channels, spec.bf, feat_kern_size=spec.feat_kern, number_of_z_layers=spec.nz,
+                         enable_slicing=True, dropout_probability=0.0, use_mixed_precision=False,
+                         act_type="relu" if spec.slope == 0.0 else "leakyrelu")
+    sd = onets.deterministic_state(onets.d_param_shapes(spec), seed=71, scale=1.0)
+    assert set(sd) == set(D.state_dict())
+    D.load_state_dict(sd)
+    D = D.to(DEV).train()
+    x = (torch.rand((2, 3, 64, 64, spec.nz), generator=torch.Generator().manual_seed(17)) * 2 - 1)
+    wgt = torch.tensor([[1.0], [-0.5]])
+    ref = {k: (v.double().clone().requires_grad_("running_" not in k) if v.is_floating_point() else v.clone())
+           for k, v in sd.items()}
+    xr = x.double().clone().requires_grad_(True)
+    want = onets.discriminator_forward(ref, xr, spec, training=True)
+    (want * wgt.double()).sum().backward()
+    xd = x.to(DEV).requires_grad_(True)
+    out = D(xd)
+    (out * wgt.to(DEV)).sum().backward()
+    assert rel_l2(out, want.detach().float()) < 2e-5
+    assert rel_l2(xd.grad.cpu().double(), xr.grad) < 5e-3
+    for k, p in D.named_parameters():
+        assert rel_l2(p.grad.cpu().double(), ref[k].grad) < 5e-3, k
