@@ -35,6 +35,14 @@ from .baseGAN import BaseGAN
 
 #: D(real) and D(fake) of an iteration as ONE batched pass of the discriminator's feature pyramid (WSR_D_PAIR=0: two)
 D_PAIR = __import__("os").environ.get("WSR_D_PAIR", "1") != "0"
+# A generator iteration's guards (non-finite loss terms, the normaliser branch) are read from the device AFTER backward has
+# been issued for the outcome that is the rule - every term finite - instead of stalling the launch queue in front of it.
+# An iteration whose flags then say otherwise is run again from the random-number state it started with (see update_G).
+SPECULATE_GUARDS = __import__("os").environ.get("WSR_SPECULATE_GUARDS", "1") != "0"
+
+
+class _GuardsSaidOtherwise(Exception):
+    """the speculative generator iteration met a flag that changes the graph: run it again the careful way"""
 
 _G_LOSS_KEYS = ("total", "adversarial", "pix", "xy_gradient", "z_gradient", "divergence", "xy_divergence",
                 "feature_D")
@@ -168,6 +176,23 @@ class wind_field_GAN_3D(BaseGAN):
             f = self.dp.global_max(f)
         return [v > 0 for v in f.tolist()]
 
+    def _flags_later(self, flags):
+        """the same flags, fetched WITHOUT waiting: the copy to pinned host memory is queued now, the returned callable
+        waits for it (by then long finished) and gives the booleans"""
+        f = torch.stack([v.reshape(()).to(torch.float32) for v in flags])
+        if self.dp is not None:
+            f = self.dp.global_max(f)
+        host = torch.empty(f.shape, dtype=f.dtype, pin_memory=True)
+        host.copy_(f, non_blocking=True)
+        done = torch.cuda.Event()
+        done.record()
+
+        def get():
+            done.synchronize()
+            return [v > 0 for v in host.tolist()]
+
+        return get
+
     def _noise(self, sigma: float, shape, it):
         return trainingtricks.instance_noise(self._scalar(sigma), shape, it, self.niter, device=self.device)
 
@@ -265,6 +290,20 @@ class wind_field_GAN_3D(BaseGAN):
 
         core, full, flags = totals()
         redo = sr_branch if sr_branch is not None else torch.zeros((), dtype=torch.bool, device=core.device)
+        if training_iteration and getattr(self, "_speculating", False):
+            # backward for "every term finite, normalisers from HR" goes out now; the flags are looked at behind it
+            later = self._flags_later(flags + [redo])
+            L["total"] = full
+            full.backward()
+            bad, bad_core, bad_full, redo = later()
+            if bad or redo:  # another total, or another graph: this pass does not count
+                raise _GuardsSaidOtherwise()
+            if not bad_full:
+                self.optimizer_G.step()
+            elif self.dp is not None:
+                self.dp.wait()  # the gradient collectives of the skipped step must still complete
+            self.log_G_losses(fake_HR, L, training_iteration)
+            return full
         bad, bad_core, bad_full, redo = self._flags(flags + [redo])
         if redo and torch.is_grad_enabled():  # rare: SR a hundred times larger than HR (see _content_losses)
             _, l_xy, l_z, l_div, l_div2, _ = self._content_losses(HR, fake_HR, Z, fused=False)
@@ -327,6 +366,28 @@ class wind_field_GAN_3D(BaseGAN):
         return pix, l_xy, l_z, l_div, l_div2, None
 
     def update_G(self, LR, HR, Z, it, training_iteration: bool):
+        if training_iteration and SPECULATE_GUARDS and torch.device(self.device).type == "cuda" \
+                and not getattr(self, "_speculating", False) and not getattr(self, "_careful", False):
+            # Speculative pass: nothing but gradients is written before the flags are known (D runs in eval mode with
+            # frozen parameters, the Adam step comes after them), and the random draws of the pass - Dropout3d masks,
+            # instance noise - are taken again from the same generator state if it has to be repeated.
+            rng = (torch.get_rng_state(), torch.cuda.get_rng_state(self.device))
+            self._speculating = True
+            try:
+                return self.update_G(LR, HR, Z, it, True)
+            except _GuardsSaidOtherwise:
+                if self.dp is not None:
+                    self.dp.wait()
+                torch.set_rng_state(rng[0])
+                torch.cuda.set_rng_state(rng[1], self.device)
+                self.G.zero_grad(set_to_none=True)
+                self._speculating, self._careful = False, True
+                try:
+                    return self.update_G(LR, HR, Z, it, True)
+                finally:
+                    self._careful = False
+            finally:
+                self._speculating = False
         if training_iteration:
             self.G.train()
             fake_HR = self.G(LR, Z)
