@@ -438,3 +438,43 @@ def test_loss_variants_vs_oracle(hip, gan_type, pix):
             names = dict(gan.G.named_parameters())
             for k in ("model.0.0.weight", "hr_convs.2.weight", "model.1.module.0.RDBs.1.LFF.bias"):
                 assert rel_l2(names[k].grad.cpu(), ref.sdG[k].grad) < 2e-3, (it, k)
+
+
+def test_checkpoint_resume_equals_uninterrupted_run(hip, tmp_path):
+    """``save_model`` after four iterations, ``load_model`` into a fresh model, two more iterations: bit for bit the
+    weights of the run that was never interrupted (deterministic kernels; the one-launch Adam keeps its step counts on
+    the host and writes them into the state when a checkpoint asks) - and the optimizer state in the file is what
+    ``torch.optim.Adam`` itself loads (the reference's ``load_model``, baseGAN.py:39-63)."""
+    over = dict(generator__num_features=16, generator__num_RRDB=1, generator__RDB_growth_chan=8,
+                generator__terrain_number_of_features=8, discriminator__num_features=8,
+                gan_config__number_of_z_layers=4, training__d_g_train_period=1)
+    LR, HR, Z, x, y = (t.to(DEV) for t in ogan.synthetic_batch(2, 16, 4, 4, seed=2001))
+
+    def fresh():
+        gan, cfg = _gan("bf16", **over)
+        cfg.env.this_runs_folder = str(tmp_path)
+        gan.feed_xy_niter(x, y, torch.tensor(cfg.training.niter, device=DEV), 1, 1)
+        return gan
+
+    a = fresh()
+    for it in (1, 2, 3, 4):
+        a.optimize_parameters(LR, HR, Z, it)
+    a.save_model(str(tmp_path), 0, 4)
+    for it in (5, 6):
+        a.optimize_parameters(LR, HR, Z, it)
+
+    b = fresh()
+    assert b.load_model(str(tmp_path / "G_4.pth"), str(tmp_path / "D_4.pth"), str(tmp_path / "state_4.pth")) == (0, 4)
+    b.G.train()
+    for it in (5, 6):
+        b.optimize_parameters(LR, HR, Z, it)
+    for net in ("G", "D"):
+        sa, sb = getattr(a, net).state_dict(), getattr(b, net).state_dict()
+        for k in sa:
+            assert torch.equal(sa[k], sb[k]), (net, k)
+    state = torch.load(str(tmp_path / "state_4.pth"), map_location="cpu")
+    for sd_opt, net in zip(state["optimizers"], (a.G, a.D)):
+        assert all(float(s["step"]) == 2.0 for s in sd_opt["state"].values())  # two G- and two D-iterations
+        plain = torch.optim.Adam([torch.nn.Parameter(p.detach().cpu().clone()) for p in net.parameters()])
+        plain.load_state_dict(sd_opt)
+        assert len(plain.state) == len(sd_opt["state"]) > 0
