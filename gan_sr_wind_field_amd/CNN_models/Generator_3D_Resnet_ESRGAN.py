@@ -38,6 +38,11 @@ class ProgramStack(nn.Sequential):
         object.__setattr__(self, "_lo", lo)
         return self
 
+    def __getstate__(self):  # torch.save(G) / copy.deepcopy(G): a weak reference does not pickle - the owner rebinds
+        d = dict(self.__dict__)
+        d.pop("_owner", None)
+        return d
+
     def __getitem__(self, idx):
         if not isinstance(idx, slice):
             return super().__getitem__(idx)
@@ -54,6 +59,11 @@ class ProgramStack(nn.Sequential):
             raise RuntimeError("this stack is not bound to a Generator_3D")
         if not x.is_cuda:
             raise RuntimeError("Generator_3D runs on the MI355X HIP kernels only (no CPU fallback)")
+        if torch.is_grad_enabled() and x.requires_grad:
+            # the reference's nn.Sequential would be differentiable here; this one is not: say so instead of handing
+            # back a tensor that silently carries no graph
+            raise RuntimeError(f"Generator_3D.{self._stack}[...] runs inference only on the HIP program: call it under "
+                               "torch.no_grad() / on a detached input (gradients flow through Generator_3D.forward)")
         prog = owner.program()
         with torch.no_grad():
             for k, child in enumerate(self):
@@ -153,6 +163,16 @@ class Generator_3D(nn.Module, lc.GlobalLoggingClass):
             raise RuntimeError("Generator_3D runs on the MI355X HIP kernels only: move the model and its inputs to "
                                "a cuda device (there is no CPU fallback)")
         return engine.run_generator(self.program(), x, Z, self.training, dropout_scale)
+
+    def __getstate__(self):  # torch.save(G): the program holds device workspaces and ctypes handles - it is rebuilt
+        d = dict(self.__dict__)
+        d["_program"] = None
+        return d
+
+    def __setstate__(self, state):
+        self.__dict__.update(state)
+        for name in ("model", "hr_convs", "terrain_convs"):
+            getattr(self, name).bind(self, name)
 
     def __deepcopy__(self, memo):
         import copy

@@ -39,6 +39,12 @@ D_PAIR = __import__("os").environ.get("WSR_D_PAIR", "1") != "0"
 # been issued for the outcome that is the rule - every term finite - instead of stalling the launch queue in front of it.
 # An iteration whose flags then say otherwise is run again from the random-number state it started with (see update_G).
 SPECULATE_GUARDS = __import__("os").environ.get("WSR_SPECULATE_GUARDS", "1") != "0"
+#: ... and stop speculating for a while when the guards keep firing (a dataset whose physics terms are non-finite on
+#: most patches, SR >> HR early in training): every miss costs a whole discarded generator pass, so after this many
+#: CONSECUTIVE misses the next SPEC_BACKOFF generator iterations take the careful path (flags read before backward,
+#: as the reference does) before speculation is tried again
+SPEC_MISS_LIMIT = int(__import__("os").environ.get("WSR_SPEC_MISS_LIMIT", "2"))
+SPEC_BACKOFF = int(__import__("os").environ.get("WSR_SPEC_BACKOFF", "64"))
 
 
 class _GuardsSaidOtherwise(Exception):
@@ -180,14 +186,25 @@ class wind_field_GAN_3D(BaseGAN):
         """the same flags, fetched WITHOUT waiting: the copy to pinned host memory is queued now, the returned callable
         waits for it (by then long finished) and gives the booleans"""
         f = torch.stack([v.reshape(()).to(torch.float32) for v in flags])
-        if self.dp is not None:
-            f = self.dp.global_max(f)
         host = torch.empty(f.shape, dtype=f.dtype, pin_memory=True)
-        host.copy_(f, non_blocking=True)
         done = torch.cuda.Event()
-        done.record()
+
+        def fetch(v):
+            host.copy_(v, non_blocking=True)
+            done.record()
+
+        if self.dp is not None:
+            # "set on ANY rank": the flags ride in the backward collective of the RaGAN mean logits (a SUM; the first
+            # thing the backward pass issues) instead of taking a blocking collective of their own
+            self.dp.ride(f, fetch)
+        else:
+            fetch(f)
 
         def get():
+            if self.dp is not None:
+                left = self.dp.take_unridden()
+                if left is not None:  # this backward pass held no scalar collective (gan_type "relativistic")
+                    fetch(self.dp.global_max(left[0]))
             done.synchronize()
             return [v > 0 for v in host.tolist()]
 
@@ -250,19 +267,29 @@ class wind_field_GAN_3D(BaseGAN):
 
     def calculate_optimize_and_log_G_loss(self, HR, fake_HR, Z, y_pred, fake_y_pred, training_iteration: bool):
         t = self.cfg.training
+        if t.gan_type not in ("relativistic", "relativisticavg"):
+            raise NotImplementedError(f"Only relativistic and relativisticavg GAN are implemented, not {t.gan_type}")
+        # Under data parallelism the two batch-global inputs of this loss - the RaGAN mean logits and the eight
+        # physics-loss maxima - cross the ranks in ONE collective (dist._MeansMax): the content losses hand their local
+        # maxima to `reduce_max`, which returns the global ones and keeps the means for the adversarial term.
+        means = []
+        reduce_max = None
+        if self.dp is not None and t.gan_type == "relativisticavg":
+            def reduce_max(m):
+                m_a, m_b, g = self.dp.means_and_max(y_pred, fake_y_pred, m)
+                means.append((m_a, m_b))
+                return g
+        pix, l_xy, l_z, l_div, l_div2, sr_branch = self._content_losses(HR, fake_HR, Z, reduce_max=reduce_max)
         if t.gan_type == "relativistic":
             adv = self.criterion(fake_y_pred - y_pred, self.HR_labels)
-        elif t.gan_type == "relativisticavg":
-            m_real, m_fake = self._means(y_pred, fake_y_pred)
+        else:
+            m_real, m_fake = means[0] if means else self._means(y_pred, fake_y_pred)
             adv = (self.criterion(fake_y_pred - m_real, self.HR_labels)
                    + self.criterion(y_pred - m_fake, self.fake_HR_labels)) / 2.0
-        else:
-            raise NotImplementedError(f"Only relativistic and relativisticavg GAN are implemented, not {t.gan_type}")
 
         feat = torch.zeros(1, device=self.device)
         if self.feature_extractor is not None:
             feat = self.feature_D_criterion(self.feature_extractor(HR).detach(), self.feature_extractor(fake_HR))
-        pix, l_xy, l_z, l_div, l_div2, sr_branch = self._content_losses(HR, fake_HR, Z)
 
         L = {
             "adversarial": adv * t.adversarial_loss_weight,
@@ -323,7 +350,7 @@ class wind_field_GAN_3D(BaseGAN):
         self.log_G_losses(fake_HR, L, training_iteration)
         return total
 
-    def _content_losses(self, HR, fake_HR, Z, fused: bool = True):
+    def _content_losses(self, HR, fake_HR, Z, fused: bool = True, reduce_max=None):
         """(pix, xy_gradient, z_gradient, divergence, xy_divergence) un-weighted (reference :377-432) and, on the
         fused path, the device flag "a normaliser came from SR" (else None).
 
@@ -339,8 +366,8 @@ class wind_field_GAN_3D(BaseGAN):
             from .. import hip_ops
             sums, mx = hip_ops.physics_loss_stats(HR, fake_HR, self.x, self.y, Z)
             m = mx.view(2, 4)
-            if self.dp is not None:
-                m = self.dp.global_max(m)
+            if self.dp is not None:  # (``reduce_max``: the caller's collective, which carries these maxima along)
+                m = reduce_max(m) if reduce_max is not None else self.dp.global_max(m)
             n = torch.max(m[0], m[1] / 100)
             nvox = float(HR.shape[0] * HR.shape[2] * HR.shape[3] * HR.shape[4])
             key = (HR.device, nvox)
@@ -371,16 +398,39 @@ class wind_field_GAN_3D(BaseGAN):
             # Speculative pass: nothing but gradients is written before the flags are known (D runs in eval mode with
             # frozen parameters, the Adam step comes after them), and the random draws of the pass - Dropout3d masks,
             # instance noise - are taken again from the same generator state if it has to be repeated.
+            if getattr(self, "_careful_left", 0) > 0:  # backed off (see SPEC_MISS_LIMIT): the reference's order
+                self._careful_left -= 1
+                self._careful = True
+                try:
+                    return self.update_G(LR, HR, Z, it, True)
+                finally:
+                    self._careful = False
             rng = (torch.get_rng_state(), torch.cuda.get_rng_state(self.device))
+            first_call = self.device_check == ""  # the pass about to run makes the reference's one extra noise draw
             self._speculating = True
             try:
-                return self.update_G(LR, HR, Z, it, True)
+                out = self.update_G(LR, HR, Z, it, True)
+                self._spec_misses = 0
+                return out
             except _GuardsSaidOtherwise:
                 if self.dp is not None:
                     self.dp.wait()
+                    self.dp.stats.retries += 1  # (the discarded pass's collectives did run: they stay in the ledger)
                 torch.set_rng_state(rng[0])
                 torch.cuda.set_rng_state(rng[1], self.device)
+                if first_call:
+                    self.device_check = ""  # ... and the repeated pass makes that draw again, from the restored state
                 self.G.zero_grad(set_to_none=True)
+                self._spec_misses = getattr(self, "_spec_misses", 0) + 1
+                self.spec_retries = getattr(self, "spec_retries", 0) + 1
+                if self._spec_misses >= SPEC_MISS_LIMIT > 0:
+                    self._careful_left, self._spec_misses = SPEC_BACKOFF, 0
+                    if not getattr(self, "_spec_logged", False):
+                        self._spec_logged = True
+                        self.status_logs.append(
+                            f"generator loss guards fired in {SPEC_MISS_LIMIT} consecutive iterations: the next "
+                            f"{SPEC_BACKOFF} generator iterations read them before the backward pass (no discarded "
+                            f"passes); speculation is retried after that (WSR_SPEC_MISS_LIMIT / WSR_SPEC_BACKOFF)")
                 self._speculating, self._careful = False, True
                 try:
                     return self.update_G(LR, HR, Z, it, True)

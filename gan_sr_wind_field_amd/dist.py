@@ -71,11 +71,13 @@ def init_from_env(backend: Optional[str] = None, single_rank: bool = False) -> b
         if world <= 1:
             # a group of one needs no TCP store: a private file keeps two such runs on one box (or one next to a real
             # torchrun job on the default port) from colliding on MASTER_PORT
+            import atexit
+            import shutil
             import tempfile
-            fd, path = tempfile.mkstemp(prefix="wsr_pg_")
-            os.close(fd)
-            os.unlink(path)
-            dist.init_process_group(backend=backend, init_method=f"file://{path}", rank=0, world_size=1)
+            d = tempfile.mkdtemp(prefix="wsr_pg_")  # a directory of our own: no name-reuse race, nothing left behind
+            atexit.register(shutil.rmtree, d, True)
+            dist.init_process_group(backend=backend, init_method=f"file://{os.path.join(d, 'store')}", rank=0,
+                                    world_size=1)
         else:
             dist.init_process_group(backend=backend)
     return True
@@ -113,24 +115,73 @@ class _BatchMean2(torch.autograd.Function):
     collectives per loss become 1 + 1."""
 
     @staticmethod
-    def forward(ctx, a: Tensor, b: Tensor, group):
+    def forward(ctx, a: Tensor, b: Tensor, group, dp=None):
         tot = torch.stack([a.sum().float(), b.sum().float()])
         _note("scalar", tot, group)
         with _timed("scalar", tot, group):
             dist.all_reduce(tot, group=group)
         world = dist.get_world_size(group)
-        ctx.group = group
+        ctx.group, ctx.dp = group, dp
         ctx.meta = ((float(a.numel() * world), a.shape, a.dtype), (float(b.numel() * world), b.shape, b.dtype))
         return (tot[0] / ctx.meta[0][0]).to(a.dtype), (tot[1] / ctx.meta[1][0]).to(b.dtype)
 
     @staticmethod
     def backward(ctx, ga: Tensor, gb: Tensor):
         g = torch.stack([ga.reshape(()).float(), gb.reshape(()).float()])
+        g, rider = _take_rider(ctx.dp, g)
         _note("scalar", g, ctx.group)
         with _timed("scalar", g, ctx.group):
             dist.all_reduce(g, group=ctx.group)
+        _give_rider(rider, g, 2)
         (ca, sa, da), (cb, sb, db) = ctx.meta
-        return (g[0] / ca).to(da).expand(sa), (g[1] / cb).to(db).expand(sb), None
+        return (g[0] / ca).to(da).expand(sa), (g[1] / cb).to(db).expand(sb), None, None
+
+
+def _take_rider(dp, g: Tensor):
+    """(vector to all-reduce, rider) - a small non-differentiable vector that waits for the next backward collective of
+    the loss scalars travels in the same SUM all-reduce (``DataParallel.ride``: the generator iteration's guard flags)"""
+    rider = getattr(dp, "_rider", None) if dp is not None else None
+    if rider is None:
+        return g, None
+    dp._rider = None
+    return torch.cat([g, rider[0].to(g.dtype).reshape(-1)]), rider
+
+
+def _give_rider(rider, g: Tensor, n: int) -> None:
+    if rider is not None:
+        rider[1](g[n:])
+
+
+class _MeansMax(torch.autograd.Function):
+    """(mean a, mean b, element-wise max m) over the global batch in ONE collective: every rank contributes the record
+    [sum a, sum b, m...] to an all-gather and reduces the gathered rows itself (sums for the means, maxima for m; a NaN
+    in any rank's maximum propagates, as ``torch.max`` does on one GPU).  The generator iteration needs the two RaGAN
+    average logits and the eight physics-loss maxima before it can form its loss (reference
+    wind_field_GAN_3D.py:360-364, 773-814): two blocking collectives become one.  Backward: one SUM all-reduce of the
+    two mean gradients (plus a rider, see ``DataParallel.ride``); the maxima are not differentiated here (the fused
+    content-loss path; the composed path keeps :class:`_GlobalMax`)."""
+
+    @staticmethod
+    def forward(ctx, a: Tensor, b: Tensor, m: Tensor, dp):
+        rec = torch.cat([a.sum().float().reshape(1), b.sum().float().reshape(1), m.detach().float().reshape(-1)])
+        rows = dp.gather_small(rec, "scalar")
+        tot = rows[:, :2].sum(0)
+        gmax = rows[:, 2:].max(0).values.reshape(m.shape).to(m.dtype)
+        ctx.dp = dp
+        ctx.meta = ((float(a.numel() * dp.world), a.shape, a.dtype), (float(b.numel() * dp.world), b.shape, b.dtype))
+        ctx.mark_non_differentiable(gmax)
+        return (tot[0] / ctx.meta[0][0]).to(a.dtype), (tot[1] / ctx.meta[1][0]).to(b.dtype), gmax
+
+    @staticmethod
+    def backward(ctx, ga: Tensor, gb: Tensor, _gm):
+        g = torch.stack([ga.reshape(()).float(), gb.reshape(()).float()])
+        g, rider = _take_rider(ctx.dp, g)
+        _note("scalar", g, ctx.dp.group)
+        with _timed("scalar", g, ctx.dp.group):
+            dist.all_reduce(g, group=ctx.dp.group)
+        _give_rider(rider, g, 2)
+        (ca, sa, da), (cb, sb, db) = ctx.meta
+        return (g[0] / ca).to(da).expand(sa), (g[1] / cb).to(db).expand(sb), None, None
 
 
 class _GlobalMax(torch.autograd.Function):
@@ -180,6 +231,7 @@ class CommStats:
         self.count = {k: 0 for k in self.KINDS}
         self.bytes = {k: 0 for k in self.KINDS}
         self._events = {"wait": [], "syncbn": [], "scalar": []}
+        self.retries = 0  # generator passes discarded by the loss guards and run again (their collectives are counted)
 
     def add(self, kind: str, t: Tensor) -> None:
         self.count[kind] += 1
@@ -204,6 +256,7 @@ class CommStats:
             "syncbn_blocking_ms_per_step": per(ms["syncbn"]) if self.timing else None,
             "scalar_blocking_ms_per_step": per(ms["scalar"]) if self.timing else None,
             "timed": self.timing,
+            "discarded_generator_passes_per_step": per(self.retries),
         }
 
 
@@ -249,6 +302,7 @@ class DataParallel:
         #: buckets shrink towards the end of a backward pass: the final collective cannot hide under anything, so a bucket
         #: also closes once it holds at least as much as everything still to come (>= tail_mb) - 32, 32, ..., 16, 8, 4, 2, 1
         self.tail_elems = max(1, int(tail_mb * 1024 * 1024 / 4))
+        self._rider = None
         self.stats = CommStats()
         _LEDGERS[_gkey(group)] = self.stats  # (one ledger per process group: a later DataParallel on another group keeps its own)
 
@@ -258,7 +312,35 @@ class DataParallel:
 
     def batch_means(self, a: Tensor, b: Tensor):
         """(global mean of a, global mean of b) with one collective per pass"""
-        return _BatchMean2.apply(a, b, self.group)
+        return _BatchMean2.apply(a, b, self.group, self)
+
+    def means_and_max(self, a: Tensor, b: Tensor, m: Tensor):
+        """(global mean of a, global mean of b, element-wise global maximum of m) with ONE collective forward and one
+        backward (see :class:`_MeansMax`); ``m`` is not differentiated"""
+        return _MeansMax.apply(a, b, m, self)
+
+    def gather_small(self, rec: Tensor, kind: str = "scalar") -> Tensor:
+        """(world, len(rec)) - every rank's copy of a small vector, one collective"""
+        out = torch.empty((self.world,) + tuple(rec.shape), dtype=rec.dtype, device=rec.device)
+        self.stats.add(kind, rec)
+        with self.stats.bracket(kind, rec):
+            if self._avg_native:  # nccl / RCCL
+                dist.all_gather_into_tensor(out, rec.contiguous(), group=self.group)
+            else:
+                dist.all_gather(list(out.unbind(0)), rec.contiguous(), group=self.group)
+        return out
+
+    def ride(self, flags: Tensor, on_result) -> None:
+        """``flags`` (small non-negative float vector, "set on any rank" semantics) travels in the NEXT backward
+        collective of the loss scalars instead of taking one of its own: that all-reduce is a SUM, and a sum of 0 / 1
+        flags is > 0 exactly when one rank set it.  ``on_result(summed)`` is called inside that backward, right behind
+        the collective.  A caller whose backward pass may hold no such collective asks ``take_unridden`` afterwards."""
+        self._rider = (flags, on_result)
+
+    def take_unridden(self):
+        """the rider no backward collective picked up (``None`` when it travelled), cleared"""
+        r, self._rider = getattr(self, "_rider", None), None
+        return r
 
     def global_max(self, t: Tensor) -> Tensor:
         """maximum over the ranks; differentiable when ``t`` is (see :class:`_GlobalMax`)"""
@@ -277,14 +359,7 @@ class DataParallel:
 
     def stat_allgather(self, t: Tensor) -> Tensor:
         """(world, len(t)) copies of a small vector from every rank - the one collective of a SyncBN forward"""
-        out = torch.empty((self.world,) + tuple(t.shape), dtype=t.dtype, device=t.device)
-        self.stats.add("syncbn", t)
-        with self.stats.bracket("syncbn", t):
-            if self._avg_native:  # nccl / RCCL
-                dist.all_gather_into_tensor(out, t.contiguous(), group=self.group)
-            else:
-                dist.all_gather(list(out.unbind(0)), t.contiguous(), group=self.group)
-        return out
+        return self.gather_small(t, "syncbn")
 
     def _avg_async(self, t: Tensor) -> None:
         if self._avg_native:

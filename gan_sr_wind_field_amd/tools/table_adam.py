@@ -45,7 +45,8 @@ class TableAdam(torch.optim.Adam):
         self._steps_dirty = False
 
     def _fast_ok(self, group: dict) -> bool:
-        if group.get("amsgrad") or group.get("maximize") or group.get("capturable") or group.get("differentiable"):
+        if group.get("amsgrad") or group.get("maximize") or group.get("capturable") or group.get("differentiable") \
+                or group.get("decoupled_weight_decay"):  # (the kernel implements Adam's L2 form of weight decay only)
             return False
         if not isinstance(group["lr"], float) and not isinstance(group["lr"], int):
             return False
@@ -61,7 +62,11 @@ class TableAdam(torch.optim.Adam):
     def step(self, closure=None):
         # (host cost matters at the small presets, where ~1 600 launches per 30 ms step leave the host no slack: one pass
         # over the pointers decides whether last step's table still describes this one - then nothing else is looked at)
-        sigs = [tuple((p.data_ptr(), p.grad.data_ptr()) if p.grad is not None else None for p in g["params"])
+        # ... the pointers AND what _fast_ok decides from the group's options: a learning rate that became a tensor, a
+        # flag switched on after construction must not ride on a table built before
+        sigs = [(type(g["lr"]) in (float, int), bool(g.get("amsgrad") or g.get("maximize") or g.get("capturable")
+                                                      or g.get("differentiable") or g.get("decoupled_weight_decay")))
+                + tuple((p.data_ptr(), p.grad.data_ptr()) if p.grad is not None else None for p in g["params"])
                 for g in self.param_groups]
         hit = closure is None and all(self._sig.get(gi) == sig for gi, sig in enumerate(sigs))
         fast = hit or (closure is None and all(self._fast_ok(g) for g in self.param_groups))

@@ -141,8 +141,8 @@ def build_ref_D(spec: onets.DSpec):
                 enable_slicing=spec.enable_slicing, dropout_probability=spec.dropout_p, normalization_type=spec.norm)
 
 
-def gen_generators():
-    for scale, n, nz in ((4, 6, 5), (8, 4, 4)):
+def gen_generators(cases=((4, 6, 5), (8, 4, 4))):
+    for scale, n, nz in cases:
         spec = onets.GSpec(upscale=scale, **G_SMALL)
         G = build_ref_G(spec)
         shapes = onets.g_param_shapes(spec)
@@ -430,7 +430,7 @@ def gen_config_golden():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["conv", "blocks", "G", "D", "physics", "trace", "init", "config", "c1", "data", "Dinst"]
+    which = sys.argv[1:] or ["conv", "blocks", "G", "D", "physics", "trace", "init", "config", "c1", "data", "Dinst", "G16"]
     if "config" in which:
         gen_config_golden()
     if "conv" in which:
@@ -439,6 +439,8 @@ if __name__ == "__main__":
         gen_blocks()
     if "G" in which:
         gen_generators()
+    if "G16" in which:  # scale = 16 (pretrained_models/upscale16_pix4_no_adv_no_slicing/config.ini:5): four UpConv stages
+        gen_generators(((16, 3, 4),))
     if "D" in which:
         gen_discriminators()
     if "Dinst" in which:  # normalization_type = "instance" (torch_blocks.py:26-30), both slicing modes (the tail stays "batch")

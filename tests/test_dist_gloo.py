@@ -256,3 +256,48 @@ def test_comm_ledger_counts_collectives_and_bytes(tmp_path):
     assert torch.allclose(r["ga"], torch.full((2,), 1.5)) and torch.allclose(r["gb"], torch.full((1,), 5.0))
     # geometric tail: full buckets, then each bucket at least as large as what is still to come; the last one is tiny
     assert r["sizes"] == [100, 100, 100, 80, 40, 20, 10] and torch.allclose(r["flat2"], torch.full((450,), 1.5))
+
+
+def _means_max_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    import torch.distributed as dist
+    from gan_sr_wind_field_amd import dist as wdist
+
+    assert wdist.init_from_env("gloo")
+    dp = wdist.DataParallel()
+    a = torch.tensor([float(rank), 2.0 * rank], requires_grad=True)
+    b = torch.tensor([1.0 + rank], requires_grad=True)
+    m = torch.tensor([[1.0 + rank, 5.0 - rank, 0.5, 2.0 * rank], [3.0, float(rank), 7.0 - 3 * rank, 1.0]])
+    if rank == 1:
+        m[1, 3] = float("nan")  # a NaN maximum on one rank reaches every rank (torch.max semantics)
+    ma, mb, gm = dp.means_and_max(a, b, m)
+    assert not gm.requires_grad
+    got = []
+    dp.ride(torch.tensor([0.0, float(rank), 0.0]), lambda v: got.append(v.clone()))  # flag 1 set on rank 1 only
+    (3.0 * ma + 5.0 * mb).backward()
+    assert dp.take_unridden() is None  # the backward collective of the means carried it
+    # a backward pass without any scalar collective leaves the rider to its owner
+    dp.ride(torch.tensor([1.0]), lambda v: None)
+    left = dp.take_unridden()
+    comm = dp.stats.summary(1)
+    torch.save(dict(ma=ma.detach(), mb=mb.detach(), gm=gm, ga=a.grad, gb=b.grad, flags=got[0], left=left[0], comm=comm),
+               os.path.join(out_dir, f"r{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_means_and_maxima_share_one_collective_and_flags_ride_on_the_backward_one(tmp_path):
+    """dist._MeansMax: the generator iteration's RaGAN mean logits and physics-loss maxima in ONE all-gather; its
+    backward all-reduce also carries the guard flags (``DataParallel.ride``): 2 scalar collectives where there were 4."""
+    world, port = 2, _free_port()
+    mp.spawn(_means_max_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    for rank in range(world):
+        r = torch.load(tmp_path / f"r{rank}.pt")
+        assert abs(float(r["ma"]) - 0.75) < 1e-6 and abs(float(r["mb"]) - 1.5) < 1e-6
+        assert torch.allclose(r["ga"], torch.full((2,), 1.5)) and torch.allclose(r["gb"], torch.full((1,), 5.0))
+        want = torch.tensor([[2.0, 5.0, 0.5, 2.0], [3.0, 1.0, 7.0, float("nan")]])
+        assert torch.allclose(r["gm"], want, equal_nan=True), r["gm"]
+        assert [bool(v > 0) for v in r["flags"]] == [False, True, False]
+        assert r["left"].tolist() == [1.0]
+        assert r["comm"]["scalar_collectives_per_step"] == 2 and r["comm"]["collectives_per_step"] == 2

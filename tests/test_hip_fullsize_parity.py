@@ -338,6 +338,68 @@ def test_gan_train_step_trace_bf16_vs_reference(golden, hip):
     _report("trace_bf16", rep)
 
 
+_c3_oracle = {}
+
+
+def _c3_full_oracle():
+    """oracle forward at the HEADLINE size, once per session: LR 32x32x128 -> SR 128^3 through the full 34.77 M-parameter
+    G (21.6 TFLOP: 15-40 s on the box's host cores), and D's eval logit on HR at 128^3 (23.4 M parameters)"""
+    if not _c3_oracle:
+        import time
+        gs, ds = onets.GSpec(), onets.DSpec(bf=32, nz=128, enable_slicing=False)
+        sdG = onets.deterministic_state(onets.g_param_shapes(gs), seed=211, scale=0.3)
+        sdD = onets.deterministic_state(onets.d_param_shapes(ds), seed=213, scale=1.0)
+        LR, HR, Z, x, y = ogan.synthetic_batch(1, 32, 128, 4, seed=2001)
+        t0 = time.time()
+        with torch.no_grad():
+            sr = onets.generator_forward(sdG, LR, Z, gs, training=False)
+            d_hr = onets.discriminator_forward(sdD, HR, ds, training=False)
+            ds16 = onets.DSpec(bf=32, nz=128, enable_slicing=False, bf16_storage=True)
+            d_em = onets.discriminator_forward(sdD, HR, ds16, training=False)
+        _c3_oracle.update(gs=gs, ds=ds, sdG=sdG, sdD=sdD, LR=LR, HR=HR, Z=Z, sr=sr, d_hr=d_hr, d_em=d_em,
+                          host_s=time.time() - t0)
+    return _c3_oracle
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_c3_full_size_forward_vs_oracle(hip, dtype):
+    """BASELINE's headline shape against the ORACLE at full size (not a slab, not a property): the SR field of the
+    full-width generator on LR 32x32x128 -> 128^3 and the discriminator's eval logit on a 128^3 HR volume, both HIP
+    programs.  fp32: rel-L2 2e-5 (SR) / 2e-5 of the logit; bf16: 2e-2 (SR) and the logit within 1e-2 + twice the
+    distance the oracle's bf16-storage emulation shows."""
+    from test_hip_networks import build_D, build_G
+
+    o = _c3_full_oracle()
+    dt = torch.float32 if dtype == "fp32" else torch.bfloat16
+    from gan_sr_wind_field_amd.CNN_models.Generator_3D_Resnet_ESRGAN import Generator_3D
+    from gan_sr_wind_field_amd.CNN_models.Discriminator_3D import Discriminator_3D
+    gs, ds = o["gs"], o["ds"]
+    G = Generator_3D(gs.in_channels, gs.out_channels, gs.nf, gs.n_rrdb, upscale=gs.upscale, hr_kern_size=gs.hr_kern,
+                     RDB_gc=gs.gc, terrain_number_of_features=gs.tf, dropout_probability=gs.dropout_p,
+                     use_mixed_precision=dt == torch.bfloat16)
+    G.load_state_dict(o["sdG"])
+    G = G.to(DEV).eval()
+    D = Discriminator_3D(ds.in_channels, ds.bf, feat_kern_size=ds.feat_kern, number_of_z_layers=ds.nz,
+                         enable_slicing=False, dropout_probability=ds.dropout_p, use_mixed_precision=dt == torch.bfloat16)
+    D.load_state_dict(o["sdD"])
+    D = D.to(DEV).eval()
+    with torch.no_grad():
+        sr = G(o["LR"].to(DEV), o["Z"].to(DEV))
+        d_hr = D(o["HR"].to(DEV))
+    assert sr.shape == (1, 3, 128, 128, 128)
+    e_sr = rel_l2(sr, o["sr"])
+    ref = float(o["d_hr"])
+    e_d = abs(float(d_hr) - ref) / abs(ref)
+    d_tol = 2e-5 if dtype == "fp32" else 1e-2 + 2 * abs(float(o["d_em"]) - ref) / abs(ref)
+    _report(f"c3_full_forward_{dtype}", {"sr_vs_oracle": e_sr, "d_logit_rel": e_d, "d_logit_tol": d_tol,
+                                         "oracle_host_s": o["host_s"], "d_logit": ref})
+    assert e_sr < (2e-5 if dtype == "fp32" else 2e-2), e_sr
+    assert e_d < d_tol, (e_d, d_tol)
+    del G, D
+    torch.cuda.empty_cache()
+
+
 @pytest.mark.parametrize("case", ["plain", "physics_nonfinite", "total_nonfinite", "sr_normaliser"])
 def test_generator_iteration_guards_vs_oracle(hip, case):
     """The reference's non-finite guards of a generator iteration (wind_field_GAN_3D.py:434-460) on the HIP path, fp32,
@@ -398,6 +460,48 @@ def test_generator_iteration_guards_vs_oracle(hip, case):
             assert torch.equal(names[k].detach(), w0[k]), (case, k)
     st = gan.optimizer_G.state_dict()["state"]
     assert (len(st) > 0 and float(st[0]["step"]) == 1.0) if stepped else all(float(s["step"]) == 0.0 for s in st.values())
+
+
+def test_speculative_guards_back_off_when_they_keep_firing(hip, monkeypatch):
+    """A batch whose physics terms are non-finite EVERY iteration (two equal z levels): the speculative generator pass
+    (flags read behind the backward pass) is discarded and repeated - after SPEC_MISS_LIMIT consecutive misses the model
+    stops speculating for SPEC_BACKOFF generator iterations (no more discarded passes), says so ONCE in the status log,
+    and every iteration's losses still equal the oracle's."""
+    from gan_sr_wind_field_amd.GAN_models import wind_field_GAN_3D as mod
+
+    monkeypatch.setattr(mod, "SPEC_MISS_LIMIT", 2)
+    monkeypatch.setattr(mod, "SPEC_BACKOFF", 3)
+    gs = onets.GSpec(in_channels=4, nf=16, n_rrdb=1, gc=8, tf=8, hr_kern=5, upscale=4)
+    ds = onets.DSpec(bf=8, nz=4, enable_slicing=True)
+    sdG = onets.deterministic_state(onets.g_param_shapes(gs), seed=41, scale=0.5)
+    sdD = onets.deterministic_state(onets.d_param_shapes(ds), seed=43, scale=1.0)
+    LR, HR, Z, x, y = ogan.synthetic_batch(2, 16, 4, 4, seed=2001)
+    Z[..., 2] = Z[..., 1]
+    gan, cfg = _gan("fp32", generator__num_features=16, generator__num_RRDB=1, generator__RDB_growth_chan=8,
+                    generator__terrain_number_of_features=8, discriminator__num_features=8,
+                    gan_config__number_of_z_layers=4, training__d_g_train_period=1)
+    gan.G.load_state_dict(sdG)
+    gan.D.load_state_dict(sdD)
+    gan.get_new_status_logs()
+    gan.feed_xy_niter(x.to(DEV), y.to(DEV), torch.tensor(cfg.training.niter, device=DEV), 1, 1)
+    ref = ogan.OracleGAN({k: v.clone() for k, v in sdG.items()}, {k: v.clone() for k, v in sdD.items()}, gs, ds,
+                         ogan.TrainSpec(use_instance_noise=False, d_g_train_period=1))
+    ref.feed_xy(x, y)
+    dev = [t.to(DEV) for t in (LR, HR, Z)]
+    retries = []
+    for it in range(2, 18, 2):  # eight generator iterations
+        gan.optimize_parameters(*dev, it)
+        assert ref.optimize_parameters(LR, HR, Z, it) == "G"
+        retries.append(getattr(gan, "spec_retries", 0))
+        for k in LOSS_KEYS:
+            want = float(ref.G_losses[k])
+            got = float(gan.get_G_train_loss_dict_ref()[k].detach())
+            assert (got == pytest.approx(want, rel=2e-3, abs=1e-7)) if np.isfinite(want) else not np.isfinite(got), (it, k)
+    # misses at iterations 1, 2 -> three careful iterations -> misses at 6, 7 -> careful again
+    assert retries == [1, 2, 2, 2, 2, 3, 4, 4], retries
+    logs = [line for line in gan.get_new_status_logs() if "guards fired" in line]
+    assert len(logs) == 1, logs
+    assert rel_l2(dict(gan.G.named_parameters())["hr_convs.2.weight"].detach().cpu(), ref.sdG["hr_convs.2.weight"].detach()) < 5e-3
 
 
 @pytest.mark.parametrize("gan_type,pix", [("relativistic", "l2"), ("relativisticavg", "l2"), ("relativistic", "l1")])

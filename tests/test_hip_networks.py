@@ -41,7 +41,7 @@ def build_D(spec, dtype, seed):
     return D.to(DEV), sd
 
 
-@pytest.mark.parametrize("scale,n,nz", [(4, 6, 5), (8, 4, 4)])
+@pytest.mark.parametrize("scale,n,nz", [(4, 6, 5), (8, 4, 4), (16, 3, 4)])  # x16: reference pretrained_models/upscale16_*/config.ini:5
 def test_generator_fp32_vs_reference(golden, hip, scale, n, nz):
     g = golden(f"g_small_s{scale}.npz")
     spec = onets.GSpec(upscale=scale, in_channels=4, out_channels=3, nf=16, n_rrdb=2, hr_kern=5, gc=8, tf=8)

@@ -2,12 +2,16 @@
 
   C1    shipped local ini: D with slicing, LR 16x16x10 -> HR 64x64x10 (parity: test_hip_fullsize_parity.py)
   C1b   the reference's real patch size 32x32x10 -> 128x128x10, no slicing
+  C1c   the reference's production training shape: cluster ini as shipped (batch 32, D sliced, 64x64x10 HR slices;
+        config/wind_field_GAN_3D_config_cluster.ini:42,47)
   C2    generator-only fwd + bwd + Adam, fp32, 64x64x64 -> 256x256x64
   C3'   the benchmark default (full-size properties: test_hip_networks.py::test_full_size_c3_*)
   C3lit BASELINE.json configs[2] read literally: generator-only at LR 128^3 -> 512 x 512 x 128 (144-channel HR tensors
         of 4.8e9 elements: beyond 32-bit element offsets; D cannot consume 512 x 512)
   C4    the per-GPU shape of the 8-GPU run: C3' at batch 4
   C5b   upscale8 ini (x8, three UpConv stages), batch 8, 16x16x10 -> 128x128x10, full G + D step
+  C6    upscale16 ini (x16, four UpConv stages; pretrained_models/upscale16_pix4_no_adv_no_slicing/config.ini:5),
+        batch 8, 8x8x10 -> 128x128x10, full G + D step
   C5lit x8 generator-only at 64x64x64 -> 512x512x64 (4.8 GB per 144-channel HR tensor: the HBM stress case)
 
 Per preset, size-independent properties: one step runs with finite losses and moves the weights, the eval
@@ -42,7 +46,7 @@ def _bench():
     return mod
 
 
-@pytest.mark.parametrize("preset", ["C1", "C1b", "C2", "C3lit", "C4", "C5b", "C5lit"])
+@pytest.mark.parametrize("preset", ["C1", "C1b", "C1c", "C2", "C3lit", "C4", "C5b", "C5lit", "C6"])
 def test_preset_runs(hip, preset):
     from gan_sr_wind_field_amd.process_data import synthetic_batch
 
