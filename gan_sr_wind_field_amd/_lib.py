@@ -17,7 +17,7 @@ WSR_F32, WSR_BF16 = 0, 1
 WSR_EUNSUPPORTED = -2
 
 EXPORTS = [
-    "wsr_abi_version", "wsr_error_string", "wsr_reload_env", "wsr_conv3d_fwd", "wsr_conv3d_dgrad", "wsr_conv3d_wgrad", "wsr_conv3d_wgrad_tri", "wsr_conv3d_wgrad_nparts", "wsr_conv3d_wgrad_parts", "wsr_unpack_wgrad_reduce_multi", "wsr_conv3d_fwd_tile", "wsr_conv3d_dgrad_tile",
+    "wsr_abi_version", "wsr_error_string", "wsr_reload_env", "wsr_conv3d_fwd", "wsr_conv3d_dgrad", "wsr_conv3d_wgrad", "wsr_conv3d_wgrad_tri", "wsr_conv3d_wgrad_nparts", "wsr_conv3d_wgrad_parts", "wsr_conv3d_wgrad_parts_x2", "wsr_conv_split_ok", "wsr_unpack_wgrad_reduce_multi", "wsr_conv3d_fwd_tile", "wsr_conv3d_dgrad_tile",
     "wsr_frag_filter_elems", "wsr_pack_filter_frag", "wsr_pack_filter_frag_multi",
     "wsr_pack_filter", "wsr_unpack_wgrad", "wsr_unpack_wgrad_multi", "wsr_lrelu_bwd_inplace", "wsr_chan_axpby", "wsr_chan_sum", "wsr_chan_sum_rows", "wsr_chan_sum_partials", "wsr_upsample2_bwd", "wsr_subpixel_fold", "wsr_subpixel_unfold", "wsr_strided_parity_filters", "wsr_strided_parity_unfold",
     "wsr_planar_to_ndhwc", "wsr_ndhwc_to_planar", "wsr_zfold", "wsr_zunfold", "wsr_wind_gradient", "wsr_wind_gradient_bwd", "wsr_plane_sum", "wsr_linear_rows", "wsr_physics_loss_workspace_floats", "wsr_physics_loss_stats", "wsr_physics_loss_bwd", "wsr_bn_stats", "wsr_bn_mean", "wsr_bn_shard_stats", "wsr_bn_combine_shards", "wsr_bn_finalize", "wsr_bn_apply_lrelu", "wsr_bn_bwd_reduce",
@@ -44,6 +44,7 @@ class Epilogue(C.Structure):
         ("ws", C.c_void_p), ("ws_bytes", C.c_int64),
         ("res2", C.c_void_p), ("res2_ctot", C.c_int32), ("res2_off", C.c_int32), ("beta2", C.c_float),
         ("mask", C.c_void_p),
+        ("in2", C.c_void_p), ("in2_ctot", C.c_int32), ("in2_c0", C.c_int32),   # ABI 8: the concat as two tensors
     ]
 
 
@@ -58,7 +59,8 @@ class DgradOpts(C.Structure):
     """``wsr_dgrad_opts_t`` (ABI 6)."""
 
     _fields_ = [("acc_src", C.c_void_p), ("ws", C.c_void_p), ("ws_bytes", C.c_int64), ("acc_beta", C.c_float),
-                ("beta2", C.c_float), ("res2", C.c_void_p), ("res2_ctot", C.c_int32), ("res2_off", C.c_int32)]
+                ("beta2", C.c_float), ("res2", C.c_void_p), ("res2_ctot", C.c_int32), ("res2_off", C.c_int32),
+                ("dx2", C.c_void_p), ("dx2_ctot", C.c_int32), ("dx2_c0", C.c_int32)]   # ABI 8
 
 
 _lib: Optional[C.CDLL] = None
@@ -93,6 +95,8 @@ def lib() -> C.CDLL:
         "wsr_conv3d_wgrad_tri": [C.POINTER(ConvDesc), vp, vp, vp, i32, i32, vp],
         "wsr_conv3d_wgrad_nparts": [C.POINTER(ConvDesc), i32, i32, C.POINTER(C.c_int32)],
         "wsr_conv3d_wgrad_parts": [C.POINTER(ConvDesc), vp, vp, vp, i64, i32, i32, i32, vp],
+        "wsr_conv3d_wgrad_parts_x2": [C.POINTER(ConvDesc), vp, vp, i32, i32, vp, vp, i64, i32, vp],
+        "wsr_conv_split_ok": [C.POINTER(ConvDesc), i32],
         "wsr_unpack_wgrad_reduce_multi": [vp, i32, vp],
         "wsr_conv3d_fwd_tile": [C.POINTER(ConvDesc), vp, vp, vp, C.POINTER(Epilogue), vp],
         "wsr_conv3d_dgrad_tile": [C.POINTER(ConvDesc), vp, vp, vp, f32, C.c_int, C.c_int, C.POINTER(LreluMask),
@@ -140,7 +144,7 @@ def lib() -> C.CDLL:
     L.wsr_frag_filter_elems.restype = C.c_int64
     L.wsr_physics_loss_workspace_floats.argtypes = []
     L.wsr_physics_loss_workspace_floats.restype = C.c_int64
-    if L.wsr_abi_version() != 7:
+    if L.wsr_abi_version() != 8:
         raise RuntimeError("libwindsr_hip.so ABI version mismatch")
     _lib = L
     return L

@@ -115,6 +115,15 @@ static inline int wsr_env_lookup(WsrEnvCache& c, const char* name) {
 #define WSR_ENV_SET(name) (WSR_ENV_RAW(name) != INT_MIN)
 #define WSR_ENV_INT(name, dflt) (WSR_ENV_SET(name) ? WSR_ENV_RAW(name) : (dflt))
 
+static inline int conv_geom_ok(const wsr_conv_t* c);
+// the same for a conv whose input channels >= c0 live in a second tensor (ABI 8): the window of the FIRST tensor only
+// has to hold channels [0, c0)
+static inline int conv_geom_ok_split(const wsr_conv_t* c, int c0) {
+  if (!c || c0 <= 0 || c0 >= c->Cin) return 0;
+  wsr_conv_t t = *c;
+  t.Cin = c0;
+  return conv_geom_ok(&t);
+}
 static inline int conv_geom_ok(const wsr_conv_t* c) {
   if (!c) return 0;
   if (c->B <= 0 || c->Xi <= 0 || c->Yi <= 0 || c->Zi <= 0 || c->Xo <= 0 || c->Yo <= 0 || c->Zo <= 0) return 0;

@@ -410,6 +410,10 @@ static int run_conv_tile(CtArgs& a, int red, hipStream_t st) {
   const int ck = 4 * epp / tpk;
   a.nchunks = (red + ck - 1) / ck;
   a.cin_valid = red;
+  if (a.in2) {  // the entry point left the first channel of the second tensor here
+    if (a.in2_chunk % ck) return WSR_EUNSUPPORTED;
+    a.in2_chunk /= ck;
+  }
   {
     static void* zp = nullptr;
     if (!zp) {
@@ -455,9 +459,34 @@ int wsr_conv_thin3(const unsigned short* in, int in_ctot, int in_off, int red, c
                    unsigned short* out, int out_ctot, int out_off, int n_out, int B, int X, int Y, int Z, const float* bias,
                    float alpha, int act, float slope, hipStream_t st);
 
+// the instantiations that take a two-tensor concat (CtArgs.in2 / out2) serve this many produced channels of this dtype
+static bool split_width_ok(int n, bool f32, int red, int taps, long vox) {
+  if (f32) return n > 128 && n <= 144 && !WSR_ENV_SET("WSR_NO_F32_TILE");
+  const int tpk = ct_tpk(red, taps, 8);
+  const long nch = (red + 32 / tpk - 1) / (32 / tpk);
+  return n == 144 && nch * taps >= 256 && vox >= 128L * 512;  // (dispatch_ct: smaller volumes run the 128-voxel tiles)
+}
+
+extern "C" int wsr_conv_split_ok(const wsr_conv_t* c, int32_t c0) {
+  if (!conv_geom_ok_split(c, c0) || WSR_ENV_SET("WSR_NO_SPLIT_CAT")) return 0;
+  if ((c->sx | c->sy | c->sz) != 1 || c->upsample_xy || c->lat) return 0;
+  const bool f32 = c->dtype == WSR_F32;
+  const int taps = c->KX * c->KY * c->KZ, epp = f32 ? 4 : 8;
+  if (taps == 1 || taps > 125 || c->KX > 8 || c->KY > 8 || c->KZ > 8) return 0;
+  if (c->Cin % epp || c->Cout % epp || c->in_ctot % epp || c->in_off % epp || c->out_ctot % epp || c->out_off % epp) return 0;
+  if (c0 % 128) return 0;  // whole reduction chunks / n-tiles / c-chunks of every kernel involved (16 .. 128 channels)
+  const long vox_o = (long)c->B * c->Xo * c->Yo * c->Zo, vox_i = (long)c->B * c->Xi * c->Yi * c->Zi;
+  // forward: produced width Cout, reduction Cin; input gradient: produced width Cin, reduction Cout
+  return split_width_ok(c->Cout, f32, c->Cin, taps, vox_o) && split_width_ok(c->Cin, f32, c->Cout, taps, vox_i) ? 1 : 0;
+}
+
 extern "C" int wsr_conv3d_fwd_tile(const wsr_conv_t* c, const void* x, const void* wfrag, void* y,
                                    const wsr_epilogue_t* ep, void* stream) {
-  if (!conv_geom_ok(c) || !x || !wfrag || !y) return WSR_EINVAL;
+  const bool two = ep && ep->in2;
+  if (!(two ? conv_geom_ok_split(c, ep->in2_c0) : conv_geom_ok(c)) || !x || !wfrag || !y) return WSR_EINVAL;
+  if (two && (ep->in2_ctot <= 0 || c->Cin - ep->in2_c0 > ep->in2_ctot || c->KX * c->KY * c->KZ == 1 || c->lat ||
+              c->upsample_xy || (c->sx | c->sy | c->sz) != 1))
+    return two && (ep->in2_ctot <= 0 || c->Cin - ep->in2_c0 > ep->in2_ctot) ? WSR_EINVAL : WSR_EUNSUPPORTED;
   if (c->sx > 2 || c->sy > 2 || c->sz > 2 || c->lat == 3) return WSR_EUNSUPPORTED;
   if ((c->sx | c->sy | c->sz) != 1 && (c->upsample_xy || WSR_ENV_SET("WSR_CT_NOSTRIDE"))) return WSR_EUNSUPPORTED;
   const bool f32 = c->dtype == WSR_F32;
@@ -487,6 +516,11 @@ extern "C" int wsr_conv3d_fwd_tile(const wsr_conv_t* c, const void* x, const voi
     if (a.res && (a.res_off < 0 || a.res_off + c->Cout > a.res_ctot)) return WSR_EINVAL;
     a.ws = ep->ws;
     a.ws_bytes = (long)ep->ws_bytes;
+    if (two) {  // (in2_chunk holds the channel count until run_conv_tile knows the chunk size)
+      a.in2 = (const unsigned short*)ep->in2;
+      a.in2_ctot = ep->in2_ctot;
+      a.in2_chunk = ep->in2_c0;
+    }
     if (ep->mask) {  // LeakyReLU-backward mask on a forward-form launch (parity input gradients of strided convs)
       const wsr_lrelu_mask_t* mk = ep->mask;
       if (!mk->y || ep->out_planar || mk->c0 < 0 || mk->c1 > c->Cout || mk->c0 >= mk->c1 || mk->c0 % 4 || mk->y_ctot % 4 ||
@@ -524,6 +558,7 @@ extern "C" int wsr_conv3d_fwd_tile(const wsr_conv_t* c, const void* x, const voi
     if (rc != WSR_EUNSUPPORTED) return rc;
   }
   if (ep && ep->res2) return WSR_EUNSUPPORTED;  // only the streaming kernel takes a second residual
+  if (two) return run_conv_tile(a, c->Cin, as_stream(stream));  // (the halo-tile kernel's 9-n-tile instantiations only)
   // thin z-tapless conv with a planar fp32 result (the z-folded last conv): sliding-window kernel
   const bool no_slide = WSR_ENV_SET("WSR_NO_SLIDE");  // tuning / A-B switch
   if (!f32 && !no_slide && c->KZ == 1 && c->Cout <= 16 && a.out_planar && !a.chan_scale && !a.res && a.act == 0 && !a.ups &&
@@ -547,8 +582,13 @@ extern "C" int wsr_conv3d_fwd_tile(const wsr_conv_t* c, const void* x, const voi
 extern "C" int wsr_conv3d_dgrad_tile(const wsr_conv_t* c, const void* dy, const void* wfrag_t, void* dx, float alpha,
                                      int accumulate, int dx_planar, const wsr_lrelu_mask_t* mask,
                                      const wsr_dgrad_opts_t* opts, void* stream) {
-  if (!conv_geom_ok(c) || !dy || !wfrag_t || !dx) return WSR_EINVAL;
+  const bool two = opts && opts->dx2;
+  if (!(two ? conv_geom_ok_split(c, opts->dx2_c0) : conv_geom_ok(c)) || !dy || !wfrag_t || !dx) return WSR_EINVAL;
   if (opts && opts->acc_src && !accumulate) return WSR_EINVAL;
+  if (two) {
+    if (opts->dx2_ctot <= 0 || c->Cin - opts->dx2_c0 > opts->dx2_ctot) return WSR_EINVAL;
+    if (accumulate || dx_planar || mask || c->lat || c->upsample_xy || c->KX * c->KY * c->KZ == 1) return WSR_EUNSUPPORTED;
+  }
   if (mask && (!mask->y || dx_planar || mask->c0 < 0 || mask->c1 > c->Cin || mask->c0 >= mask->c1 ||
                mask->c0 % 4 || mask->y_ctot % 4 || mask->y_off % 4 ||
                mask->y_off + (mask->c1 - mask->c0) > mask->y_ctot))
@@ -604,6 +644,12 @@ extern "C" int wsr_conv3d_dgrad_tile(const wsr_conv_t* c, const void* dy, const 
     if (rc != WSR_EUNSUPPORTED) return rc;
   }
   if (res2) return WSR_EUNSUPPORTED;  // only the streaming kernel takes a second residual
+  if (two) {  // the gradient of a two-tensor concat: channels >= dx2_c0 leave for the second tensor
+    a.out2 = opts->dx2;
+    a.out2_ctot = opts->dx2_ctot;
+    a.out2_c0 = opts->dx2_c0;
+    return run_conv_tile(a, c->Cout, as_stream(stream));
+  }
   // z-tapless conv with a thin output side and the mask of the layer below (the z-folded last conv): sliding window
   const bool no_slide = WSR_ENV_SET("WSR_NO_SLIDE");  // tuning / A-B switch
   if (!f32 && !no_slide && mask && c->KZ == 1 && c->Cout <= 16 && !accumulate && !dx_planar && !c->lat && ux == 1 && c->pz == 0 &&

@@ -93,6 +93,14 @@ struct CtArgs {
   // take the next chunk; the rest is issued when the next chunk starts, whose first stage (kx = 0 only) reads planes
   // < TX.  xs_stage < 0: off (the whole image is reloaded between chunks behind an exposed wait + barrier).
   int xs_stage, xs_units;
+  // The gathered tensor in TWO parts (wsr_epilogue_t.in2: the generator's concat in front of the 5x5x5 conv): reduction
+  // chunks >= in2_chunk come from channels [0, ...) of in2 (in2_ctot channels per voxel).  And its mirror image for the
+  // input gradient (wsr_dgrad_opts_t.dx2): produced channels >= out2_c0 go to channels [0, ...) of out2.  TN = 9
+  // instantiations only (ct_two_src): the others never look at these fields.
+  const unsigned short* in2;
+  int in2_ctot, in2_chunk;
+  void* out2;
+  int out2_ctot, out2_c0;
   int f32;     // 1: fp32 operands (the element type of in / wf / res / mask_y / out; see the kernel's T)
   int prio;    // 1: waves of the second half of the workgroup run the main loop at s_setprio 1 (tuning switch)
   int ablate;  // -DWSR_CT_STAMPS builds, timing only: skip 1 = activation prefetch, 2 = weight prefetch, 4 = LDS reads, 8 = MFMAs; 32 = paired 16-byte epilogue stores
@@ -135,6 +143,9 @@ __device__ __forceinline__ void dma_wait() { asm volatile("s_waitcnt vmcnt(0)" :
 __device__ __forceinline__ unsigned fdiv(unsigned n, unsigned d, unsigned mg) { return d == 1 ? n : __umulhi(n, mg); }
 static inline unsigned fdiv_magic(int d) { return d <= 1 ? 0u : (unsigned)(((1ull << 32) + d - 1) / d); }
 
+// instantiations that take the gathered / produced tensor in two parts (CtArgs.in2 / out2): the 512-voxel 9-n-tile
+// workgroups of the 5x5x5 144 -> 144 conv - everywhere else the extra address arithmetic would be paid for nothing
+constexpr bool ct_two_src(int wn, int tn) { return wn == 1 && tn == 9; }
 // activation DMA units (1 KB) a wave may have to issue per chunk: registers of the resolved source offsets
 constexpr int ct_xk(int waves, int tm) { return waves <= 4 ? 16 : (tm <= 2 ? 13 : 10); }
 
@@ -179,6 +190,7 @@ void conv_tile_kernel(const CtArgs a) {
   constexpr int PL = 4 / TPK;      // pieces (bf16: channel octets) per chunk and voxel
   constexpr int CK = EPP * PL;     // channels per chunk
   constexpr int NTW = WN * TN;     // n-tiles per workgroup
+  constexpr bool TWO = ct_two_src(WN, TN);  // this instantiation reads a two-tensor concat / writes a two-tensor gradient
   constexpr bool STAGGER = true;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int t = threadIdx.x, lane = t & 63;
@@ -270,7 +282,8 @@ void conv_tile_kernel(const CtArgs a) {
   const int gx_lo = max(x0 * a.sx - ppx, 0) >> U;  // first stored x-plane of the halo
   const long vox_base = ((long)b * a.Xi + gx_lo) * a.il_m * ((long)a.Yi * a.il_m) * a.Zi;
   const E* in_base = reinterpret_cast<const E*>(a.in) + vox_base * a.in_ctot;
-  unsigned xoff[XK];
+  const E* in2_base = TWO && a.in2 ? reinterpret_cast<const E*>(a.in2) + vox_base * a.in2_ctot : nullptr;
+  unsigned xoff[XK];  // element offset of the lane's voxel + window + piece (TWO: the voxel index; the rest per issue)
   int xo8[VM ? 1 : XK], xdst[VM ? 1 : XK];  // voxel-major rows: octet = lane & 1, unit u lands at u KB
 #pragma unroll
   for (int k = 0; k < XK; ++k) {
@@ -296,7 +309,7 @@ void conv_tile_kernel(const CtArgs a) {
           // 32-bit arithmetic on the voxel index relative to plane gx_lo (the host checked the halo's extent)
           const unsigned vox = ((((unsigned)((gx >> U) - gx_lo)) * a.il_m + a.il_ox) * (a.Yi * a.il_m) +
                                 (gy >> U) * a.il_m + a.il_oy) * a.Zi + gz;
-          off = vox * (unsigned)a.in_ctot + (unsigned)(a.in_off + EPP * pl);
+          off = TWO ? vox : vox * (unsigned)a.in_ctot + (unsigned)(a.in_off + EPP * pl);
         }
       }
     }
@@ -315,7 +328,17 @@ void conv_tile_kernel(const CtArgs a) {
       const int u = wave + WAVES * k;
       if (u >= u0 && u < u1) {
         const bool ok = xoff[k] != 0xFFFFFFFFu && (chunk + c_begin) * CK + xo8[VM ? 0 : k] < a.cin_valid;
-        const E* src = ok ? in_base + (size_t)xoff[k] + (chunk + c_begin) * CK : reinterpret_cast<const E*>(a.zero16);
+        const E* src;
+        if constexpr (TWO) {  // (uniform choice of the tensor per chunk; the offsets are rebuilt from the voxel index)
+          const int cg = chunk + c_begin;
+          const bool second = in2_base != nullptr && cg >= a.in2_chunk;
+          const E* bp = second ? in2_base : in_base;
+          const unsigned ct = second ? (unsigned)a.in2_ctot : (unsigned)a.in_ctot;
+          const unsigned co = second ? (unsigned)((cg - a.in2_chunk) * CK) : (unsigned)(a.in_off + cg * CK);
+          src = ok ? bp + (size_t)(xoff[k] * ct + co + (unsigned)xo8[VM ? 0 : k]) : reinterpret_cast<const E*>(a.zero16);
+        } else {
+          src = ok ? in_base + (size_t)xoff[k] + (chunk + c_begin) * CK : reinterpret_cast<const E*>(a.zero16);
+        }
         glds16(src, dst + (VM ? u * 1024 : xdst[VM ? 0 : k]));
       }
     }
@@ -644,6 +667,12 @@ void conv_tile_kernel(const CtArgs a) {
           }
         }
 #endif
+        if constexpr (TWO) {
+          if (a.out2 && co0 >= a.out2_c0) {  // (uniform) this n-tile belongs to the second tensor of the concat's gradient
+            st4<T>(reinterpret_cast<E*>(a.out2) + mrow[i] * a.out2_ctot + (co0 - a.out2_c0), o4);
+            continue;
+          }
+        }
         st4<T>(orow[i] + 16 * j, o4);
         continue;
       }
@@ -688,6 +717,16 @@ int launch_ct(CtArgs& a, hipStream_t st) {
   const int taps = a.KX * a.KY * a.KZ;
   constexpr int M = WM * TM * 16;  // table sizes follow the MFMA rows; the tile volume may be smaller
   if (a.TX * a.TY * a.TZ > M) return WSR_EUNSUPPORTED;
+  if (a.in2 || a.out2) {  // two-tensor concat (wsr_epilogue_t.in2 / wsr_dgrad_opts_t.dx2): the 9-n-tile instantiations only
+    constexpr int CKH = T::EPP * (4 / TPK);
+    if (!ct_two_src(WN, TN) || a.ups || a.nphase == 4) return WSR_EUNSUPPORTED;
+    if (a.in2 && (a.in2_ctot % T::EPP || a.in2_chunk < 1 || a.in2_chunk * CKH >= a.cin_valid)) return WSR_EINVAL;
+    if (a.out2 && (a.out_planar || !a.vec_ok || (a.Cout & 3) || a.res || a.mask_y || (a.out2_c0 & 15) || (a.out2_ctot & 3) ||
+                   a.out2_c0 <= 0 || a.out2_c0 >= a.Cout || a.Cout - a.out2_c0 > a.out2_ctot))
+      return WSR_EUNSUPPORTED;
+    a.ws = nullptr;  // (never split: the split-reduction pass knows one produced tensor)
+    a.ws_bytes = 0;
+  }
   if (a.sx < 1) a.sx = a.sy = a.sz = 1;
   if (a.il_m < 1) a.il_m = 1;
   if (a.ol_m < 1) a.ol_m = 1;

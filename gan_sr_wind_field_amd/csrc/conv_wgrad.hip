@@ -250,23 +250,28 @@ int dispatch_wgrad(WgradArgs& a, hipStream_t st, int* plan, int n_parts) {
 }  // namespace
 
 int wsr_wgrad_tile_bf16(const wsr_conv_t* c, const void* x, const void* dy, float* dw, int tri_base, int tri_step,
-                        long part_stride, int n_parts, int* plan, void* stream);  // conv_wgrad_tile.hip
+                        long part_stride, int n_parts, int* plan, void* stream, const void* x2, int x2_ctot,
+                        int x2_c0);  // conv_wgrad_tile.hip
 
 int wsr_wgrad_tile_f32(const wsr_conv_t* c, const void* x, const void* dy, float* dw, long part_stride, int n_parts,
-                       int* plan, void* stream);  // conv_wgrad_tile_f32.hip
+                       int* plan, void* stream, const void* x2, int x2_ctot, int x2_c0);  // conv_wgrad_tile_f32.hip
 
 // shared body: accumulate (part_stride = 0), deterministic parts (part_stride > 0) or plan only (plan != nullptr)
+// x2 != NULL: the input's channels >= x2_c0 live in a second tensor (tile kernels only)
 static int wgrad_any(const wsr_conv_t* c, const void* x, const void* dy, float* dw, int tri_base, int tri_step,
-                     long part_stride, int n_parts, int* plan, void* stream) {
+                     long part_stride, int n_parts, int* plan, void* stream, const void* x2 = nullptr, int x2_ctot = 0,
+                     int x2_c0 = 0) {
   {  // stride-1 bf16 convs: LDS-tile kernel (x / dy read once per tile, not per tap)
-    const int rc = wsr_wgrad_tile_bf16(c, x, dy, dw, tri_base, tri_step, part_stride, n_parts, plan, stream);
+    const int rc = wsr_wgrad_tile_bf16(c, x, dy, dw, tri_base, tri_step, part_stride, n_parts, plan, stream, x2, x2_ctot,
+                                       x2_c0);
     if (rc != WSR_EUNSUPPORTED || tri_step > 0) return rc;
   }
   if (c->lat) return WSR_EUNSUPPORTED;  // parity convs of the sub-pixel form: tile kernels only
   if (c->dtype == WSR_F32 && tri_step == 0) {  // stride-1 fp32 convs: LDS-tile kernel (all taps per workgroup)
-    const int rc = wsr_wgrad_tile_f32(c, x, dy, dw, part_stride, n_parts, plan, stream);
+    const int rc = wsr_wgrad_tile_f32(c, x, dy, dw, part_stride, n_parts, plan, stream, x2, x2_ctot, x2_c0);
     if (rc != WSR_EUNSUPPORTED) return rc;
   }
+  if (x2) return WSR_EUNSUPPORTED;  // the per-tap kernel reads one tensor
   const int epp = c->dtype == WSR_BF16 ? 8 : 4;
   if (c->Cin % epp || c->in_ctot % epp || c->in_off % epp) return WSR_EUNSUPPORTED;
   if (c->out_ctot % epp || c->out_off % epp) return WSR_EUNSUPPORTED;
@@ -314,4 +319,11 @@ extern "C" int wsr_conv3d_wgrad_parts(const wsr_conv_t* c, const void* x, const 
   if (!conv_geom_ok(c) || !x || !dy || !parts || tri_base < 0 || tri_step < 0 || n_parts <= 0) return WSR_EINVAL;
   if (part_stride < (int64_t)c->Cout * c->KX * c->KY * c->KZ * c->Cin) return WSR_EINVAL;
   return wgrad_any(c, x, dy, parts, tri_base, tri_step, (long)part_stride, n_parts, nullptr, stream);
+}
+
+extern "C" int wsr_conv3d_wgrad_parts_x2(const wsr_conv_t* c, const void* x, const void* x2, int32_t x2_ctot, int32_t x2_c0,
+                                         const void* dy, float* parts, int64_t part_stride, int32_t n_parts, void* stream) {
+  if (!conv_geom_ok_split(c, x2_c0) || !x || !x2 || !dy || !parts || n_parts <= 0 || x2_ctot <= 0) return WSR_EINVAL;
+  if (part_stride < (int64_t)c->Cout * c->KX * c->KY * c->KZ * c->Cin) return WSR_EINVAL;
+  return wgrad_any(c, x, dy, parts, 0, 0, (long)part_stride, n_parts, nullptr, stream, x2, x2_ctot, x2_c0);
 }

@@ -40,6 +40,8 @@ typedef s16x4_t __attribute__((address_space(3))) * lds_s16x4_ptr;
 
 struct WgtArgs {
   const unsigned short* x;
+  const unsigned short* x2;    // input channels >= x2_c0 come from channels [0, ...) of this tensor (x2_ctot per voxel): the
+  int x2_ctot, x2_c0;          // generator's concat as two tensors (wsr_conv3d_wgrad_parts_x2); NULL = one tensor
   const unsigned short* dy;
   float* dw;
   const void* zero16;
@@ -161,6 +163,11 @@ __global__ __launch_bounds__(512) void wgrad_tile_kernel(const WgtArgs a) {
     s0 = bid / a.n_chunks;
   }
   const int c0 = cc * 16 * CT, n0 = nc * 16 * TN;
+  // the tensor this workgroup's c-chunk lives in (uniform; the host made x2_c0 a multiple of the chunk)
+  const bool second = a.x2 != nullptr && c0 >= a.x2_c0;
+  const unsigned short* xt = second ? a.x2 : a.x;
+  const int x_ctot = second ? a.x2_ctot : a.in_ctot;
+  const int x_off = second ? c0 - a.x2_c0 : a.in_off + c0;
 
   // block-triangular structure: n-tile i is needed iff c0 < tri_base + tri_step*conv(n)
   bool act[TN];
@@ -209,7 +216,7 @@ __global__ __launch_bounds__(512) void wgrad_tile_kernel(const WgtArgs a) {
         const int hy = qq % Ly, hx = qq / Ly;
         geo = hx | (hy << 8) | (hz << 16) | (1u << 24);
         rel = ((((hx + parx) >> U) * a.xl_m * (a.Yi * a.xl_m) + ((hy + pary) >> U) * a.xl_m) * (a.Zi * a.xl_mz) +
-               hz * a.xl_mz) * a.in_ctot + 8 * ch8;
+               hz * a.xl_mz) * x_ctot + 8 * ch8;
       }
     }
     xgeo[k] = geo;
@@ -253,8 +260,8 @@ __global__ __launch_bounds__(512) void wgrad_tile_kernel(const WgtArgs a) {
       // (xl_m = xl_mz = 1 unless the input sits on a lattice; then U = 0)
       const long base = ((((long)b * a.Xi * a.xl_m + (long)((x0 - a.px - parx) >> U) * a.xl_m + a.xl_ox) * (a.Yi * a.xl_m) +
                           (long)((y0 - a.py - pary) >> U) * a.xl_m + a.xl_oy) * (a.Zi * a.xl_mz) +
-                         (long)(z0 - a.pz) * a.xl_mz + a.xl_oz) * a.in_ctot + a.in_off + c0;
-      const unsigned short* bp = a.x + base;
+                         (long)(z0 - a.pz) * a.xl_mz + a.xl_oz) * x_ctot + x_off;
+      const unsigned short* bp = xt + base;
 #pragma unroll
       for (int k = 0; k < XK; ++k) {
         const int u = wave + WAVES * k;
@@ -555,6 +562,7 @@ int launch_tile(WgtArgs& a, hipStream_t st) {
   constexpr int WAVES = 8;
   const int taps = a.KX * a.KY * a.KZ;
   if (taps * CT > WAVES * SPW) return WSR_EUNSUPPORTED;
+  if (a.x2 && a.x2_c0 % (16 * CT)) return WSR_EUNSUPPORTED;  // a workgroup's c-chunk lives in ONE of the two tensors
   {
     static void* zp = nullptr;
     if (!zp) {
@@ -675,8 +683,11 @@ int run_tile(WgtArgs& a, int taps, int Cout, int Cin, hipStream_t st);
 // part_stride > 0: deterministic form with n_parts (as returned by a plan call) split copies; plan != nullptr: only
 // report the number of spatial splits (*plan) the launch would use.
 int wsr_wgrad_tile_bf16(const wsr_conv_t* c, const void* x, const void* dy, float* dw, int tri_base, int tri_step,
-                        long part_stride, int n_parts, int* plan, void* stream) {
+                        long part_stride, int n_parts, int* plan, void* stream, const void* x2, int x2_ctot, int x2_c0) {
   if (c->dtype != WSR_BF16 || (c->sx | c->sy | c->sz) != 1) return WSR_EUNSUPPORTED;
+  if (x2 && (c->lat || c->upsample_xy || tri_step > 0 || x2_c0 <= 0 || x2_c0 >= c->Cin || x2_c0 % 32 || x2_ctot % 8 ||
+             c->Cin - x2_c0 > x2_ctot))
+    return WSR_EUNSUPPORTED;
   if (c->lat == 2 && (c->lat_phases || c->lat_mz > 1 || tri_step > 0)) return WSR_EUNSUPPORTED;  // one parity per launch
   if (c->lat == 3 && (c->lat_phases || tri_step > 0 || c->upsample_xy)) return WSR_EUNSUPPORTED;
   const int taps = c->KX * c->KY * c->KZ;
@@ -687,6 +698,7 @@ int wsr_wgrad_tile_bf16(const wsr_conv_t* c, const void* x, const void* dy, floa
   if (c->KX > 8 || c->KY > 8 || c->KZ > 8) return WSR_EUNSUPPORTED;
   WgtArgs a{};
   a.x = (const unsigned short*)x;
+  a.x2 = (const unsigned short*)x2; a.x2_ctot = x2_ctot; a.x2_c0 = x2_c0;
   a.dy = (const unsigned short*)dy;
   a.dw = dw;
   a.B = c->B; a.Xi = c->Xi; a.Yi = c->Yi; a.Zi = c->Zi;

@@ -20,6 +20,8 @@ namespace {
 
 struct WgfArgs {
   const float* x;
+  const float* x2;              // input channels >= x2_c0 come from channels [0, ...) of this tensor (x2_ctot per voxel), or NULL
+  int x2_ctot, x2_c0;
   const float* dy;
   float* dw;
   const void* zero16;
@@ -65,6 +67,11 @@ __global__ __launch_bounds__(512) void wgrad_tile_f32_kernel(const WgfArgs a) {
   const int s0 = bid / a.n_chunks;
   const int c0 = cc * 16 * CT, n0 = nc * 16 * TN;
   const int U = a.ups ? 1 : 0;
+  // the tensor this workgroup's c-chunk lives in (wsr_conv3d_wgrad_parts_x2: the generator's concat as two tensors)
+  const bool second = a.x2 != nullptr && c0 >= a.x2_c0;
+  const float* xt = second ? a.x2 : a.x;
+  const int x_ctot = second ? a.x2_ctot : a.in_ctot;
+  const int x_off = second ? c0 - a.x2_c0 : a.in_off + c0;
 
   // ---- DMA of one tile: x image [c-tile][halo voxel][64 B], dy image [n-tile][voxel][64 B] -----------------------
   // 1 KB units of 16 rows x 4 pieces; the geometry is resolved per tile (a tile is tens of microseconds of fp32
@@ -90,7 +97,7 @@ __global__ __launch_bounds__(512) void wgrad_tile_f32_kernel(const WgfArgs a) {
         const int hy = qq % Ly, hx = qq / Ly;
         const int gx = x0 - a.px + hx, gy = y0 - a.py + hy, gz = z0 - a.pz + hz;
         if ((unsigned)gx < (unsigned)(a.Xi << U) && (unsigned)gy < (unsigned)(a.Yi << U) && (unsigned)gz < (unsigned)a.Zi)
-          src = a.x + ((((long)b * a.Xi + (gx >> U)) * a.Yi + (gy >> U)) * a.Zi + gz) * a.in_ctot + a.in_off + c;
+          src = xt + ((((long)b * a.Xi + (gx >> U)) * a.Yi + (gy >> U)) * a.Zi + gz) * x_ctot + x_off + 16 * ct + 4 * pc;
       }
       wgf_glds16(src, __builtin_amdgcn_readfirstlane(dstx + ct * a.xp_bytes + (u - ct * XUP) * 1024));
     }
@@ -269,8 +276,10 @@ int launch_wgf(WgfArgs& a, int n_parts, int* plan, hipStream_t st) {
 // WSR_EUNSUPPORTED: shape outside this kernel (strided / lattice convs, ragged channel windows) - the caller falls back
 // to the per-tap kernel.  part_stride / n_parts / plan as in wsr_wgrad_tile_bf16.
 int wsr_wgrad_tile_f32(const wsr_conv_t* c, const void* x, const void* dy, float* dw, long part_stride, int n_parts,
-                       int* plan, void* stream) {
+                       int* plan, void* stream, const void* x2, int x2_ctot, int x2_c0) {
   if (c->dtype != WSR_F32 || (c->sx | c->sy | c->sz) != 1 || c->lat) return WSR_EUNSUPPORTED;
+  if (x2 && (c->upsample_xy || x2_c0 <= 0 || x2_c0 >= c->Cin || x2_c0 % 128 || x2_ctot % 4 || c->Cin - x2_c0 > x2_ctot))
+    return WSR_EUNSUPPORTED;  // (x2_c0 a multiple of every instantiation's c-chunk: 16 .. 128 channels)
   const int taps = c->KX * c->KY * c->KZ;
   if (taps > 128) return WSR_EUNSUPPORTED;
   if (c->Cin % 4 || c->in_ctot % 4 || c->in_off % 4 || c->out_ctot % 4 || c->out_off % 4) return WSR_EUNSUPPORTED;
@@ -278,6 +287,7 @@ int wsr_wgrad_tile_f32(const wsr_conv_t* c, const void* x, const void* dy, float
   if (WSR_ENV_SET("WSR_NO_WGRAD_F32_TILE")) return WSR_EUNSUPPORTED;  // tuning / A-B switch
   WgfArgs a{};
   a.x = (const float*)x; a.dy = (const float*)dy; a.dw = dw;
+  a.x2 = (const float*)x2; a.x2_ctot = x2_ctot; a.x2_c0 = x2_c0;
   a.B = c->B; a.Xi = c->Xi; a.Yi = c->Yi; a.Zi = c->Zi; a.Xo = c->Xo; a.Yo = c->Yo; a.Zo = c->Zo;
   a.Cin = c->Cin; a.in_ctot = c->in_ctot; a.in_off = c->in_off;
   a.Cout = c->Cout; a.out_ctot = c->out_ctot; a.out_off = c->out_off;

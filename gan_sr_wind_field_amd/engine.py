@@ -59,6 +59,13 @@ FOLD_D_MASK = __import__("os").environ.get("WSR_FOLD_D_MASK", "0") != "0"
 # Filter gradient of the z-folded last conv with the operands' roles exchanged (GeneratorProgram.backward): the 16-channel
 # output gradient is the image that is shifted per tap, the 144-channel activation the one that is read once
 SWAP_THIN_WGRAD = __import__("os").environ.get("WSR_THIN_WGRAD_SWAP", "1") != "0"
+#: the generator's concat in front of the 5x5x5 conv (reference Generator_3D_Resnet_ESRGAN.py:228: torch.cat((x, Zf), 1)) as
+#: TWO dense tensors - the last up-conv's nf channels and the terrain branch's tf - that the conv's three kernels read /
+#: write side by side (wsr_epilogue_t.in2, wsr_dgrad_opts_t.dx2, wsr_conv3d_wgrad_parts_x2) where they can
+#: (wsr_conv_split_ok), instead of one (nf + tf)-channel buffer into whose 288-byte voxel rows the terrain conv wrote
+#: 32-byte pieces: partial cache lines, 1.6 x the bytes at the memory side, 0.17-0.27 of the HBM rate on the two
+#: memory-bound launches that touch that window (WSR_SPLIT_CAT=0: the channel window)
+SPLIT_CAT = __import__("os").environ.get("WSR_SPLIT_CAT", "1") != "0"
 POISON_BUFFERS = bool(int(__import__("os").environ.get("WSR_POISON_BUFFERS", "0")))
 #: filter gradients without float atomics: every spatial split of a wgrad launch stores its partial sums to its own
 #: copy and the unpack pass adds the copies in index order - two backward passes give bit-identical gradients
@@ -273,6 +280,10 @@ class ProgramBase:
         self.launch_probe: Optional[Callable[[str, Callable[[], None]], None]] = None
         #: route stride-1 bf16 convs through the LDS halo-tile kernels (False: generic implicit GEMM only)
         self.use_tile = True
+        #: test aid: a list that receives (tag, layer index, copy of the tensor) for every intermediate gradient of a
+        #: backward pass - the layer-by-layer checks of the bf16 path feed each stage's fp32 CPU evaluation with the HIP
+        #: path's OWN operands, so that one stage's rounding (or LeakyReLU branch flips) cannot hide another's error
+        self.trace: Optional[list] = None
         self._arena: Optional[Tensor] = None
         self._arena_off = 0
         self._arena_need = 0
@@ -392,6 +403,8 @@ class ProgramBase:
                 return
             if "res2" in ep:
                 raise RuntimeError("a second residual needs the streaming 1x1x1 kernel")
+            if ep.get("in2") is not None:
+                raise RuntimeError("a two-tensor input needs the tile kernels wsr_conv_split_ok vouched for (set WSR_SPLIT_CAT=0)")
             ops.conv_fwd(d, x, self._w(s), y, bias=bias, **ep)
 
         if self.launch_probe is not None:
@@ -401,7 +414,7 @@ class ProgramBase:
 
     def dgrad(self, s: ConvSite, g: Tensor, g_off: int, dx: Tensor, dx_off: int, in_xyz, *, alpha: float = 1.0,
               accumulate: bool = False, dx_planar: bool = False, mask=None, acc_src: Optional[Tensor] = None,
-              acc_beta: float = 1.0, res2: Optional[Tensor] = None) -> None:
+              acc_beta: float = 1.0, res2: Optional[Tensor] = None, dx2: Optional[Tensor] = None, dx2_c0: int = 0) -> None:
         """dx[window] (+)= alpha * conv^T(g[window]);  in_xyz = stored input extent of the conv.
         ``mask`` = (y, y_off, c0, c1[, chan_scale]): afterwards multiply channels [c0, c1) of the window by the
         LeakyReLU derivative taken from channels [y_off, ...) of ``y`` - and by the Dropout3d keep factors
@@ -416,8 +429,11 @@ class ProgramBase:
             m = None if mask is None else (mask[0], mask[1], mask[2], mask[3], self.slope) + tuple(mask[4:5])
             if self.tile_ok(s) and ops.conv_dgrad_tile(d, g, self.filters.get_frag(s.weight, True), dx, alpha=alpha,
                                                        accumulate=accumulate, dx_planar=dx_planar, mask=m,
-                                                       acc_src=acc_src, acc_beta=acc_beta, res2=res2):
+                                                       acc_src=acc_src, acc_beta=acc_beta, res2=res2, dx2=dx2,
+                                                       dx2_c0=dx2_c0):
                 return
+            if dx2 is not None:
+                raise RuntimeError("a two-tensor input gradient needs the tile kernels (set WSR_SPLIT_CAT=0)")
             if acc_src is not None or res2 is not None or acc_beta != 1.0:
                 raise RuntimeError("accumulating from another buffer needs the tile kernels (set WSR_WGRAD_STREAM=0)")
             if int(accumulate) > 1:
@@ -433,16 +449,22 @@ class ProgramBase:
             run()
 
     def wgrad(self, s: ConvSite, x: Tensor, x_off: int, g: Tensor, g_off: int, flat: Tensor, space: GradSpace,
-              scratch: Tensor, scale: float = 1.0, dst: Optional[Tensor] = None) -> None:
-        """master-layout gradient slot of s.weight (or ``dst``) = scale * wgrad(x[window], g[window])"""
+              scratch: Tensor, scale: float = 1.0, dst: Optional[Tensor] = None, x2: Optional[Tensor] = None,
+              x2_c0: int = 0) -> None:
+        """master-layout gradient slot of s.weight (or ``dst``) = scale * wgrad(x[window], g[window]);
+        ``x2``: the conv's input channels >= ``x2_c0`` live in this second tensor (see SPLIT_CAT)"""
         B = x.shape[0]
         cin_p = self.cp(s.cin)
         d = self._desc(s, B, tuple(x.shape[1:4]), x.shape[-1], x_off, g.shape[-1], g_off, cin=cin_p)
         out = space.view(flat, s.weight) if dst is None else dst
+        if x2 is not None and not DETERMINISTIC:
+            raise RuntimeError("a two-tensor filter gradient needs the deterministic form (set WSR_SPLIT_CAT=0)")
         if DETERMINISTIC:
-            n = self._wgrad_nparts(("w", s.name, B) + tuple(x.shape[1:4]), d)
+            # (the split count is a property of the un-split conv's geometry: asked with the concatenated width)
+            dq = d if x2 is None else self._desc(s, B, tuple(x.shape[1:4]), cin_p, 0, g.shape[-1], g_off, cin=cin_p)
+            n = self._wgrad_nparts(("w", s.name, B) + tuple(x.shape[1:4]), dq)
             parts = self._arena_take(n * s.cout * s.taps * cin_p, x.device).view(n, s.cout, s.taps, cin_p)
-            run = lambda: ops.conv_wgrad_parts(d, x, g, parts, n)  # noqa: E731
+            run = lambda: ops.conv_wgrad_parts(d, x, g, parts, n, x2=x2, x2_c0=x2_c0)  # noqa: E731
             self._pending_unpack.append((parts[0], out, scale, n, parts[0].numel()))
         else:
             dwp = self._arena_take(s.cout * s.taps * cin_p, x.device)
@@ -1090,7 +1112,12 @@ class GeneratorProgram(ProgramBase):
         self.conv(self.lr_conv, t_last, 0, s, 0, res=first, res_off=0, beta=1.0)
         sX, sY = X * (2 ** len(self.ups)), Y * (2 ** len(self.ups))
         cat_c = self.cp(nf + tf)
-        hcat = self._empty((B, sX, sY, nz, cat_c), x, zero=cat_c != nf + tf)
+        tf_p = self.cp(tf)
+        # the concat as two dense tensors where the 5x5x5 conv's kernels read them side by side (SPLIT_CAT)
+        split = bool(SPLIT_CAT and self.ups and DETERMINISTIC and self.tile_ok(self.hr0) and nf + tf == cat_c and tf_p == tf
+                     and ops.conv_split_ok(self._desc(self.hr0, B, (sX, sY, nz), nf, 0, cat_c, 0, cin=cat_c), nf))
+        hcat = self._empty((B, sX, sY, nz, nf if split else cat_c), x, zero=cat_c != nf + tf)
+        tfeat = self._empty((B, sX, sY, nz, tf_p), x) if split else None
         cur = s
         up_io: List[Tuple[Tensor, Tensor]] = []
         for u, site in enumerate(self.ups):
@@ -1104,12 +1131,15 @@ class GeneratorProgram(ProgramBase):
         z_p = self.cp(1)
         z_nd = self._empty((B, sX, sY, nz, z_p), x)
         ops.planar_to_ndhwc(Z, z_nd, 0, z_p)
-        tf_p = self.cp(tf)
         t0 = self._empty((B, sX, sY, nz, tf_p), x, zero=tf_p != tf)
         self.conv(self.terrain0, z_nd, 0, t0, 0, act=True, slope=sl)
-        self.conv(self.terrain1, t0, 0, hcat, nf)
         h = self._empty((B, sX, sY, nz, cat_c), x, zero=cat_c != nf + tf)
-        self.conv(self.hr0, hcat, 0, h, 0, act=True, slope=sl, chan_scale=drop_scale)
+        if split:
+            self.conv(self.terrain1, t0, 0, tfeat, 0)
+            self.conv(self.hr0, hcat, 0, h, 0, act=True, slope=sl, chan_scale=drop_scale, in2=tfeat, in2_c0=nf)
+        else:
+            self.conv(self.terrain1, t0, 0, hcat, nf)
+            self.conv(self.hr0, hcat, 0, h, 0, act=True, slope=sl, chan_scale=drop_scale)
         out = torch.empty((B, self.hr1.cout, sX, sY, nz), dtype=torch.float32, device=x.device)
         if self.zfold_active():
             kz = self.hr1.kernel[2]
@@ -1121,7 +1151,7 @@ class GeneratorProgram(ProgramBase):
             self.conv(self.hr1, h, 0, out, 0, out_planar=True)
         saved = None
         if save:
-            saved = dict(x_nd=x_nd, first=first, bufs=bufs, t_last=t_last, s=s, up_io=up_io, hcat=hcat, z_nd=z_nd,
+            saved = dict(x_nd=x_nd, first=first, bufs=bufs, t_last=t_last, s=s, up_io=up_io, hcat=hcat, tfeat=tfeat, z_nd=z_nd,
                          t0=t0, h=h, drop=drop_scale, lr_xyz=(X, Y, nz), hr_xyz=(sX, sY, nz))
         return out, saved
 
@@ -1191,16 +1221,25 @@ class GeneratorProgram(ProgramBase):
         ready(self.hr1.weight, self.hr1.bias)
         del g3
         # ---- hr0 (k5 + LReLU + Dropout3d mask: already applied to gh above)
-        self.wgrad(self.hr0, hcat, 0, gh, 0, flat, sp, scratch)
+        tfeat = saved.get("tfeat")  # not None: the concat is two tensors (SPLIT_CAT), and so is its gradient
         ghcat = self._empty(hcat.shape, g_out)
-        self.dgrad(self.hr0, gh, 0, ghcat, 0, (sX, sY, nz))
+        if tfeat is not None:
+            gtf = self._empty(tfeat.shape, g_out)
+            self.wgrad(self.hr0, hcat, 0, gh, 0, flat, sp, scratch, x2=tfeat, x2_c0=nf)
+            self.dgrad(self.hr0, gh, 0, ghcat, 0, (sX, sY, nz), dx2=gtf, dx2_c0=nf)
+            gt_src, gt_off = gtf, 0
+        else:
+            self.wgrad(self.hr0, hcat, 0, gh, 0, flat, sp, scratch)
+            self.dgrad(self.hr0, gh, 0, ghcat, 0, (sX, sY, nz))
+            gt_src, gt_off = ghcat, nf
         ready(self.hr0.weight)
         del gh
         # ---- terrain branch (channels nf.. of the concat)
         t0, z_nd = saved["t0"], saved["z_nd"]
-        self.wgrad(self.terrain1, t0, 0, ghcat, nf, flat, sp, scratch)
+        self.wgrad(self.terrain1, t0, 0, gt_src, gt_off, flat, sp, scratch)
         gt0 = self._empty(t0.shape, g_out)
-        self.dgrad(self.terrain1, ghcat, nf, gt0, 0, (sX, sY, nz))
+        self.dgrad(self.terrain1, gt_src, gt_off, gt0, 0, (sX, sY, nz))
+        del gt_src
         ops.lrelu_bwd_(gt0, 0, t0, 0, t0.shape[-1], sl)
         self.wgrad(self.terrain0, z_nd, 0, gt0, 0, flat, sp, scratch)
         ready(self.terrain1.weight, self.terrain0.weight)
@@ -1812,6 +1851,8 @@ class DiscriminatorProgram(ProgramBase):
             s = l.conv
             C_ = s.cout
             act_o = r["a"][lo:]
+            if self.trace is not None:
+                self.trace.append(("g", li, g.clone()))
             if l.bn is None:
                 if l.act and not premasked:
                     ops.lrelu_bwd_(g, 0, act_o, 0, g.shape[-1], sl)
@@ -1869,6 +1910,8 @@ class DiscriminatorProgram(ProgramBase):
                             sp.view(flat, bn.bias).copy_(sums[:C_])
                             sp.view(flat, bn.weight).copy_(sums[C_:])
                         ops.bn_bwd_apply(g, y_o, gy, mean, invstd, bn.weight.detach(), None, 0.0)
+            if self.trace is not None:
+                self.trace.append(("gy", li, gy.clone()))
             inp = r["inp"][lo:]
             lattice_ok = (li in self.dparity and tuple(inp.shape[1:3]) == (2 * gy.shape[1], 2 * gy.shape[2])
                           and inp.shape[3] == s.stride[2] * gy.shape[3] and inp.shape[-1] == self.cp(s.cin))
@@ -1891,6 +1934,8 @@ class DiscriminatorProgram(ProgramBase):
                                        if premasked else None)
                 else:
                     self.dgrad(s, gy, 0, gin, 0, tuple(inp.shape[1:4]))
+                if self.trace is not None:
+                    self.trace.append(("gin", li, gin.clone()))
                 g = gin
             elif need_dx:
                 dx = torch.empty((inp.shape[0],) + tuple(saved["in_shape"][1:]), dtype=torch.float32, device=dev)

@@ -187,7 +187,8 @@ def conv_fwd_tile(desc: ConvDesc, x: Tensor, wfrag: Tensor, y: Tensor, *, bias: 
                   chan_scale: Optional[Tensor] = None, res: Optional[Tensor] = None, res_off: int = 0,
                   alpha: float = 1.0, beta: float = 0.0, act=False, slope: float = 0.2,
                   out_planar: bool = False, act_c1: int = 0, res2: Optional[Tensor] = None, res2_off: int = 0,
-                  beta2: float = 0.0, use_ws: bool = True, mask=None) -> bool:
+                  beta2: float = 0.0, use_ws: bool = True, mask=None, in2: Optional[Tensor] = None,
+                  in2_c0: int = 0) -> bool:
     """LDS halo-tile forward conv (bf16, stride 1).  Returns False when the shape is outside
     the tile kernels (the caller then uses :func:`conv_fwd`).  ``act`` = 2 / ``act_c1``: the two stages of a
     split dense-block conv (see ``wsr_epilogue_t``)."""
@@ -205,6 +206,11 @@ def conv_fwd_tile(desc: ConvDesc, x: Tensor, wfrag: Tensor, y: Tensor, *, bias: 
         ep.res2, ep.res2_ctot, ep.res2_off, ep.beta2 = _p(res2), res2.shape[-1], res2_off, beta2
     if use_ws:
         ep.ws, ep.ws_bytes = tile_workspace()
+    if in2 is not None:  # reduction channels >= in2_c0 come from this second tensor (wsr_epilogue_t.in2: the concat as two)
+        _need_cuda(in2)
+        if in2.shape[:-1] != x.shape[:-1] or in2.dtype != x.dtype:
+            raise ValueError("in2 must have x's extents and dtype")
+        ep.in2, ep.in2_ctot, ep.in2_c0 = _p(in2), in2.shape[-1], in2_c0
     if mask is not None:  # (y, y_off, c0, c1, slope): LeakyReLU-backward mask on a forward-form launch (wsr_epilogue_t.mask)
         my, my_off, mc0, mc1, mslope = mask
         _need_cuda(my)
@@ -228,7 +234,7 @@ def conv1x1_covers(red: int, n_out: int, masked: bool) -> bool:
 def conv_dgrad_tile(desc: ConvDesc, dy: Tensor, wfrag_t: Tensor, dx: Tensor, *, alpha: float = 1.0,
                     accumulate: bool = False, dx_planar: bool = False, mask=None, acc_src: Optional[Tensor] = None,
                     use_ws: bool = True, acc_beta: float = 1.0, res2: Optional[Tensor] = None, res2_off: int = 0,
-                    beta2: float = 1.0) -> bool:
+                    beta2: float = 1.0, dx2: Optional[Tensor] = None, dx2_c0: int = 0) -> bool:
     """``mask`` = (y, y_off, c0, c1, slope): fold ``leaky_relu_backward`` of produced channels [c0, c1) into
     the epilogue, the mask taken from channels [y_off, y_off + c1 - c0) of the saved output ``y``.
     ``acc_src``: with ``accumulate``, the tensor (same layout as ``dx``) whose values are added instead of dx's own."""
@@ -243,6 +249,11 @@ def conv_dgrad_tile(desc: ConvDesc, dy: Tensor, wfrag_t: Tensor, dx: Tensor, *, 
         opts.res2, opts.res2_ctot, opts.res2_off, opts.beta2 = _p(res2), res2.shape[-1], res2_off, beta2
     if use_ws:
         opts.ws, opts.ws_bytes = tile_workspace()
+    if dx2 is not None:  # produced channels >= dx2_c0 go to this second tensor (wsr_dgrad_opts_t.dx2)
+        _need_cuda(dx2)
+        if dx2.shape[:-1] != dx.shape[:-1] or dx2.dtype != dx.dtype:
+            raise ValueError("dx2 must have dx's extents and dtype")
+        opts.dx2, opts.dx2_ctot, opts.dx2_c0 = _p(dx2), dx2.shape[-1], dx2_c0
     mp = None
     if mask is not None:
         y, y_off, c0, c1, slope = mask[:5]
@@ -364,13 +375,27 @@ def conv_wgrad_nparts(desc: ConvDesc, tri_base: int = 0, tri_step: int = 0) -> i
     return int(n.value)
 
 
+def conv_split_ok(desc: ConvDesc, c0: int) -> bool:
+    """True when the forward, input-gradient and filter-gradient kernels all take this conv with its input channels
+    split at ``c0`` over two tensors (``wsr_conv_split_ok``: host-side query)"""
+    return bool(_lib.lib().wsr_conv_split_ok(C.byref(desc), c0))
+
+
 def conv_wgrad_parts(desc: ConvDesc, x: Tensor, dy: Tensor, parts: Tensor, n_parts: int, tri_base: int = 0,
-                     tri_step: int = 0) -> Tensor:
+                     tri_step: int = 0, x2: Optional[Tensor] = None, x2_c0: int = 0) -> Tensor:
     """Deterministic filter gradient: ``parts`` (n_parts, Cout, taps, Cin) fp32 receives one partial sum per split
-    (plain stores, nothing to zero); :func:`unpack_wgrad_reduce_multi` adds them in order."""
+    (plain stores, nothing to zero); :func:`unpack_wgrad_reduce_multi` adds them in order.  ``x2``: the conv's input
+    channels >= ``x2_c0`` live in this second tensor (``wsr_conv3d_wgrad_parts_x2``)."""
     _need_cuda(x, dy, parts)
     if parts.dtype != torch.float32 or not parts.is_contiguous() or parts.shape[0] != n_parts:
         raise ValueError("conv_wgrad_parts wants a contiguous fp32 (n_parts, Cout, taps, Cin) buffer")
+    if x2 is not None:
+        _need_cuda(x2)
+        if tri_step or x2.shape[:-1] != x.shape[:-1] or x2.dtype != x.dtype:
+            raise ValueError("x2 must have x's extents and dtype (no stacked form)")
+        check(_lib.lib().wsr_conv3d_wgrad_parts_x2(C.byref(desc), _p(x), _p(x2), x2.shape[-1], x2_c0, _p(dy), _p(parts),
+                                                   parts[0].numel(), n_parts, _stream()), "conv3d_wgrad_parts_x2")
+        return parts
     check(_lib.lib().wsr_conv3d_wgrad_parts(C.byref(desc), _p(x), _p(dy), _p(parts), parts[0].numel(), n_parts, tri_base,
                                             tri_step, _stream()), "conv3d_wgrad_parts")
     return parts

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define WSR_ABI_VERSION 7
+#define WSR_ABI_VERSION 8
 
 enum wsr_dtype { WSR_F32 = 0, WSR_BF16 = 1 };
 
@@ -112,7 +112,22 @@ typedef struct wsr_epilogue {
    * that layer's leaky_relu_backward needs no pass of its own.  bf16, <= 32 or 65..224 produced channels
    * (WSR_EUNSUPPORTED otherwise).                                                                           */
   const struct wsr_lrelu_mask* mask;
+  /* ABI 8 (tile entry point only, NULL = none): the conv's input is the channel concatenation of TWO tensors
+   * (torch.cat((x, Zf), 1) of Generator_3D_Resnet_ESRGAN.py:228 in front of hr_convs[0]) WITHOUT the concatenated copy
+   * and without one producer writing 32-byte pieces into the other's 288-byte voxel rows (partial cache lines: 1.6 x
+   * the bytes at the memory side): reduction channels [0, in2_c0) of the conv are read from `x` (window in_off of
+   * in_ctot channels, as always), channels [in2_c0, Cin) from channels [0, Cin - in2_c0) of `in2` (same extents,
+   * in2_ctot channels per voxel, same dtype).  in2_c0 must be a multiple of the kernel's reduction chunk (16 bf16 /
+   * 8 fp32 channels).  Only the 512-voxel 129..144-output tile instantiations (the 5x5x5 144 -> 144 conv) carry it:
+   * WSR_EUNSUPPORTED elsewhere - ask wsr_conv_split_ok first and keep the concatenated buffer when it says no. */
+  const void* in2;
+  int32_t in2_ctot, in2_c0;
 } wsr_epilogue_t;
+
+/* 1 when wsr_conv3d_fwd_tile (wsr_epilogue_t.in2), wsr_conv3d_dgrad_tile (wsr_dgrad_opts_t.dx2) and
+ * wsr_conv3d_wgrad_parts_x2 all take this conv with its input channels split at `c0` into two tensors, else 0
+ * (host-side query, no launch).                                                                              */
+int wsr_conv_split_ok(const wsr_conv_t* c, int32_t c0);
 
 int wsr_abi_version(void);
 const char* wsr_error_string(int code);
@@ -179,6 +194,12 @@ typedef struct wsr_dgrad_opts {
   float beta2;
   const void* res2;
   int32_t res2_ctot, res2_off;
+  /* ABI 8 - the mirror image of wsr_epilogue_t.in2: the input gradient of a conv over a two-tensor concatenation is
+   * written to TWO tensors - produced channels [0, dx2_c0) to dx (window in_off of in_ctot, as always), channels
+   * [dx2_c0, Cin) to channels [0, Cin - dx2_c0) of `dx2` (dx2_ctot channels per voxel).  No accumulate / mask /
+   * planar output with it; same instantiations as in2 (WSR_EUNSUPPORTED elsewhere).                         */
+  void* dx2;
+  int32_t dx2_ctot, dx2_c0;
 } wsr_dgrad_opts_t;
 int wsr_conv3d_dgrad_tile(const wsr_conv_t* c, const void* dy, const void* wfrag_t, void* dx, float alpha,
                           int accumulate, int dx_planar, const wsr_lrelu_mask_t* mask, const wsr_dgrad_opts_t* opts,
@@ -221,6 +242,12 @@ int wsr_conv3d_wgrad(const wsr_conv_t* c, const void* x, const void* dy, float* 
 int wsr_conv3d_wgrad_nparts(const wsr_conv_t* c, int32_t tri_base, int32_t tri_step, int32_t* n_parts);
 int wsr_conv3d_wgrad_parts(const wsr_conv_t* c, const void* x, const void* dy, float* parts, int64_t part_stride,
                            int32_t n_parts, int32_t tri_base, int32_t tri_step, void* stream);
+/* ABI 8 - the same with the conv's input split over two tensors (wsr_epilogue_t.in2): input channels [x2_c0, Cin)
+ * are read from channels [0, Cin - x2_c0) of `x2` (x2_ctot channels per voxel); x2_c0 a multiple of 32.  The
+ * packed [Cout][taps][Cin] image is the un-split conv's.  bf16 / fp32 tile filter-gradient kernels, stride 1, no
+ * lattice (WSR_EUNSUPPORTED otherwise).                                                                        */
+int wsr_conv3d_wgrad_parts_x2(const wsr_conv_t* c, const void* x, const void* x2, int32_t x2_ctot, int32_t x2_c0,
+                              const void* dy, float* parts, int64_t part_stride, int32_t n_parts, void* stream);
 /* Filter gradients of ALL growth convs of a residual dense block in one launch
  * (torch_blocks.py:256-267: conv i reads channels [0, tri_base + i*tri_step) of the
  * dense buffer and writes tri_step channels).  c describes the stacked conv: Cin =

@@ -1375,3 +1375,59 @@ def test_table_adam_equals_torch_adam(hip):
     opt.step()
     sd = opt.state_dict()
     assert float(sd["state"][0]["step"]) == 9.0 and float(sd["state"][2]["step"]) == 7.0
+
+
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float32], ids=["bf16", "fp32"])
+def test_concat_as_two_tensors_equals_the_concatenated_conv(hip, dt):
+    """ABI 8 - the generator's concat in front of its 5x5x5 conv (reference Generator_3D_Resnet_ESRGAN.py:228,
+    torch.cat((x, Zf), 1): 128 up-conv channels + 16 terrain channels) as TWO tensors: forward (wsr_epilogue_t.in2),
+    input gradient (wsr_dgrad_opts_t.dx2) and filter gradient (wsr_conv3d_wgrad_parts_x2) must equal the same kernels
+    on the concatenated buffer BIT FOR BIT (same products, same order - only the addresses differ), at the tile
+    geometry of the benchmark (512-voxel tiles, 9 n-tiles); shapes the two-tensor kernels do not serve say so
+    (wsr_conv_split_ok) instead of computing something else."""
+    o = ops()
+    nf, tf, k, p = 128, 16, (5, 5, 5), (2, 2, 2)
+    B, xyz = 1, (16, 32, 128)   # 65 536 voxels: the smallest volume dispatch_ct keeps on the 512-voxel tiles
+    cin = cout = nf + tf
+    gen = torch.Generator().manual_seed(11)
+    xa = torch.randn((B,) + xyz + (nf,), generator=gen).to(DEV).to(dt)
+    xt = torch.randn((B,) + xyz + (tf,), generator=gen).to(DEV).to(dt)
+    xcat = torch.cat([xa, xt], dim=-1).contiguous()
+    w = (torch.randn((cout, cin) + k, generator=gen) / math.sqrt(cin * 125)).to(DEV)
+    geom = o.ConvGeom(cin, cout, k, (1, 1, 1), p)
+    d_cat = o.make_desc(geom, dt, B, xyz, cin, 0, cout, 0)
+    d_two = o.make_desc(geom, dt, B, xyz, nf, 0, cout, 0, cin=cin)      # the first tensor's window holds nf channels
+    assert o.conv_split_ok(d_two, nf)
+    d_small = o.make_desc(geom, dt, B, (8, 8, 16), nf, 0, cout, 0, cin=cin)
+    assert not o.conv_split_ok(d_small, nf) or dt == torch.float32      # small bf16 volumes run the 128-voxel tiles
+    assert not o.conv_split_ok(o.make_desc(o.ConvGeom(80, 80, k, (1, 1, 1), p), dt, B, xyz, 64, 0, 80, 0, cin=80), 64)
+    wf = o.pack_filter_frag(w, dtype=dt)
+    bias = torch.randn(cout, generator=gen).to(DEV)
+    y_cat = torch.zeros((B,) + xyz + (cout,), dtype=dt, device=DEV)
+    y_two = torch.zeros_like(y_cat)
+    assert o.conv_fwd_tile(d_cat, xcat, wf, y_cat, bias=bias, act=True, slope=0.2)
+    assert o.conv_fwd_tile(d_two, xa, wf, y_two, bias=bias, act=True, slope=0.2, in2=xt, in2_c0=nf)
+    assert torch.equal(y_cat, y_two) and float(y_cat.float().abs().sum()) > 0
+    # against the CPU conv of the same operands on a slab (the whole volume would take minutes on the host)
+    sl = slice(4, 10)
+    ref = F.leaky_relu(F.conv3d(xcat[:, 2:12].permute(0, 4, 1, 2, 3).float().cpu(), w.to(dt).float().cpu(),
+                                bias.cpu(), 1, p), 0.2)[:, :, 2:8]
+    assert rel_l2(y_two[:, sl].permute(0, 4, 1, 2, 3).float().cpu(), ref) < (4e-3 if dt == torch.bfloat16 else 2e-5)
+    # input gradient: channels [0, nf) to one tensor, [nf, nf + tf) to the other
+    gy = torch.randn((B,) + xyz + (cout,), generator=gen).to(DEV).to(dt)
+    wt = o.pack_filter_frag(w, transpose=True, dtype=dt)
+    dx_cat = torch.zeros((B,) + xyz + (cin,), dtype=dt, device=DEV)
+    dxa = torch.full((B,) + xyz + (nf,), float("nan"), dtype=dt, device=DEV)
+    dxt = torch.full((B,) + xyz + (tf,), float("nan"), dtype=dt, device=DEV)
+    assert o.conv_dgrad_tile(d_cat, gy, wt, dx_cat)
+    assert o.conv_dgrad_tile(d_two, gy, wt, dxa, dx2=dxt, dx2_c0=nf)
+    assert torch.equal(dx_cat[..., :nf], dxa) and torch.equal(dx_cat[..., nf:], dxt)
+    # filter gradient: same split copies, same ordered sum
+    n = o.conv_wgrad_nparts(d_cat)
+    parts_cat = torch.empty((n, cout, 125, cin), dtype=torch.float32, device=DEV)
+    parts_two = torch.full_like(parts_cat, float("nan"))
+    o.conv_wgrad_parts(d_cat, xcat, gy, parts_cat, n)
+    o.conv_wgrad_parts(d_two, xa, gy, parts_two, n, x2=xt, x2_c0=nf)
+    assert torch.equal(parts_cat, parts_two)
+    del parts_cat, parts_two
+    torch.cuda.empty_cache()

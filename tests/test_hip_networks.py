@@ -52,9 +52,20 @@ def test_generator_fp32_vs_reference(golden, hip, scale, n, nz):
     assert out.shape == (2, 3, scale * n, scale * n, nz) and out.dtype == torch.float32
     assert rel_l2(out, T(g["out"])) < 2e-5
     (out * T(g["gy"]).to(DEV)).sum().backward()
-    worst = max(rel_l2(p.grad, T(g[f"grad.{k}"])) for k, p in G.named_parameters())
+    # The fixture is the reference's own fp32 CPU evaluation, and that is not always within 2e-4 of the exact gradients:
+    # at x16 (LR 3x3x4, batch 2) PyTorch's CPU convolution backward leaves the reference 2e-3 away from an fp64
+    # evaluation of the same graph on hr_convs.0 and everything below it (found with this fixture in round 5; the
+    # same inputs at batch 1 agree to 1e-6).  So every tensor is held to the fixture within 2e-4 + 1.5 x the fixture's
+    # own distance from fp64 (the rule of the full-width test), and to the fp64 evaluation itself within 2e-4.
+    sd64 = {k: v.double().requires_grad_(True)
+            for k, v in onets.deterministic_state(onets.g_param_shapes(spec), seed=11 + scale, scale=0.7).items()}
+    (onets.generator_forward(sd64, LR.double(), Z.double(), spec) * T(g["gy"]).double()).sum().backward()
+    worst = max(rel_l2(p.grad, sd64[k].grad) for k, p in G.named_parameters())
     for k, p in G.named_parameters():
-        assert rel_l2(p.grad, T(g[f"grad.{k}"])) < 2e-4, (k, worst)
+        d_ref = rel_l2(T(g[f"grad.{k}"]), sd64[k].grad)
+        assert rel_l2(p.grad, sd64[k].grad) < 2e-4, (k, worst)
+        assert rel_l2(p.grad, T(g[f"grad.{k}"])) < 2e-4 + 1.5 * d_ref, (k, d_ref)
+        assert d_ref < (5e-3 if scale == 16 else 2e-4), (k, d_ref)  # (the fixture itself: fp32 noise, except as said above)
     # no-grad forward saves nothing and gives the same numbers
     with torch.no_grad():
         out2 = G(LR.to(DEV), Z.to(DEV))
@@ -291,6 +302,84 @@ def test_discriminator_bf16_vs_oracle(hip):
         if k != "classifier.2.bias":
             cos = torch.nn.functional.cosine_similarity(p.grad.flatten().cpu(), res["fp32"][1][k].flatten(), dim=0)
             assert float(cos) > 0.97, (k, float(cos))
+
+
+@pytest.mark.parametrize("slicing,xy,nz", [(True, 64, 10), (False, 128, 10)])
+def test_discriminator_bf16_backward_layer_by_layer(hip, slicing, xy, nz):
+    """The bf16 discriminator backward, STAGE BY STAGE, against an fp32 CPU evaluation of each stage fed the HIP path's
+    own operands - its saved bf16 activations, its batch statistics and the bf16 gradient it handed to that stage - so
+    that neither the rounding of the stages above nor a LeakyReLU branch that falls the other way can hide an error:
+    BatchNorm (+ LeakyReLU) backward, input gradient, filter gradient and the BatchNorm parameter gradients of every
+    layer within 1e-2 (bf16-stored results; fp32 results 1e-3).  Full width (bf 32), train-mode batch statistics, batch
+    2; the end-to-end bounds of the network-level bf16 tests are 0.5-0.7 on these tensors (conditioning), this one
+    would catch a 1 % error in any single kernel of the pass."""
+    import torch.nn.functional as F
+    from torch.nn import grad as ngrad
+
+    spec = onets.DSpec(bf=32, nz=nz, enable_slicing=slicing)
+    D, _ = build_D(spec, torch.bfloat16, 77)
+    D.train()
+    prog = D.features.program()
+    gen = torch.Generator().manual_seed(5)
+    x = (torch.rand((2, 3, xy, xy, nz), generator=gen) * 2 - 1).to(DEV)
+    feat, saved = prog.forward(x, True, True)
+    g_feat = (torch.randn(feat.shape, generator=gen) * 0.1).to(DEV).to(feat.dtype)
+    prog.trace = []
+    try:
+        dx, flat = prog.backward(saved, g_feat, need_dx=True, need_dw=True)
+    finally:
+        trace, prog.trace = prog.trace, None
+    torch.cuda.synchronize()
+    tr = {(tag, li): t for tag, li, t in trace}
+    sl, worst = prog.slope, {}
+
+    def planar(t, c):  # NDHWC (B, X, Y, Z, Cp) -> fp32 (B, c, X, Y, Z) on the host
+        return t[..., :c].permute(0, 4, 1, 2, 3).float().cpu().contiguous()
+
+    for li, (l, r) in enumerate(zip(prog.layers, saved["recs"])):
+        s = l.conv
+        g = planar(tr[("g", li)], s.cout)
+        a = planar(r["a"], s.cout)
+        dact = g * torch.where(a > 0, torch.ones_like(a), torch.full_like(a, sl)) if l.act else g
+        if l.bn is None:
+            gy_ref = dact
+        else:
+            y = planar(r["y"], s.cout)
+            mean, invstd = r["mean"][0].float().cpu().view(1, -1, 1, 1, 1), r["invstd"][0].float().cpu().view(1, -1, 1, 1, 1)
+            gamma = l.bn.weight.detach().float().cpu().view(1, -1, 1, 1, 1)
+            xhat = (y - mean) * invstd
+            n = float(y.numel() // y.shape[1])
+            dbeta, dgamma = dact.sum((0, 2, 3, 4)), (dact * xhat).sum((0, 2, 3, 4))
+            gy_ref = gamma * invstd * (dact - dbeta.view(1, -1, 1, 1, 1) / n - xhat * dgamma.view(1, -1, 1, 1, 1) / n)
+            worst[f"{li}.bn.bias"] = rel_l2(prog.space.view(flat, l.bn.bias), dbeta)
+            worst[f"{li}.bn.weight"] = rel_l2(prog.space.view(flat, l.bn.weight), dgamma)
+            assert worst[f"{li}.bn.bias"] < 1e-3 and worst[f"{li}.bn.weight"] < 1e-3, (li, worst)
+        gy_hip = planar(tr[("gy", li)], s.cout)
+        worst[f"{li}.gy"] = rel_l2(gy_hip, gy_ref)
+        assert worst[f"{li}.gy"] < 1e-2, (li, worst)
+        # the two conv gradients from the HIP path's own gy (bf16) and saved input; the filter as the kernels see it
+        inp = planar(r["inp"], s.cin)
+        w = s.weight.detach().float().cpu()
+        dw_ref = ngrad.conv3d_weight(inp, w.shape, gy_hip, stride=s.stride, padding=s.pad)
+        worst[f"{li}.dw"] = rel_l2(prog.space.view(flat, s.weight), dw_ref)
+        assert worst[f"{li}.dw"] < 1e-3, (li, worst)   # fp32 sums of the same bf16 products: only the order differs
+        w16 = w.to(torch.bfloat16).float()
+        gin_ref = ngrad.conv3d_input(inp.shape, w16, gy_hip, stride=s.stride, padding=s.pad)
+        if li > 0:
+            worst[f"{li}.gin"] = rel_l2(planar(tr[("gin", li)], s.cin), gin_ref)
+            assert worst[f"{li}.gin"] < 1e-2, (li, worst)
+        else:
+            worst["0.dx"] = rel_l2(dx.cpu(), gin_ref)
+            assert worst["0.dx"] < 1e-3, worst     # planar fp32 output of the first layer's input gradient
+    try:
+        import json
+        import os
+        from conftest import REPO
+        os.makedirs(os.path.join(REPO, "gpurun_out"), exist_ok=True)
+        with open(os.path.join(REPO, "gpurun_out", f"parity_d_bf16_layerwise_{'slice' if slicing else 'full'}.json"), "w") as f:
+            json.dump(worst, f, indent=1, sort_keys=True)
+    except OSError:
+        pass
 
 
 def _gpu_gan(dtype="fp32", use_noise=False, dropout=0.0, feature_cost=False):
