@@ -310,7 +310,8 @@ def test_discriminator_bf16_backward_layer_by_layer(hip, slicing, xy, nz):
     own operands - its saved bf16 activations, its batch statistics and the bf16 gradient it handed to that stage - so
     that neither the rounding of the stages above nor a LeakyReLU branch that falls the other way can hide an error:
     BatchNorm (+ LeakyReLU) backward, input gradient, filter gradient and the BatchNorm parameter gradients of every
-    layer within 1e-2 (bf16-stored results; fp32 results 1e-3).  Full width (bf 32), train-mode batch statistics, batch
+    layer: results the path stores in bf16 within 4e-3 (one rounding: measured 1.7e-3), fp32 results within 2e-5
+    (measured 1e-7 .. 1e-6).  Full width (bf 32), train-mode batch statistics, batch
     2; the end-to-end bounds of the network-level bf16 tests are 0.5-0.7 on these tensors (conditioning), this one
     would catch a 1 % error in any single kernel of the pass."""
     import torch.nn.functional as F
@@ -353,24 +354,24 @@ def test_discriminator_bf16_backward_layer_by_layer(hip, slicing, xy, nz):
             gy_ref = gamma * invstd * (dact - dbeta.view(1, -1, 1, 1, 1) / n - xhat * dgamma.view(1, -1, 1, 1, 1) / n)
             worst[f"{li}.bn.bias"] = rel_l2(prog.space.view(flat, l.bn.bias), dbeta)
             worst[f"{li}.bn.weight"] = rel_l2(prog.space.view(flat, l.bn.weight), dgamma)
-            assert worst[f"{li}.bn.bias"] < 1e-3 and worst[f"{li}.bn.weight"] < 1e-3, (li, worst)
+            assert worst[f"{li}.bn.bias"] < 2e-5 and worst[f"{li}.bn.weight"] < 2e-5, (li, worst)
         gy_hip = planar(tr[("gy", li)], s.cout)
         worst[f"{li}.gy"] = rel_l2(gy_hip, gy_ref)
-        assert worst[f"{li}.gy"] < 1e-2, (li, worst)
+        assert worst[f"{li}.gy"] < 4e-3, (li, worst)   # ONE bf16 rounding of the stored result (measured 1.7e-3)
         # the two conv gradients from the HIP path's own gy (bf16) and saved input; the filter as the kernels see it
         inp = planar(r["inp"], s.cin)
         w = s.weight.detach().float().cpu()
         dw_ref = ngrad.conv3d_weight(inp, w.shape, gy_hip, stride=s.stride, padding=s.pad)
         worst[f"{li}.dw"] = rel_l2(prog.space.view(flat, s.weight), dw_ref)
-        assert worst[f"{li}.dw"] < 1e-3, (li, worst)   # fp32 sums of the same bf16 products: only the order differs
+        assert worst[f"{li}.dw"] < 2e-5, (li, worst)   # fp32 sums of the same bf16 products: only the order differs (1e-6)
         w16 = w.to(torch.bfloat16).float()
         gin_ref = ngrad.conv3d_input(inp.shape, w16, gy_hip, stride=s.stride, padding=s.pad)
         if li > 0:
             worst[f"{li}.gin"] = rel_l2(planar(tr[("gin", li)], s.cin), gin_ref)
-            assert worst[f"{li}.gin"] < 1e-2, (li, worst)
+            assert worst[f"{li}.gin"] < 4e-3, (li, worst)
         else:
             worst["0.dx"] = rel_l2(dx.cpu(), gin_ref)
-            assert worst["0.dx"] < 1e-3, worst     # planar fp32 output of the first layer's input gradient
+            assert worst["0.dx"] < 2e-5, worst     # planar fp32 output of the first layer's input gradient
     try:
         import json
         import os
