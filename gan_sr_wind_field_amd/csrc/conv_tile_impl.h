@@ -866,9 +866,24 @@ static void pick_tile(CtArgs& a, int M) {
     while (tx * ty < rest) {  // power of two: balanced split, y first
       if (ty <= tx) ty <<= 1; else tx <<= 1;
     }
-  } else {
+  } else if (WSR_ENV_SET("WSR_CT_SQUARE_TILES")) {  // (rounds 1-4: the most nearly square x-y tile, whatever the extents)
     while ((tx + 1) * (tx + 1) <= rest) ++tx;
     ty = rest / tx;
+  } else {
+    // z extents such as the reference's 10 levels leave an x-y budget that is no power of two (512 / 10 = 51): take the
+    // split that covers THIS volume with the fewest tiles - 16 x 16 x 10 (the LR patches of the shipped configurations,
+    // config/wind_field_GAN_3D_config_cluster.ini:42-47) needs 3 x 3 = 9 tiles of 7 x 7 x 10 but only 2 x 3 = 6 of 8 x 6 x 10:
+    // a third of the trunk's workgroups were padding - and among equals the one with the smallest halo image.
+    long best_tiles = -1, best_halo = 0;
+    for (int cx = 1; cx <= rest; ++cx) {
+      const int cy = rest / cx;
+      if (cy < 1) break;
+      const long tiles = (long)((a.Xo + cx - 1) / cx) * ((a.Yo + cy - 1) / cy);
+      const long halo = (long)((cx - 1) * (a.sx > 0 ? a.sx : 1) + a.KX) * ((cy - 1) * (a.sy > 0 ? a.sy : 1) + a.KY);
+      if (best_tiles < 0 || tiles < best_tiles || (tiles == best_tiles && halo < best_halo)) {
+        best_tiles = tiles; best_halo = halo; tx = cx; ty = cy;
+      }
+    }
   }
   a.TX = tx; a.TY = ty; a.TZ = tz;
 }
