@@ -716,6 +716,18 @@ int wsr_wgrad_tile_bf16(const wsr_conv_t* c, const void* x, const void* dy, floa
   }
   a.tri_base = tri_base; a.tri_step = tri_step;
   a.part_stride = part_stride; a.S_forced = n_parts; a.plan_only = plan ? 1 : 0;
+  if (taps == 1 && !c->lat && !c->upsample_xy && c->Zi % 16 != 0 && (c->px | c->py | c->pz) == 0) {
+    // A 1x1x1 conv has no halo: its filter gradient is a GEMM over the voxel INDEX, whatever the volume's shape.  The
+    // tile picker wants 16-level tiles (the reference's 10-level patches left it no tile that fits two LDS buffers:
+    // the cluster configuration's 48 LFF gradients ran on the per-tap kernel, 58 us each against ~25) - so hand it the
+    // same voxels as an (n / 128) x 8 x 16 volume.
+    const long nv = (long)c->Xi * c->Yi * c->Zi;
+    if (nv % 128 == 0 && nv / 128 < (1L << 24)) {
+      a.Xi = a.Xo = (int)(nv / 128);
+      a.Yi = a.Yo = 8;
+      a.Zi = a.Zo = 16;
+    }
+  }
   hipStream_t st = as_stream(stream);
   const int rc = run_tile(a, taps, c->Cout, c->Cin, st);
   if (plan && rc == 0) *plan = a.S;

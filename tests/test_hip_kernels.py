@@ -1431,3 +1431,40 @@ def test_concat_as_two_tensors_equals_the_concatenated_conv(hip, dt):
     assert torch.equal(parts_cat, parts_two)
     del parts_cat, parts_two
     torch.cuda.empty_cache()
+
+
+def test_plane_sum_uses_the_batch(hip):
+    """bias gradient of the last conv (planar fp32 (B, 3, V) -> 3 sums): every (sample, voxel slice) is a row of the
+    two-pass sum - a batch of 32 small patches is 96+ workgroups, not 9 - and the result does not depend on the launch
+    (fixed summation order)."""
+    o = ops()
+    gen = torch.Generator().manual_seed(4)
+    for B, V in ((32, 64 * 64 * 10), (1, 128 * 128 * 16), (5, 1000), (600, 64)):
+        src = torch.randn((B, 3, V), generator=gen).to(DEV)
+        out = torch.empty(3, device=DEV)
+        o.plane_sum(src, out)
+        ref = src.double().sum(dim=(0, 2))
+        assert rel_l2(out, ref) < 1e-6, (B, V)
+        out2 = torch.empty(3, device=DEV)
+        o.plane_sum(src, out2)
+        assert torch.equal(out, out2)
+
+
+def test_lff_filter_gradient_on_ten_level_patches(hip):
+    """the 1x1x1 (LFF) filter gradient at the cluster configuration's trunk shape - batch 32 of 16 x 16 x 10 voxels: the
+    tile kernel takes the voxels as a flat index (no halo, no geometry), same sums as the fp32 CPU evaluation."""
+    o = ops()
+    dt = torch.bfloat16
+    gen = torch.Generator().manual_seed(21)
+    B, xyz, cin, cout = 4, (16, 16, 10), 256, 128
+    x = torch.randn((B, cin) + xyz, generator=gen).bfloat16().float()
+    gy = torch.randn((B, cout) + xyz, generator=gen).bfloat16().float()
+    geom = o.ConvGeom(cin, cout, (1, 1, 1), (1, 1, 1), (0, 0, 0))
+    xb, gb = to_ndhwc(x, cin, 0, dt), to_ndhwc(gy, cout, 0, dt)
+    d = o.make_desc(geom, dt, B, xyz, cin, 0, cout, 0)
+    n = o.conv_wgrad_nparts(d)
+    parts = torch.full((n, cout, 1, cin), float("nan"), dtype=torch.float32, device=DEV)
+    o.conv_wgrad_parts(d, xb, gb, parts, n)
+    dw = parts.sum(0)[:, 0, :].cpu()
+    ref = torch.einsum("bnxyz,bcxyz->nc", gy, x)
+    assert rel_l2(dw, ref) < 2e-5
