@@ -35,6 +35,8 @@ int wsr_ct_run_wide(CtArgs& a, int tpk, hipStream_t st);    // conv_tile_wide.hi
 int wsr_ct_run_masked(CtArgs& a, int tpk, hipStream_t st);  // conv_tile_masked.hip
 int wsr_ct_run_narrow_masked(CtArgs& a, int tpk, hipStream_t st);  // conv_tile_narrow_masked.hip
 int wsr_ct_run_small(CtArgs& a, int tpk, hipStream_t st);          // conv_tile_small.hip
+int wsr_ct_run_tm3(CtArgs& a, int tpk, hipStream_t st);            // conv_tile_tm3.hip
+long wsr_ct_tiles(const CtArgs& a, int rows);                      // conv_tile_tm3.hip
 int wsr_ct_run_strided(CtArgs& a, int tpk, hipStream_t st);        // conv_tile_strided.hip
 int wsr_ct_run_f32(CtArgs& a, int tpk, hipStream_t st);            // conv_tile_f32*.hip
 #ifdef WSR_TUNING
@@ -59,6 +61,16 @@ int dispatch_ct(CtArgs& a, int tpk, hipStream_t st) {
   if ((long)a.B * a.Xo * a.Yo * a.Zo < 128L * 512 && !WSR_ENV_SET("WSR_CT_NOSMALL")) {
     const int rc = wsr_ct_run_small(a, tpk, st);
     if (rc != WSR_EUNSUPPORTED) return rc;
+  }
+  // 384-voxel tiles where they need fewer (rounds of 256 workgroups) x (MFMA rows per workgroup) than 512-voxel ones:
+  // single-round launches that leave CUs idle (conv_tile_tm3.hip: the cluster configuration's trunk, 192 -> 256
+  // workgroups of three quarters the length)
+  if (tpk == 2 && ((N > 16 && N <= 32) || (N > 64 && N <= 128 && !a.mask_y)) && a.nphase != 4 && !a.ups && !WSR_ENV_SET("WSR_CT_NO_TM3")) {
+    const long n4 = wsr_ct_tiles(a, 512), n3 = wsr_ct_tiles(a, 384);
+    if (((n3 + 255) / 256) * 3 < ((n4 + 255) / 256) * 4) {
+      const int rc = wsr_ct_run_tm3(a, tpk, st);
+      if (rc != WSR_EUNSUPPORTED) return rc;
+    }
   }
   if (a.mask_y) return N <= 64 ? wsr_ct_run_narrow_masked(a, tpk, st) : wsr_ct_run_masked(a, tpk, st);
   if (N <= 64) return wsr_ct_run_narrow(a, tpk, st);

@@ -440,7 +440,10 @@ if __name__ == "__main__":
     if "G" in which:
         gen_generators()
     if "G16" in which:  # scale = 16 (pretrained_models/upscale16_pix4_no_adv_no_slicing/config.ini:5): four UpConv stages
-        gen_generators(((16, 3, 4),))
+        # (LR 3 x 3 x 5; NOT 3 x 3 x 4: at that size and these seeds one LeakyReLU input of the trunk sits within fp32
+        # rounding of zero - the reference's fp32 gradients, an fp64 evaluation and the HIP path then differ pairwise by
+        # 2e-3 on everything below it, a property of the input, found in round 5)
+        gen_generators(((16, 3, 5),))
     if "D" in which:
         gen_discriminators()
     if "Dinst" in which:  # normalization_type = "instance" (torch_blocks.py:26-30), both slicing modes (the tail stays "batch")

