@@ -174,7 +174,7 @@ def cpu_baseline(n_threads, full=False, budget_s=30.0):
     return shapes
 
 
-TRAFFIC_JSON = "profiles/r04_hbm_traffic.json"
+TRAFFIC_JSON = "profiles/r05_hbm_traffic.json"
 
 
 def recorded_traffic(key):
@@ -442,37 +442,51 @@ def main():
     cf_bytes = V * (c_hr * esz + 3 * kz_fold * 4) + 125 * c_hr * 3 * esz
     cd_bytes = V * ((3 * kz_fold + 7) // 8 * 8 * esz + 2 * c_hr * esz) + 125 * c_hr * 3 * esz
 
-    def hbm_block(evs, nbytes, kernel):
+    def hbm_block(evs, nbytes, kernel, flops=0.0):
+        """HBM roofline of one memory-bound conv launch; ``flops`` (algorithmic, 2 x MACs) adds the OTHER roofline
+        beside it - the time the launch's arithmetic takes at the dtype's dense MFMA peak - and says which of the
+        two floors is the higher one: in fp32 (matrix rate 1/16 of bf16) most of this set is matrix-bound, and so is
+        the 16 -> 16 terrain conv in bf16 (433 flop per byte against a machine balance of 312)"""
         ms_, n_ = mean_ms(evs)
         ach = nbytes / (ms_ * 1e-3) / 1e9 if ms_ else None
-        return {"bound": "hbm", "kernel": kernel, "achieved": round(ach, 1) if ach else None, "peak": 8000.0,
-                "unit": "GB/s", "frac": round(ach / 8000.0, 4) if ach else None, "traffic": None,
-                "algorithmic_bytes": int(nbytes), "launches_timed": n_,
-                "avg_launch_us": round(ms_ * 1e3, 2) if ms_ else None}
+        blk = {"bound": "hbm", "kernel": kernel, "achieved": round(ach, 1) if ach else None, "peak": 8000.0,
+               "unit": "GB/s", "frac": round(ach / 8000.0, 4) if ach else None, "traffic": None,
+               "algorithmic_bytes": int(nbytes), "launches_timed": n_,
+               "avg_launch_us": round(ms_ * 1e3, 2) if ms_ else None}
+        if flops and ms_:
+            hbm_us, mfma_us = nbytes / 8e12 * 1e6, flops / (peak * 1e12) * 1e6
+            blk.update({"algorithmic_gflop": round(flops / 1e9, 2), "hbm_floor_us": round(hbm_us, 2),
+                        "mfma_floor_us": round(mfma_us, 2), "binding_roofline": "mfma" if mfma_us > hbm_us else "hbm",
+                        "frac_of_binding_roofline": round(max(hbm_us, mfma_us) / (ms_ * 1e3), 4)})
+        return blk
 
+    hr1_flops = 2.0 * V * 125 * c_hr * 3  # (the fold computes 16 columns for 15: counted as the conv's 3 x 125 taps)
     conv_d = hbm_block(probe_events["conv_dgrad"], cd_bytes,
-                       "hr_convs.2 input gradient (z-folded 15 -> 144, 5x5x1, LeakyReLU+Dropout3d mask epilogue)")
-    conv_f = hbm_block(probe_events["conv_fwd"], cf_bytes, "hr_convs.2 forward (z-folded 144 -> 15, 5x5x1, planar fp32 out)")
+                       "hr_convs.2 input gradient (z-folded 15 -> 144, 5x5x1, LeakyReLU+Dropout3d mask epilogue)", hr1_flops)
+    conv_f = hbm_block(probe_events["conv_fwd"], cf_bytes, "hr_convs.2 forward (z-folded 144 -> 15, 5x5x1, planar fp32 out)",
+                       hr1_flops)
     default_shape = args.dtype == "bf16" and n == 32 and nz == 128 and B == 1 and s == 4
     if default_shape:
         conv_d["traffic"], conv_f["traffic"] = recorded_traffic("hr1_dgrad"), recorded_traffic("hr1_fwd")
     # the other members of the memory-bound conv3d set: (Cin * V_in + Cout * V_out) * sizeof + filter (SURVEY 8d)
     tf_c, nf_c = gan.G.program().tf, gan.G.program().nf
     side = [
-        ("terrain0_fwd", "terrain_convs.0 forward (3x3x3, 1 -> %d, LeakyReLU)" % tf_c, V * (1 + tf_c) * esz + 27 * tf_c * esz),
-        ("terrain1_fwd", "terrain_convs.1 forward (3x3x3, %d -> %d into the concat window)" % (tf_c, tf_c),
-         V * 2 * tf_c * esz + 27 * tf_c * tf_c * esz),
+        ("terrain0_fwd", "terrain_convs.0 forward (3x3x3, 1 -> %d, LeakyReLU)" % tf_c, V * (1 + tf_c) * esz + 27 * tf_c * esz,
+         2.0 * V * 27 * tf_c),
+        ("terrain1_fwd", "terrain_convs.1 forward (3x3x3, %d -> %d, the terrain half of the concat)" % (tf_c, tf_c),
+         V * 2 * tf_c * esz + 27 * tf_c * tf_c * esz, 2.0 * V * 27 * tf_c * tf_c),
         ("terrain1_dgrad", "terrain_convs.1 input gradient (3x3x3, %d -> %d)" % (tf_c, tf_c),
-         V * 2 * tf_c * esz + 27 * tf_c * tf_c * esz),
-        ("feature_fwd", "model.0 feature conv forward (3x3x3, 4 -> %d)" % nf_c, vox * (4 + nf_c) * esz + 27 * 4 * nf_c * esz),
+         V * 2 * tf_c * esz + 27 * tf_c * tf_c * esz, 2.0 * V * 27 * tf_c * tf_c),
+        ("feature_fwd", "model.0 feature conv forward (3x3x3, 4 -> %d)" % nf_c, vox * (4 + nf_c) * esz + 27 * 4 * nf_c * esz,
+         2.0 * vox * 27 * 4 * nf_c),
     ]
     if kind == "gan":
         d0 = gan.D.features.program().layers[0].conv
         side.append(("d0_fwd", "D features.0.0 forward (3x3x3, %d -> %d, D(real) + D(fake) in one launch)" % (d0.cin, d0.cout),
-                     2 * V * (d0.cin + d0.cout) * esz + 27 * d0.cin * d0.cout * esz))
+                     2 * V * (d0.cin + d0.cout) * esz + 27 * d0.cin * d0.cout * esz, 2.0 * 2 * V * 27 * d0.cin * d0.cout))
     side_blocks = []
-    for key, name, nbytes in side:
-        blk = hbm_block(probe_events[key], nbytes, name)
+    for key, name, nbytes, flops in side:
+        blk = hbm_block(probe_events[key], nbytes, name, flops)
         if default_shape:
             blk["traffic"] = recorded_traffic(key)
         side_blocks.append(blk)

@@ -2,7 +2,7 @@
 # usage (in the build container, after tools/tuning/final_batch.sh TAG ran on the GPU box): copies the judged artefacts
 # from gpurun_out/ into profiles/ and prints the per-kernel tables
 set -e
-tag=${1:-r04_h}
+tag=${1:-r05_h}
 r=${tag%_h}
 cd /root/repo
 for n in $tag ${r}_c2 ${tag}_c1b; do
@@ -15,4 +15,5 @@ grep '^{' gpurun_out/${tag}_bench_single_rank_rccl.json.log > profiles/${tag}_be
 cp gpurun_out/${r}_presets.jsonl profiles/${r}_presets.jsonl
 python tools/tuning/pmc_step_sum.py $tag gpurun_out/${tag}_kernel_stats.csv > profiles/${tag}_hbm_kernels.txt
 for f in gpurun_out/parity_*.json; do cp $f profiles/${r}_$(basename $f); done
+for n in c1c_launch p_launch; do [ -f gpurun_out/${r}_${n}_shapes.txt ] && cp gpurun_out/${r}_${n}_shapes.txt profiles/${r}_${n}_shapes.txt; done
 ls -la profiles/${r}_* | wc -l
