@@ -445,8 +445,8 @@ def main():
     def hbm_block(evs, nbytes, kernel, flops=0.0):
         """HBM roofline of one memory-bound conv launch; ``flops`` (algorithmic, 2 x MACs) adds the OTHER roofline
         beside it - the time the launch's arithmetic takes at the dtype's dense MFMA peak - and says which of the
-        two floors is the higher one: in fp32 (matrix rate 1/16 of bf16) most of this set is matrix-bound, and so is
-        the 16 -> 16 terrain conv in bf16 (433 flop per byte against a machine balance of 312)"""
+        two floors is the higher one: in fp32 (matrix rate 1/16 of bf16) most of this set is matrix-bound - the last
+        conv's 0.48 TFLOP at C2 take 3.1 ms at the fp32 MFMA peak against 0.33 ms at 8 TB/s"""
         ms_, n_ = mean_ms(evs)
         ach = nbytes / (ms_ * 1e-3) / 1e9 if ms_ else None
         blk = {"bound": "hbm", "kernel": kernel, "achieved": round(ach, 1) if ach else None, "peak": 8000.0,
