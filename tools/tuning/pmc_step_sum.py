@@ -43,7 +43,7 @@ def main(name, stats_csv):
         # third launch (last block of an RRDB) also reads the RRDB shortcut: average over the launches
         "conv1x1_v2_kernel<8, 8, false, true>": v * (256 + 128) * 2 + 256 * 128 * 2 + v * 128 * 2 // 3,
         "conv_slide_fwd_kernel<5, 5, 18>": V * (144 * 2 + 15 * 4) + 125 * 144 * 3 * 2,
-        "conv_slide_dgrad_kernel<5, 5, 9>": V * (16 * 2 + 2 * 144 * 2) + 125 * 144 * 3 * 2,
+        "conv_slide_dgrad_kernel<5, 5, 9, 0>": V * (16 * 2 + 2 * 144 * 2) + 125 * 144 * 3 * 2,
         "conv1x1_v2_kernel<16, 4, true, true>": v * (128 + 128 + 256 + 32) * 2 + 256 * 128 * 2,
         "wgrad_tile_kernel<8, 1, 8, true>": v * (256 + 128) * 2,
         "wgrad_tile_kernel<3, 16, 1, true>": 2 * V * 144 * 2,
@@ -79,7 +79,7 @@ def main(name, stats_csv):
         print(f"{k[:58]:58s} {calls:6d} {us:9.1f} {f / 1e6:10.1f} {w / 1e6:10.1f} {rate:6.2f} {util:6.2f} {wait:6.2f} {a}")
     traffic = {}
     for key, k in (("hr0", "conv_tile_kernel<8, 1, 4, 9, 2, false, false>"), ("lff_fwd", "conv1x1_v2_kernel<8, 8, false, true>"),
-                   ("hr1_fwd", "conv_slide_fwd_kernel<5, 5, 18>"), ("hr1_dgrad", "conv_slide_dgrad_kernel<5, 5, 9>"),
+                   ("hr1_fwd", "conv_slide_fwd_kernel<5, 5, 18>"), ("hr1_dgrad", "conv_slide_dgrad_kernel<5, 5, 9, 0>"),
                    ("terrain0_fwd", "conv_thin3_kernel<8, 1, 1, 2, 32, 8>"),
                    # (forward and input gradient of terrain_convs.1 are launches of ONE kernel: their mean)
                    ("terrain1_fwd", "conv_thin3_kernel<16, 1, 1, 2, 32, 8>"),
