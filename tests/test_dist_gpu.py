@@ -56,13 +56,18 @@ def _build_gan(dtype, device_index=0):
 def _two_iterations(gan, cfg, LR, HR, Z, x, y):
     dev = cfg.device
     gan.feed_xy_niter(x.to(dev), y.to(dev), torch.tensor(cfg.training.niter, device=dev), 1, 1)
-    gan.optimize_parameters(LR.to(dev), HR.to(dev), Z.to(dev), 0)  # G-iteration
-    gan.optimize_parameters(LR.to(dev), HR.to(dev), Z.to(dev), 1)  # D-iteration (train-mode BatchNorm)
-    sdG, sdD = gan.G.state_dict(), gan.D.state_dict()
     keys_g = ("model.0.0.weight", "hr_convs.2.weight", "hr_convs.0.0.weight", "model.1.module.0.RDBs.1.LFF.bias")
     keys_d = ("features.0.0.0.weight", "features.1.1.1.weight", "features.3.1.0.weight", "classifier.2.weight",
               "features.2.0.1.running_var")
-    out = {"G." + k: sdG[k].detach().float().cpu() for k in keys_g}
+    gan.optimize_parameters(LR.to(dev), HR.to(dev), Z.to(dev), 0)  # G-iteration
+    # the (averaged) gradients that drove the Adam step - what the buckets carried, before any sign(g) step hides a
+    # mis-scaled or dropped bucket behind "the weights moved by about lr"
+    out = {"gradG." + k: dict(gan.G.named_parameters())[k].grad.detach().float().cpu().clone() for k in keys_g}
+    gan.optimize_parameters(LR.to(dev), HR.to(dev), Z.to(dev), 1)  # D-iteration (train-mode BatchNorm)
+    out.update({"gradD." + k: dict(gan.D.named_parameters())[k].grad.detach().float().cpu().clone()
+                for k in keys_d if "running" not in k})
+    sdG, sdD = gan.G.state_dict(), gan.D.state_dict()
+    out.update({"G." + k: sdG[k].detach().float().cpu() for k in keys_g})
     out.update({"D." + k: sdD[k].detach().float().cpu() for k in keys_d})
     return out
 
@@ -88,6 +93,9 @@ def _worker(rank, world, port, out_dir, dtype, bucket_mb, hr_scale, backend="glo
     sl = slice(2 * rank, 2 * rank + 2)  # two samples per rank
     res = _two_iterations(gan, cfg, LR[sl], HR[sl], Z[sl], x, y)
     res["n_coll"] = dp.n_collectives
+    # every element of both flat gradient buffers (and the classifier head's four tensors) went through a bucket, once
+    res["grad_elems_expected"] = (gan.G.program().space.total + gan.D.features.program().space.total
+                                  + sum(p.numel() for p in gan.D.classifier.parameters()))
     torch.cuda.synchronize()
     res["comm"] = dp.stats.summary(1)
     res["bn_layers"] = sum(1 for l in gan.D.features.program().layers if l.bn is not None)
@@ -114,8 +122,15 @@ def test_two_rank_step_equals_full_batch_hip(hip, tmp_path, bucket_mb, hr_scale)
     LR, HR, Z, x, y = synthetic_batch(2 * world, 16, 4, 4, seed=2001)
     ref = _two_iterations(gan, cfg, LR, HR * hr_scale, Z, x, y)
     lr = cfg.training.learning_rate_d if hasattr(cfg.training, "learning_rate_d") else 1e-4
+    from conftest import rel_l2
     for k, v in ref.items():
         assert torch.equal(r0[k], r1[k]), k  # replicas stay identical
+        if k.startswith("grad"):
+            # gradients BEFORE Adam: tight for the generator iteration (same weights on both sides: only the order of the
+            # batch sums differs), the discriminator iteration's at the bound of the other fp32 D tests (its input was
+            # generated by weights that already took one sign(g) step: see below)
+            assert rel_l2(r0[k], v) < (1e-4 if k.startswith("gradG") else 2.5e-2), (k, rel_l2(r0[k], v))
+            continue
         a, b = r0[k].numpy(), v.numpy()
         bad = np.abs(a - b) > 2e-6 + 5e-4 * np.abs(b)
         # Adam's first step moves every weight by lr * sign(g): an element whose gradient is at the rounding level of
@@ -129,7 +144,8 @@ def test_two_rank_step_equals_full_batch_hip(hip, tmp_path, bucket_mb, hr_scale)
     comm = r0["comm"]
     assert comm["syncbn_collectives_per_step"] == 2 * r0["bn_layers"], comm
     assert comm["grad_bucket_collectives_per_step"] == r0["n_coll"]
-    assert comm["grad_mbytes_per_step"] > 0 and comm["scalar_collectives_per_step"] >= 2
+    assert abs(comm["grad_mbytes_per_step"] * 1e6 - 4 * r0["grad_elems_expected"]) < 1e3, (comm, r0["grad_elems_expected"])
+    assert comm["scalar_collectives_per_step"] >= 2
     assert comm["timed"] and comm["exposed_grad_wait_ms_per_step"] >= 0.0
 
 
@@ -171,7 +187,12 @@ def test_two_rank_step_equals_full_batch_rccl(hip, tmp_path):
     gan, cfg = _build_gan("fp32")
     LR, HR, Z, x, y = synthetic_batch(2 * world, 16, 4, 4, seed=2001)
     ref = _two_iterations(gan, cfg, LR, HR, Z, x, y)
+    from conftest import rel_l2
     for k, v in ref.items():
         assert torch.equal(r0[k], r1[k]), k
-        np.testing.assert_allclose(r0[k].numpy(), v.numpy(), rtol=5e-4, atol=2e-6, err_msg=k)
+        if k.startswith("grad"):
+            assert rel_l2(r0[k], v) < (1e-4 if k.startswith("gradG") else 2.5e-2), (k, rel_l2(r0[k], v))
+        else:
+            np.testing.assert_allclose(r0[k].numpy(), v.numpy(), rtol=5e-4, atol=2e-6, err_msg=k)
     assert r0["comm"]["syncbn_collectives_per_step"] == 2 * r0["bn_layers"]
+    assert abs(r0["comm"]["grad_mbytes_per_step"] * 1e6 - 4 * r0["grad_elems_expected"]) < 1e3
