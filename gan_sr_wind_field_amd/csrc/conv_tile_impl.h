@@ -180,13 +180,17 @@ template <class T> __device__ __forceinline__ typename ct_v4<T>::type ct_zero4()
 template <> __device__ __forceinline__ uint2 ct_zero4<BF16>() { return make_uint2(0u, 0u); }
 template <> __device__ __forceinline__ uint4 ct_zero4<F32>() { return make_uint4(0u, 0u, 0u, 0u); }
 
-template <int WM, int WN, int TM, int TN, int TPK, bool PIPE, bool MASK, class T = BF16>
-__global__ __launch_bounds__(WM * WN * 64) __attribute__((amdgpu_waves_per_eu(1, WM * WN <= 4 ? 1 : 8)))
+// WK > 1 (small volumes, conv_tile_small.hip): WK waves share each (m-tile group, n-tile group) and split the K-STEPS of
+// every weight stage between them - a volume of 80 tiles leaves three quarters of the chip's SIMDs without a wave while
+// each of its two-wave workgroups walks 28..162 dependent K-steps; with the reduction over four waves the same workgroup
+// is four times shorter, and the partial sums meet in LDS (fixed order: bit-reproducible) before the epilogue.
+template <int WM, int WN, int TM, int TN, int TPK, bool PIPE, bool MASK, class T = BF16, int WK = 1>
+__global__ __launch_bounds__(WM * WN * WK * 64) __attribute__((amdgpu_waves_per_eu(1, WM * WN * WK <= 4 ? 1 : 8)))
 void conv_tile_kernel(const CtArgs a) {
   using E = typename T::elem;
   using V4 = typename ct_v4<T>::type;
   constexpr int EPP = T::EPP;      // channels per 16-byte piece
-  constexpr int WAVES = WM * WN, NT = WAVES * 64;
+  constexpr int WAVES = WM * WN * WK, NT = WAVES * 64;
   constexpr int PL = 4 / TPK;      // pieces (bf16: channel octets) per chunk and voxel
   constexpr int CK = EPP * PL;     // channels per chunk
   constexpr int NTW = WN * TN;     // n-tiles per workgroup
@@ -195,7 +199,9 @@ void conv_tile_kernel(const CtArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int t = threadIdx.x, lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-  const int wm = wave / WN, wn = wave % WN;
+  const int wk = WK > 1 ? wave / (WM * WN) : 0;            // which share of every stage's K-steps (waves 0 .. WM*WN-1: share 0)
+  const int wmn = WK > 1 ? wave - wk * (WM * WN) : wave;
+  const int wm = wmn / WN, wn = wmn % WN;
   CT_STAMP(0);
   CT_STAMP(6);
 
@@ -452,7 +458,13 @@ void conv_tile_kernel(const CtArgs a) {
     };
     auto run_ksteps = [&](int lo, int hi) __attribute__((always_inline)) {
       if (lo >= hi) return;
-      if constexpr (PIPE) {
+      if constexpr (WK > 1) {  // this wave's share of the stage: K-steps wk, wk + WK, ...
+        for (int tsi = lo + ((wk - lo % WK) + WK) % WK; tsi < hi; tsi += WK) {
+          uint4 wf[TN], xf[TM];
+          load_frags(tsi, wf, xf);
+          mma_frags(wf, xf);
+        }
+      } else if constexpr (PIPE) {
         // register double-buffering: the fragments of K-step t+1 are in flight during the MFMAs of K-step t
         uint4 wA[TN], xA[TM], wB[TN], xB[TM];
         load_frags(lo, wA, xA);
@@ -530,6 +542,31 @@ void conv_tile_kernel(const CtArgs a) {
   }
 
   CT_STAMP(4);
+  if constexpr (WK > 1) {
+    // the K-step shares meet: waves of share > 0 hand their sums over through LDS (the activation / weight buffers are
+    // free: every DMA has landed and the last phase's barrier is behind us), share 0 adds them in share order
+    f32x4_t* red = reinterpret_cast<f32x4_t*>(smem + a.off_xs);
+    if (wk > 0) {
+      f32x4_t* dst = red + (size_t)(((wk - 1) * (WM * WN) + wmn) * TM * TN) * 64 + lane;
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) dst[(i * TN + j) * 64] = acc[i][j];
+    }
+    __syncthreads();
+    if (wk > 0) return;
+#pragma unroll
+    for (int k = 1; k < WK; ++k) {
+      const f32x4_t* src = red + (size_t)(((k - 1) * (WM * WN) + wmn) * TM * TN) * 64 + lane;
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          const f32x4_t v = src[(i * TN + j) * 64];
+          acc[i][j][0] += v[0]; acc[i][j][1] += v[1]; acc[i][j][2] += v[2]; acc[i][j][3] += v[3];
+        }
+    }
+  }
   // ---- epilogue: acc[i][j][r] -> channel (nt0 + wn*TN + j)*16 + 4*fg + r, voxel row fr of m-tile i.
   // No load may sit between two stores (the compiler cannot move it above a store that might alias, so
   // every tile would pay a full memory round trip).  The n-tiles are walked one at a time; the operands
@@ -711,9 +748,9 @@ void conv_tile_kernel(const CtArgs a) {
 
 static inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 
-template <int WM, int WN, int TM, int TN, int TPK, bool MASK = false, class T = BF16>
+template <int WM, int WN, int TM, int TN, int TPK, bool MASK = false, class T = BF16, int WK = 1>
 int launch_ct(CtArgs& a, hipStream_t st) {
-  constexpr int WAVES = WM * WN, NTW = WN * TN;
+  constexpr int WAVES = WM * WN * WK, NTW = WN * TN;
   const int taps = a.KX * a.KY * a.KZ;
   constexpr int M = WM * TM * 16;  // table sizes follow the MFMA rows; the tile volume may be smaller
   if (a.TX * a.TY * a.TZ > M) return WSR_EUNSUPPORTED;
@@ -769,7 +806,11 @@ int launch_ct(CtArgs& a, hipStream_t st) {
   }
   const int nph = (a.nts + ts_max - 1) / ts_max;
   a.TS = (a.nts + nph - 1) / nph;  // balanced stages
-  const size_t lds = (size_t)a.off_ws + (size_t)2 * a.TS * NTW * 1024;
+  size_t lds = (size_t)a.off_ws + (size_t)2 * a.TS * NTW * 1024;
+  if (WK > 1) {  // the K-step shares' partial sums meet in the (then free) activation / weight buffers
+    const size_t red = (size_t)a.off_xs + (size_t)(WK - 1) * WM * WN * TM * TN * 1024;
+    if (red > lds) lds = red;
+  }
   if (lds > 160 * 1024) return WSR_EUNSUPPORTED;
   a.xs_stage = -1;
   a.xs_units = 0;
@@ -809,7 +850,7 @@ int launch_ct(CtArgs& a, hipStream_t st) {
   constexpr bool PIPE = TN <= 7 || WAVES <= 4;
   if (a.mask_y && !MASK) return WSR_EUNSUPPORTED;
   if (std::is_same<T, F32>::value) a.ws = nullptr;  // (the split-reduction second pass writes bf16)
-  auto kern = conv_tile_kernel<WM, WN, TM, TN, TPK, PIPE, MASK, T>;
+  auto kern = conv_tile_kernel<WM, WN, TM, TN, TPK, PIPE, MASK, T, WK>;
   static bool attr_done = false;
   if (!attr_done) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
