@@ -33,6 +33,7 @@ static int run(CtArgs& a, hipStream_t st) {
       // 8 - twice the workgroups, half the filter bytes each streams (measured 51.9 -> 37.1 us for 128 -> 128)
       const long tiles = (long)a.B * ((a.Xo + a.TX - 1) / a.TX) * ((a.Yo + a.TY - 1) / a.TY) * ((a.Zo + a.TZ - 1) / a.TZ);
       const int mode = WSR_ENV_INT("WSR_CT_SMALL_MODE", tiles * ((N + 127) / 128) < 160 ? 1 : 0);
+      // (four shares = 16 waves of <= 128 registers: the instantiation spills - two shares it is)
       if (mode == 1) return wk ? launch_ct<2, 2, 4, 2, TPK, false, BF16, 2>(a, st) : launch_ct<2, 2, 4, 2, TPK>(a, st);
       return launch_ct<2, 4, 4, 2, TPK>(a, st);
     }
