@@ -96,6 +96,7 @@ def _worker(rank, world, port, out_dir, dtype, bucket_mb, hr_scale, backend="glo
     # every element of both flat gradient buffers (and the classifier head's four tensors) went through a bucket, once
     res["grad_elems_expected"] = (gan.G.program().space.total + gan.D.features.program().space.total
                                   + sum(p.numel() for p in gan.D.classifier.parameters()))
+    res["grad_elems_g"] = gan.G.program().space.total  # (a generator pass the loss guards discarded sent its buckets too)
     torch.cuda.synchronize()
     res["comm"] = dp.stats.summary(1)
     res["bn_layers"] = sum(1 for l in gan.D.features.program().layers if l.bn is not None)
@@ -144,7 +145,9 @@ def test_two_rank_step_equals_full_batch_hip(hip, tmp_path, bucket_mb, hr_scale)
     comm = r0["comm"]
     assert comm["syncbn_collectives_per_step"] == 2 * r0["bn_layers"], comm
     assert comm["grad_bucket_collectives_per_step"] == r0["n_coll"]
-    assert abs(comm["grad_mbytes_per_step"] * 1e6 - 4 * r0["grad_elems_expected"]) < 1e3, (comm, r0["grad_elems_expected"])
+    sent = r0["grad_elems_expected"] + int(comm["discarded_generator_passes_per_step"]) * r0["grad_elems_g"]
+    assert abs(comm["grad_mbytes_per_step"] * 1e6 - 4 * sent) < 1e3, (comm, sent)
+    assert comm["discarded_generator_passes_per_step"] == (1 if hr_scale < 1 else 0)  # SR normalisers: one repeated pass
     assert comm["scalar_collectives_per_step"] >= 2
     assert comm["timed"] and comm["exposed_grad_wait_ms_per_step"] >= 0.0
 
