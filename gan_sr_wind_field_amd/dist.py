@@ -303,6 +303,8 @@ class DataParallel:
         #: also closes once it holds at least as much as everything still to come (>= tail_mb) - 32, 32, ..., 16, 8, 4, 2, 1
         self.tail_elems = max(1, int(tail_mb * 1024 * 1024 / 4))
         self._rider = None
+        self._small: List = []        # tiny gradients waiting to travel together (see _avg_param)
+        self._small_back: List = []   # (flat, [tensors]) of coalesced collectives in flight
         self.stats = CommStats()
         _LEDGERS[_gkey(group)] = self.stats  # (one ledger per process group: a later DataParallel on another group keeps its own)
 
@@ -393,8 +395,25 @@ class DataParallel:
             self._avg_async(cur[0][cur[1]:cur[2]])
         self.wait()
 
+    def _avg_param(self, g: Tensor) -> None:
+        """gradient of a parameter outside the flat buffers (the classifier head): large ones go out at once, the few tiny
+        ones (two biases, a 100-element weight) wait for `wait()` and travel together - one collective instead of three"""
+        if g.numel() >= 16384:
+            self._avg_async(g)
+        else:
+            self._small.append(g)
+
+    def _flush_small(self) -> None:
+        if not self._small:
+            return
+        small, self._small = self._small, []
+        flat = torch.cat([g.reshape(-1) for g in small])
+        self._avg_async(flat)
+        self._small_back.append((flat, small))
+
     def wait(self) -> None:
         """make the compute stream wait for every gradient bucket in flight (the host does not block on RCCL)"""
+        self._flush_small()
         if not self._pending:
             return
         with self.stats.bracket("wait", self._pending[0][1]):
@@ -404,6 +423,12 @@ class DataParallel:
             for _, t in self._pending:
                 t.div_(self.world)
         self._pending.clear()
+        for flat, small in self._small_back:  # the coalesced tiny gradients return to their tensors
+            off = 0
+            for g in small:
+                g.copy_(flat[off:off + g.numel()].view_as(g))
+                off += g.numel()
+        self._small_back.clear()
 
     # ---- wiring --------------------------------------------------------------------------
     def broadcast_module(self, module: torch.nn.Module) -> None:
@@ -452,7 +477,7 @@ class DataParallel:
                     progD.stat_world = self.world
             # the classifier head is ordinary torch autograd: reduce its 4 small tensors per step
             for p in gan.D.classifier.parameters():
-                p.register_post_accumulate_grad_hook(lambda p_: self._avg_async(p_.grad))
+                p.register_post_accumulate_grad_hook(lambda p_: self._avg_param(p_.grad))
         for opt in getattr(gan, "optimizers", []):
             opt.register_step_pre_hook(lambda *_: self.wait())
         # decorrelate dropout / instance-noise streams across ranks
