@@ -1180,6 +1180,10 @@ class GeneratorProgram(ProgramBase):
                 self.grad_ready_hook(flat, done, hi, self.flush_unpack)
                 done = hi
 
+        def tr(tag, idx, t):  # (test aid, see ProgramBase.trace)
+            if self.trace is not None:
+                self.trace.append((tag, idx, t.clone()))
+
         g_out = g_out.contiguous().float()
         # ---- hr1 (k5, bias, planar out)
         h, hcat = saved["h"], saved["hcat"]
@@ -1219,6 +1223,8 @@ class GeneratorProgram(ProgramBase):
             self.dgrad(self.hr1, g3, 0, gh, 0, (sX, sY, nz), mask=hr0_mask)
         ops.plane_sum(g_out, sp.view(flat, self.hr1.bias))
         ready(self.hr1.weight, self.hr1.bias)
+        tr("g3", 0, g3)
+        tr("gh", 0, gh)
         del g3
         # ---- hr0 (k5 + LReLU + Dropout3d mask: already applied to gh above)
         tfeat = saved.get("tfeat")  # not None: the concat is two tensors (SPLIT_CAT), and so is its gradient
@@ -1234,6 +1240,8 @@ class GeneratorProgram(ProgramBase):
             gt_src, gt_off = ghcat, nf
         ready(self.hr0.weight)
         del gh
+        tr("ghcat", 0, ghcat)
+        tr("gterrain", 0, gt_src[..., gt_off:gt_off + self.cp(tf)])
         # ---- terrain branch (channels nf.. of the concat)
         t0, z_nd = saved["t0"], saved["z_nd"]
         self.wgrad(self.terrain1, t0, 0, gt_src, gt_off, flat, sp, scratch)
@@ -1241,6 +1249,7 @@ class GeneratorProgram(ProgramBase):
         self.dgrad(self.terrain1, gt_src, gt_off, gt0, 0, (sX, sY, nz))
         del gt_src
         ops.lrelu_bwd_(gt0, 0, t0, 0, t0.shape[-1], sl)
+        tr("gt0", 0, gt0)
         self.wgrad(self.terrain0, z_nd, 0, gt0, 0, flat, sp, scratch)
         ready(self.terrain1.weight, self.terrain0.weight)
         del gt0
@@ -1252,6 +1261,7 @@ class GeneratorProgram(ProgramBase):
             if not masked:
                 ops.lrelu_bwd_(gbuf, 0, outp, 0, nf, sl)
             masked = False
+            tr("gup_out", u, gbuf[..., :nf])
             if self.subpixel_active(u) and SUBPIXEL_WGRAD and self.dt == torch.bfloat16:
                 self.up_wgrad(u, inp, gbuf, flat, sp)  # (fp32: the direct 27-tap gradient - its tile kernel has no lattice form)
             else:
@@ -1268,6 +1278,7 @@ class GeneratorProgram(ProgramBase):
                 ops.upsample2_bwd(fine, gin)
                 del fine
             ready(site.weight)
+            tr("gup_in", u, gin)
             gbuf = gin
         if not self.ups:
             gs = self._empty((B, X, Y, nz, nf), g_out)
@@ -1288,6 +1299,8 @@ class GeneratorProgram(ProgramBase):
         g = gd if pingpong else self._empty((B, X, Y, nz, nf), g_out)
         self.dgrad(self.lr_conv, gs, 0, g, 0, (X, Y, nz))
         ready(self.lr_conv.weight)
+        tr("gs", 0, gs)
+        tr("g_lr", 0, g[..., :nf])
         # ---- trunk
         # Filter gradients on a second stream (WSR_WGRAD_STREAM = ring size): they read the saved dense buffer and the
         # block's output gradients and feed nothing in the input-gradient chain.  The running gradient then MOVES through
@@ -1401,6 +1414,7 @@ class GeneratorProgram(ProgramBase):
             for convs, lff, rdb_scale in reversed(rdbs):
                 bi -= 1
                 buf = bufs[bi]
+                tr("rdb_go", bi, go[..., :nf])
                 # LFF (1x1x1, bias): out = rdb_scale * (LFF(buf) + b) + x
                 self.wgrad(lff, buf, 0, go, 0, flat, sp, scratch, scale=rdb_scale)
                 gb = sp.view(flat, lff.bias)
@@ -1430,6 +1444,8 @@ class GeneratorProgram(ProgramBase):
                         self.dgrad(convs[i], gd, off, gd, 0, (X, Y, nz), accumulate=True, mask=m)
                 # all growth-channel gradients of the block are final now: one stacked wgrad
                 self.wgrad_dense(convs, buf, gd, flat, sp, scratch)
+                if inplace:
+                    tr("rdb_gd", bi, gd)
                 if not inplace:
                     ops.chan_axpby(go, 0, gd, 0, nf, alpha=1.0, beta=1.0)  # + grad through the dense input
                 ready(lff.weight, lff.bias, *[c.weight for c in convs])

@@ -372,6 +372,141 @@ def test_discriminator_bf16_backward_layer_by_layer(hip, slicing, xy, nz):
         pass
 
 
+def test_generator_bf16_backward_stage_by_stage(hip, monkeypatch):
+    """The bf16 generator backward, STAGE BY STAGE, against fp32 CPU evaluations fed the HIP path's own operands (its saved
+    bf16 activations, the bf16 gradient it handed to the stage - ``ProgramBase.trace``): the z-folded last conv's masked input
+    gradient, the 5x5x5 conv over the two-tensor concat (input gradient to both tensors, filter gradient), the terrain
+    branch, the sub-pixel up-convs (parity input gradients with the mask of the conv below, parity filter gradients
+    folded back), lr_conv, and every residual dense block (LFF input gradient in place, stacked growth windows with their
+    LeakyReLU masks, stacked filter gradients, LFF filter / bias gradients).  Full width (nf 128, gc 32, tf 16), one
+    RRDB; HR 32 x 64 x 32 = 65 536 voxels, so the HR stages run the 512-voxel production tiles and the split concat.
+    Results the path stores in bf16: within 4e-3 of the fp32 evaluation per stage (measured 1.66e-3: ONE rounding; the dense
+    block's windows accumulate through bf16 once more: 2.35e-3 = sqrt(2) x that, bound 5e-3; the parity filters of the up-convs
+    are rounded sums of taps: 3.1e-3, bound 6e-3); fp32 results (every filter / bias gradient): 2e-5 (measured 1e-7 .. 4e-6).  The network-
+    level bounds on these tensors are 0.1-0.26 (test_hip_fullsize_parity): this is the test that sees a 1 % error in one kernel."""
+    import torch.nn.functional as F
+    from torch.nn import grad as ngrad
+    from gan_sr_wind_field_amd import engine
+
+    monkeypatch.setattr(engine, "GD_PINGPONG", False)  # (the in-place form: one gradient buffer, block by block)
+    spec = onets.GSpec(n_rrdb=1)
+    G, _ = build_G(spec, torch.bfloat16, 91, scale=0.5)
+    G.eval()
+    prog = G.program()
+    LR, HR, Z, x, y = ogan.synthetic_batch(1, 8, 32, 4, seed=6)
+    LR, Z = LR[:, :, :, :, :], Z
+    # (LR 8 x 16 x 32: a non-square patch)
+    LR = torch.cat([LR, LR.flip(3)], dim=3)
+    Z = torch.cat([Z, Z.flip(3) + 3.0], dim=3)
+    out, saved = prog.forward(LR.to(DEV), Z.to(DEV), False, True, None)
+    gen = torch.Generator().manual_seed(8)
+    g_out = torch.randn(out.shape, generator=gen).to(DEV)
+    prog.trace = []
+    try:
+        flat = prog.backward(saved, g_out)
+    finally:
+        trace, prog.trace = prog.trace, None
+    torch.cuda.synchronize()
+    tr = {(tag, i): t for tag, i, t in trace}
+    nf, gc, tf, sl = prog.nf, prog.gc, prog.tf, prog.slope
+    worst = {}
+
+    def planar(t, c0=0, c1=None):
+        c1 = t.shape[-1] if c1 is None else c1
+        return t[..., c0:c1].permute(0, 4, 1, 2, 3).float().cpu().contiguous()
+
+    def w16(site):
+        return site.weight.detach().to(torch.bfloat16).float().cpu()
+
+    def mask(a):
+        return torch.where(a > 0, torch.ones_like(a), torch.full_like(a, sl))
+
+    def gradw(site):
+        return prog.space.view(flat, site.weight).float().cpu()
+
+    def hold(name, got, want, tol):
+        worst[name] = rel_l2(got, want)
+        assert worst[name] < tol, (name, worst)
+
+    # ---- last conv in z-folded form: input gradient with the mask of the 5x5x5 conv's output
+    h = planar(saved["h"])
+    g3 = planar(tr[("g3", 0)], 0, prog.hr1z.cout)
+    wz = prog.hr1z.weight.detach().to(torch.bfloat16).float().cpu()
+    gh_ref = ngrad.conv3d_input(h.shape, wz, g3, padding=prog.hr1z.pad) * mask(h)
+    gh = planar(tr[("gh", 0)])
+    hold("hr1.dgrad", gh, gh_ref, 4e-3)
+    # ---- the 5x5x5 conv over the concat (two tensors): input gradient to both, filter gradient from both
+    hcat = torch.cat([planar(saved["hcat"], 0, nf), planar(saved["tfeat"])], dim=1) if saved.get("tfeat") is not None \
+        else planar(saved["hcat"], 0, nf + tf)
+    assert saved.get("tfeat") is not None  # (this size runs the split form)
+    dcat_ref = ngrad.conv3d_input(hcat.shape, w16(prog.hr0), gh, padding=prog.hr0.pad)
+    hold("hr0.dgrad.up", planar(tr[("ghcat", 0)], 0, nf), dcat_ref[:, :nf], 4e-3)
+    hold("hr0.dgrad.terrain", planar(tr[("gterrain", 0)], 0, tf), dcat_ref[:, nf:], 4e-3)
+    hold("hr0.wgrad", gradw(prog.hr0), ngrad.conv3d_weight(hcat, prog.hr0.weight.shape, gh, padding=prog.hr0.pad), 2e-5)
+    # ---- terrain branch
+    t0, gter = planar(saved["t0"], 0, tf), planar(tr[("gterrain", 0)], 0, tf)
+    gt0_ref = ngrad.conv3d_input(t0.shape, w16(prog.terrain1), gter, padding=1) * mask(t0)
+    gt0 = planar(tr[("gt0", 0)], 0, tf)
+    hold("terrain1.dgrad", gt0, gt0_ref, 4e-3)
+    hold("terrain1.wgrad", gradw(prog.terrain1), ngrad.conv3d_weight(t0, prog.terrain1.weight.shape, gter, padding=1), 2e-5)
+    hold("terrain0.wgrad", gradw(prog.terrain0),
+         ngrad.conv3d_weight(planar(saved["z_nd"], 0, 1), prog.terrain0.weight.shape, gt0, padding=1), 2e-5)
+    # ---- up-convs (nearest x(2,2,1) + 3x3x3 conv + LeakyReLU), last to first
+    for u in reversed(range(len(prog.ups))):
+        site, (inp, outp) = prog.ups[u], saved["up_io"][u]
+        gy = planar(tr[("gup_out", u)], 0, nf)                    # (already carries the LeakyReLU derivative of outp)
+        xin = planar(inp, 0, nf)
+        xup = xin.repeat_interleave(2, dim=2).repeat_interleave(2, dim=3)
+        hold(f"up{u}.wgrad", gradw(site), ngrad.conv3d_weight(xup, site.weight.shape, gy, padding=1), 2e-5)
+        dfine = ngrad.conv3d_input(xup.shape, site.weight.detach().float().cpu(), gy, padding=1)
+        B_, C_, X2, Y2, Z_ = dfine.shape
+        gin_ref = dfine.view(B_, C_, X2 // 2, 2, Y2 // 2, 2, Z_).sum((3, 5))
+        if u > 0:  # the mask of up-conv u-1's output rides on the last parity launch
+            gin_ref = gin_ref * mask(xin)
+        # (parity filters are sums of fp32 master taps rounded to bf16 once: a different rounding of the filter than
+        # tap-by-tap - the fp32 master filter is the reference)
+        hold(f"up{u}.dgrad", planar(tr[("gup_in", u)], 0, nf), gin_ref, 6e-3)
+    # ---- lr_conv
+    gs, tl = planar(tr[("gs", 0)], 0, nf), planar(saved["t_last"], 0, nf)
+    hold("lr_conv.dgrad", planar(tr[("g_lr", 0)], 0, nf), ngrad.conv3d_input(tl.shape, w16(prog.lr_conv), gs, padding=1), 4e-3)
+    hold("lr_conv.wgrad", gradw(prog.lr_conv), ngrad.conv3d_weight(tl, prog.lr_conv.weight.shape, gs, padding=1), 2e-5)
+    # ---- residual dense blocks, last to first (in-place form)
+    bufs = saved["bufs"]
+    bi = len(bufs)
+    for rdbs in reversed(prog.rrdbs):
+        for convs, lff, rdb_scale in reversed(rdbs):
+            bi -= 1
+            buf = planar(bufs[bi])                                # all nf + 4 gc channels as saved (bf16)
+            go = planar(tr[("rdb_go", bi)], 0, nf)
+            gd = planar(tr[("rdb_gd", bi)])                       # the gradient buffer after the block
+            lw = lff.weight.detach().to(torch.bfloat16).float().cpu()[:, :, 0, 0, 0]
+            d = rdb_scale * torch.einsum("bnxyz,nc->bcxyz", go, lw)
+            d[:, :nf] += go
+            for i in reversed(range(len(convs))):
+                win = slice(nf + i * gc, nf + (i + 1) * gc)
+                d[:, win] = d[:, win] * mask(buf[:, win])
+                # the filter gradient of conv i from the HIP path's OWN final window (bf16) and saved input
+                hold(f"rdb{bi}.conv{i}.wgrad", gradw(convs[i]),
+                     ngrad.conv3d_weight(buf[:, :nf + i * gc], convs[i].weight.shape, gd[:, win], padding=1), 2e-5)
+                d[:, :nf + i * gc] += ngrad.conv3d_input(buf[:, :nf + i * gc].shape, w16(convs[i]), d[:, win].contiguous(),
+                                                         padding=1)
+            for i in range(len(convs)):
+                win = slice(nf + i * gc, nf + (i + 1) * gc)
+                hold(f"rdb{bi}.window{i + 1}", gd[:, win], d[:, win], 5e-3)
+            hold(f"rdb{bi}.input", gd[:, :nf], d[:, :nf], 5e-3)
+            hold(f"rdb{bi}.lff.wgrad", gradw(lff)[:, :, 0, 0, 0], rdb_scale * torch.einsum("bnxyz,bcxyz->nc", go, buf), 2e-5)
+            hold(f"rdb{bi}.lff.bias", prog.space.view(flat, lff.bias).float().cpu(), rdb_scale * go.sum((0, 2, 3, 4)), 2e-5)
+    try:
+        import json
+        import os
+        from conftest import REPO
+        os.makedirs(os.path.join(REPO, "gpurun_out"), exist_ok=True)
+        with open(os.path.join(REPO, "gpurun_out", "parity_g_bf16_stagewise.json"), "w") as f:
+            json.dump(worst, f, indent=1, sort_keys=True)
+    except OSError:
+        pass
+
+
 def _gpu_gan(dtype="fp32", use_noise=False, dropout=0.0, feature_cost=False):
     import os
     from gan_sr_wind_field_amd.config.config import Config
