@@ -86,7 +86,12 @@ struct Ct3Args {
 // Compile-time geometry of an instantiation.  CP: reduction channels as stored (8 or 16).  WN waves share a plane's
 // m-tiles and split the n-tiles (NTW each); 8 / WN wave rows split the m-tiles (MT each); the column is TY rows x TZ
 // levels (TZ = 16 or 32), its planes carry a one-voxel halo in y and z.
-template <int CP, int WN, int NTW, int MT, int TZ, int WAVES_>
+// PS ("paired stores", NTW = 1 and MT even): a lane holds 4 channels of one voxel per m-tile - an 8-byte store, and 8-byte
+// stores run at 0.54-0.70 of the 16-byte rate (MI355X_MICROARCH.md).  With the n-tile's rows dealt to the lane groups as
+// channel blocks (0, 2, 1, 3) one v_permlane32_swap per dword between the results of an m-tile PAIR leaves lane groups 0 / 1
+// with channels 0-7 / 8-15 of the first m-tile's voxel and groups 2 / 3 with the same of the second's: ONE 16-byte store per
+// lane and pair (the guide's T21).
+template <int CP, int WN, int NTW, int MT, int TZ, int WAVES_, bool PS = false>
 struct Ct3Geom {
   static constexpr int WAVES = WAVES_, WM = WAVES / WN;
   static constexpr int MTILES = WM * MT;
@@ -104,15 +109,16 @@ struct Ct3Geom {
   static constexpr int NB_FIT = (WAVES == 8 ? 64 * 1024 : 39 * 1024) / STRIDE;  // LDS for 16 waves per CU
   static constexpr int NB = NB_FIT > 8 ? 8 : NB_FIT;   // plane buffers
   static constexpr int D = NB - 1;                // planes in flight
-  static constexpr int SPP = MT;                  // store instructions per wave and output plane (8 or 16 B per lane)
+  static constexpr int SPP = PS ? MT / 2 : MT;    // store instructions per wave and output plane (8 or 16 B per lane)
+  static_assert(!PS || (NTW == 1 && MT % 2 == 0), "paired stores: one n-tile, an even number of m-tiles");
   static_assert(TY >= 1 && TY * TZ == MTILES * 16, "the plane's m-tiles must fill TY x TZ");
   static_assert(NB >= 3, "at least two planes in flight");
   static_assert((D - 1) * DUW + D * SPP <= 63, "counted waits: vmcnt is a 6-bit counter");
 };
 
-template <int CP, int WN, int NTW, int MT, int TZ, int WAVES>
+template <int CP, int WN, int NTW, int MT, int TZ, int WAVES, bool PS = false>
 __global__ __launch_bounds__(WAVES * 64) void conv_thin3_kernel(const Ct3Args a) {
-  using G = Ct3Geom<CP, WN, NTW, MT, TZ, WAVES>;
+  using G = Ct3Geom<CP, WN, NTW, MT, TZ, WAVES, PS>;
   constexpr int WM = G::WM, TY = G::TY, LZ = G::LZ, TPK = G::TPK, PPV = G::PPV, RB = G::RB, SK = G::SK;
   constexpr int NP = G::NP, DUW = G::DUW, NXW = G::NXW, NB = G::NB, D = G::D, SPP = G::SPP;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -149,7 +155,9 @@ __global__ __launch_bounds__(WAVES * 64) void conv_thin3_kernel(const Ct3Args a)
         // channels of its voxel: one 16-byte store, whole 64-byte runs per voxel (two 8-byte stores per voxel wrote
         // every line half by half: the stores were 2/3 of the discriminator's first conv)
         const int cb = TPK * j + sub;
-        const int ch = NTW == 2 ? wn * 32 + 8 * (fr >> 2) + 4 * n + (fr & 3) : (wn * NTW + n) * 16 + fr;
+        // (PS: row block g of the n-tile <- channel block (0, 2, 1, 3)[g], see Ct3Geom)
+        const int ch = NTW == 2 ? wn * 32 + 8 * (fr >> 2) + 4 * n + (fr & 3)
+                                : (PS ? wn * 16 + 4 * ((((fr >> 2) & 1) << 1) | (fr >> 3)) + (fr & 3) : (wn * NTW + n) * 16 + fr);
         uint4 w = make_uint4(0u, 0u, 0u, 0u);
         if (cb < 9 && ch < a.NT_total * 16) {
           const int tap = kx * 9 + cb;
@@ -226,7 +234,8 @@ __global__ __launch_bounds__(WAVES * 64) void conv_thin3_kernel(const Ct3Args a)
   for (int n = 0; n < NTW; ++n)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const int co = (NTW == 2 ? wn * 32 + 8 * fg + 4 * n : (wn * NTW + n) * 16 + fg * 4) + r;
+      const int co = (NTW == 2 ? wn * 32 + 8 * fg + 4 * n
+                               : (PS ? wn * 16 + 4 * (((fg & 1) << 1) | (fg >> 1)) : (wn * NTW + n) * 16 + fg * 4)) + r;
       bb[n][r] = (a.bias && co < a.N) ? a.bias[co] : 0.f;
     }
   const float neg = a.act ? a.slope : 1.f;  // LeakyReLU as a select (no branch in the store path)
@@ -235,11 +244,13 @@ __global__ __launch_bounds__(WAVES * 64) void conv_thin3_kernel(const Ct3Args a)
   // channels past the last) carry an out-of-range offset and are dropped by the hardware - every wave issues the same
   // number of store instructions per plane, with no divergence, which is what lets the DMA waits be COUNTED (vmcnt is
   // one in-order counter for loads and stores).
-  const int co0 = NTW == 2 ? wn * 32 + 8 * fg : wn * 16 + fg * 4;
+  // (PS: after the swap lane groups 0 / 1 hold channels 0-7 / 8-15 of the pair's FIRST m-tile, groups 2 / 3 of its second)
+  const int co0 = NTW == 2 ? wn * 32 + 8 * fg : (PS ? wn * 16 + 8 * (fg & 1) : wn * 16 + fg * 4);
   unsigned orow[MT];
 #pragma unroll
   for (int i = 0; i < MT; ++i) {
-    const int gy = y0 + mry[i], gz = z0 + mzm[i] + fr;
+    const int im = PS ? (i & ~1) + (fg >> 1) : i;  // (PS: only the even entries are used, one per pair)
+    const int gy = y0 + mry[im], gz = z0 + mzm[im] + fr;
     orow[i] = (gy < a.Y && gz < a.Z && co0 < a.N) ? (unsigned)((((gy * a.Z + gz) * a.out_ctot) + a.out_off + co0) * 2)
                                                   : CT3_OOB;
   }
@@ -257,6 +268,7 @@ __global__ __launch_bounds__(WAVES * 64) void conv_thin3_kernel(const Ct3Args a)
 
   int rb = 0;  // ring buffer of the plane being contracted; the DMA of plane pi + D goes to the one before it
   // epilogue + store of m-tile i of accumulator set S as output index oi (output plane x_begin - 1 + oi)
+  unsigned held[2] = {0u, 0u};  // (PS) packed results of a pair's first m-tile
   auto store_tile = [&](auto sc, int i, const __amdgpu_buffer_rsrc_t& orsrc) __attribute__((always_inline)) {
     constexpr int S = decltype(sc)::value;
     unsigned o[NTW][2];
@@ -272,7 +284,18 @@ __global__ __launch_bounds__(WAVES * 64) void conv_thin3_kernel(const Ct3Args a)
       o[n][0] = (unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16);
       o[n][1] = (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16);
     }
-    if constexpr (NTW == 2) {
+    if constexpr (PS) {
+      if ((i & 1) == 0) {  // the pair's first m-tile waits for the second (the loops are unrolled: i is a constant)
+        held[0] = o[0][0];
+        held[1] = o[0][1];
+      } else {
+        auto r0 = __builtin_amdgcn_permlane32_swap(held[0], o[0][0], false, false);
+        auto r1 = __builtin_amdgcn_permlane32_swap(held[1], o[0][1], false, false);
+        ct3_u4 o4;
+        o4.x = r0[0]; o4.y = r1[0]; o4.z = r0[1]; o4.w = r1[1];
+        __builtin_amdgcn_raw_buffer_store_b128(o4, orsrc, (int)orow[i & ~1], 0, 0);
+      }
+    } else if constexpr (NTW == 2) {
       ct3_u4 o4;
       o4.x = o[0][0]; o4.y = o[0][1]; o4.z = o[1][0]; o4.w = o[1][1];
       __builtin_amdgcn_raw_buffer_store_b128(o4, orsrc, (int)orow[i], 0, 0);
@@ -375,9 +398,9 @@ __global__ __launch_bounds__(WAVES * 64) void conv_thin3_kernel(const Ct3Args a)
   ct3_wait<0>();
 }
 
-template <int CP, int WN, int NTW, int MT, int TZ, int WAVES>
+template <int CP, int WN, int NTW, int MT, int TZ, int WAVES, bool PS>
 int launch_thin3_tz(Ct3Args& a, hipStream_t st) {
-  using G = Ct3Geom<CP, WN, NTW, MT, TZ, WAVES>;
+  using G = Ct3Geom<CP, WN, NTW, MT, TZ, WAVES, PS>;
   a.nty = (a.Y + G::TY - 1) / G::TY;
   a.ntz = (a.Z + TZ - 1) / TZ;
   // x segments: enough workgroups for two per CU; a segment re-reads two halo planes
@@ -390,7 +413,7 @@ int launch_thin3_tz(Ct3Args& a, hipStream_t st) {
   a.nseg = (a.X + xs - 1) / xs;
   if ((long)a.Y * a.Z * a.in_ctot * 2 >= (long)CT3_OOB) return WSR_EUNSUPPORTED;  // plane offsets are 32-bit
   if ((long)a.Y * a.Z * a.out_ctot * 2 >= (long)CT3_OOB) return WSR_EUNSUPPORTED;
-  auto kern = conv_thin3_kernel<CP, WN, NTW, MT, TZ, WAVES>;
+  auto kern = conv_thin3_kernel<CP, WN, NTW, MT, TZ, WAVES, PS>;
   static bool attr_done = false;
   if (!attr_done) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -411,10 +434,27 @@ int launch_thin3_tz(Ct3Args& a, hipStream_t st) {
 template <int CP, int WN, int NTW, int MT, int WAVES = 8>
 int launch_thin3(Ct3Args& a, hipStream_t st) {
   if (a.Z % 16) return WSR_EUNSUPPORTED;
+  // one n-tile per wave, an even number of m-tiles, whole 16-byte pieces of the output window: paired stores (Ct3Geom)
+  constexpr bool CAN_PAIR = NTW == 1 && MT % 2 == 0;
+  // Measured (round 5, same-device A/B at C3-literal, where these launches last 0.2-0.6 ms): the one-n-tile-per-workgroup convs
+  // do NOT gain - terrain 1 -> 16: 315 -> 322 us, 16 -> 16: 555 -> 581 / 528 -> 540 - they are not store-issue-bound (the
+  // guide's T21 test: halve the store instructions at equal bytes and nothing moves); the 4 -> 128 feature conv, whose eight
+  // waves each write a 32-byte slice of every 256-byte voxel row, does: 194 -> 182 us.  So: paired stores where several
+  // waves share a voxel row (WN > 1); WSR_CT3_PAIR=1 / 0 forces them on / off everywhere.
+  const int want = WSR_ENV_INT("WSR_CT3_PAIR", WN > 1 ? 1 : 0);
+  const bool ps = CAN_PAIR && want && a.N % 8 == 0 && a.out_ctot % 8 == 0 && a.out_off % 8 == 0;
   if constexpr ((WAVES / WN) * MT >= 8 && ((WAVES / WN) * MT) % 2 == 0) {
-    if (a.Z % 32 == 0 && !WSR_ENV_SET("WSR_CT3_TZ16")) return launch_thin3_tz<CP, WN, NTW, MT, 32, WAVES>(a, st);
+    if (a.Z % 32 == 0 && !WSR_ENV_SET("WSR_CT3_TZ16")) {
+      if constexpr (CAN_PAIR) {
+        if (ps) return launch_thin3_tz<CP, WN, NTW, MT, 32, WAVES, true>(a, st);
+      }
+      return launch_thin3_tz<CP, WN, NTW, MT, 32, WAVES, false>(a, st);
+    }
   }
-  return launch_thin3_tz<CP, WN, NTW, MT, 16, WAVES>(a, st);
+  if constexpr (CAN_PAIR) {
+    if (ps) return launch_thin3_tz<CP, WN, NTW, MT, 16, WAVES, true>(a, st);
+  }
+  return launch_thin3_tz<CP, WN, NTW, MT, 16, WAVES, false>(a, st);
 }
 
 }  // namespace

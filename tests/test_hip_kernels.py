@@ -1505,3 +1505,34 @@ def test_conv_tile_384_voxel_tiles_masked_window(hip):
     ref = (xg.grad + acc) * torch.where(ysaved > 0, torch.ones_like(ysaved), torch.full_like(ysaved, 0.2))
     assert rel_l2(from_ndhwc(buf, 128, n), ref) < 4e-3
     assert torch.equal(buf[..., 160:160 + red].cpu(), gy.permute(0, 2, 3, 4, 1).to(dt))  # the gradients it read are intact
+
+
+def test_conv_thin_paired_stores_equal_the_plain_form(hip, monkeypatch):
+    """conv_thin.hip, paired 16-byte stores (one v_permlane32_swap per dword between the results of an m-tile pair, the
+    n-tile's rows dealt to the lane groups as channel blocks 0, 2, 1, 3): forced on for the one-n-tile convs (default: only
+    where several waves share a voxel row - the feature conv), bit-identical to the 8-byte form, windows and tails included."""
+    o = ops()
+    dt = torch.bfloat16
+    gen = torch.Generator().manual_seed(3)
+    for cin, cout, xyz, in_ctot, in_off, out_ctot, out_off in ((16, 16, (8, 16, 32), 16, 0, 16, 0), (8, 16, (9, 11, 32), 24, 8, 40, 16),
+                                                            (8, 128, (8, 8, 32), 8, 0, 128, 0), (16, 16, (5, 9, 16), 16, 0, 144, 128)):
+        x = torch.randn((1, cin) + xyz, generator=gen)
+        w = torch.randn((cout, cin, 3, 3, 3), generator=gen) / math.sqrt(cin * 27)
+        bias = torch.randn(cout, generator=gen).to(DEV)
+        xb = to_ndhwc(x, in_ctot, in_off, dt)
+        d = o.make_desc(o.ConvGeom(cin, cout, (3, 3, 3), (1, 1, 1), (1, 1, 1)), dt, 1, xyz, in_ctot, in_off, out_ctot, out_off)
+        wf = o.pack_filter_frag(packed_master(w), dtype=dt)
+        outs = []
+        for pair in ("0", "1"):
+            monkeypatch.setenv("WSR_CT3_PAIR", pair)
+            reload_wsr_env()
+            y = torch.full((1,) + xyz + (out_ctot,), 7.0, dtype=dt, device=DEV)
+            assert o.conv_fwd_tile(d, xb, wf, y, bias=bias, act=True, slope=0.2)
+            outs.append(y)
+        assert torch.equal(outs[0], outs[1]), (cin, cout, xyz)
+        assert float(outs[1][..., out_off:out_off + cout].float().abs().sum()) > 0
+        if out_ctot > cout:  # the rest of the voxel rows is untouched
+            rest = torch.cat([outs[1][..., :out_off], outs[1][..., out_off + cout:]], dim=-1)
+            assert bool((rest == 7.0).all())
+    monkeypatch.delenv("WSR_CT3_PAIR")
+    reload_wsr_env()
