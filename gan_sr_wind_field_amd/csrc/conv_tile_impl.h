@@ -533,6 +533,9 @@ void conv_tile_kernel(const CtArgs a) {
 #ifdef WSR_CT_STAMPS
     const long long tw1 = clock64();
 #endif
+#ifdef WSR_CT_STAMPS
+    if (!(a.ablate & 16))  // (timing only, wrong results: what the phase barriers cost - the bound on any barrier-free weight ring)
+#endif
     __syncthreads();  // ... and so have everybody else's; the buffers just read are free again
 #ifdef WSR_CT_STAMPS
     st_dma += tw1 - tw0;
