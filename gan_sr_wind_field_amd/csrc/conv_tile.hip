@@ -36,6 +36,7 @@ int wsr_ct_run_masked(CtArgs& a, int tpk, hipStream_t st);  // conv_tile_masked.
 int wsr_ct_run_narrow_masked(CtArgs& a, int tpk, hipStream_t st);  // conv_tile_narrow_masked.hip
 int wsr_ct_run_small(CtArgs& a, int tpk, hipStream_t st);          // conv_tile_small.hip
 int wsr_ct_run_tm3(CtArgs& a, int tpk, hipStream_t st);            // conv_tile_tm3.hip
+int wsr_ct_run_narrow_wk(CtArgs& a, int tpk, hipStream_t st);      // conv_tile_narrow_wk.hip
 long wsr_ct_tiles(const CtArgs& a, int rows);                      // conv_tile_tm3.hip
 int wsr_ct_run_strided(CtArgs& a, int tpk, hipStream_t st);        // conv_tile_strided.hip
 int wsr_ct_run_f32(CtArgs& a, int tpk, hipStream_t st);            // conv_tile_f32*.hip
@@ -71,6 +72,10 @@ int dispatch_ct(CtArgs& a, int tpk, hipStream_t st) {
       const int rc = wsr_ct_run_tm3(a, tpk, st);
       if (rc != WSR_EUNSUPPORTED) return rc;
     }
+  }
+  if (tpk == 2 && N > 16 && N <= 32 && a.nphase != 4 && WSR_ENV_INT("WSR_CT_NARROW_WK", 0)) {  // (tuning: 16-wave K-step shares)
+    const int rc = wsr_ct_run_narrow_wk(a, tpk, st);
+    if (rc != WSR_EUNSUPPORTED) return rc;
   }
   if (a.mask_y) return N <= 64 ? wsr_ct_run_narrow_masked(a, tpk, st) : wsr_ct_run_masked(a, tpk, st);
   if (N <= 64) return wsr_ct_run_narrow(a, tpk, st);
