@@ -208,6 +208,10 @@ def launch_ranks(args, argv):
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL needs it on this driver
     env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // args.gpus)))
+    if args.one_device and args.gpus > 2:
+        # rehearsal only: N processes on one card at HIP's default of four hardware queues each oversubscribe the card's
+        # queue slots - with four ranks the first generator backward never finishes (profiles/README.md, round 5)
+        env.setdefault("GPU_MAX_HW_QUEUES", "2")
     return subprocess.run(cmd, env=env).returncode
 
 
@@ -265,6 +269,9 @@ def main():
         sys.exit(launch_ranks(args, sys.argv[1:]))
     if args.dry_launch:
         return dry_launch(args)
+    if os.environ.get("WSR_BENCH_WATCHDOG"):  # debugging aid: every rank prints its stacks after this many seconds
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ["WSR_BENCH_WATCHDOG"]), repeat=False)
     # stdout carries the ONE JSON line and nothing else: RCCL prints a version banner to stdout when a communicator
     # is made (and other libraries may chat there too) - from here on file descriptor 1 is stderr, and the line goes
     # to the saved descriptor at the end
