@@ -37,6 +37,9 @@ int wsr_ct_run_narrow_masked(CtArgs& a, int tpk, hipStream_t st);  // conv_tile_
 int wsr_ct_run_small(CtArgs& a, int tpk, hipStream_t st);          // conv_tile_small.hip
 int wsr_ct_run_tm3(CtArgs& a, int tpk, hipStream_t st);            // conv_tile_tm3.hip
 int wsr_ct_run_narrow_wk(CtArgs& a, int tpk, hipStream_t st);      // conv_tile_narrow_wk.hip
+int wsr_ct_run_simple_narrow(CtArgs& a, int tpk, int tm3, hipStream_t st);  // conv_tile_simple_narrow.hip
+int wsr_ct_run_simple_n128(CtArgs& a, int tpk, int tm3, hipStream_t st);    // conv_tile_simple_n128.hip
+int wsr_ct_run_simple_small(CtArgs& a, int tpk, hipStream_t st);            // conv_tile_simple_small.hip
 long wsr_ct_tiles(const CtArgs& a, int rows);                      // conv_tile_tm3.hip
 int wsr_ct_run_strided(CtArgs& a, int tpk, hipStream_t st);        // conv_tile_strided.hip
 int wsr_ct_run_f32(CtArgs& a, int tpk, hipStream_t st);            // conv_tile_f32*.hip
@@ -59,19 +62,36 @@ int dispatch_ct(CtArgs& a, int tpk, hipStream_t st) {
   }
 #endif
   // small volumes (< 128 tiles of 512 voxels): 128-voxel tiles where an instantiation exists
+  // (SIMPLE: instantiations with the general forms' run-time switches folded away, for the plain stride-1 launches of the
+  // trunk - conv_tile_impl.h; each returns WSR_EUNSUPPORTED for anything else)
+  const int simple = WSR_ENV_INT("WSR_CT_SIMPLE", 1);
   if ((long)a.B * a.Xo * a.Yo * a.Zo < 128L * 512 && !WSR_ENV_SET("WSR_CT_NOSMALL")) {
+    if (simple & 1) {
+      const int rc = wsr_ct_run_simple_small(a, tpk, st);
+      if (rc != WSR_EUNSUPPORTED) return rc;
+    }
     const int rc = wsr_ct_run_small(a, tpk, st);
     if (rc != WSR_EUNSUPPORTED) return rc;
   }
   // 384-voxel tiles where they need fewer (rounds of 256 workgroups) x (MFMA rows per workgroup) than 512-voxel ones:
   // single-round launches that leave CUs idle (conv_tile_tm3.hip: the cluster configuration's trunk, 192 -> 256
   // workgroups of three quarters the length)
+  int tm3 = 0;
   if (tpk == 2 && ((N > 16 && N <= 32) || (N > 64 && N <= 128 && !a.mask_y)) && a.nphase != 4 && !a.ups && !WSR_ENV_SET("WSR_CT_NO_TM3")) {
     const long n4 = wsr_ct_tiles(a, 512), n3 = wsr_ct_tiles(a, 384);
-    if (((n3 + 255) / 256) * 3 < ((n4 + 255) / 256) * 4) {
-      const int rc = wsr_ct_run_tm3(a, tpk, st);
-      if (rc != WSR_EUNSUPPORTED) return rc;
-    }
+    tm3 = ((n3 + 255) / 256) * 3 < ((n4 + 255) / 256) * 4;
+  }
+  if ((simple & 1) && tpk == 2 && N > 16 && N <= 32 && !(WSR_ENV_INT("WSR_CT_NARROW_WK", 0))) {
+    const int rc = wsr_ct_run_simple_narrow(a, tpk, tm3, st);
+    if (rc != WSR_EUNSUPPORTED) return rc;
+  }
+  if ((simple & 1) && tpk == 2 && N > 64 && N <= 128 && !a.mask_y && !WSR_ENV_SET("WSR_CT_NO_N128")) {
+    const int rc = wsr_ct_run_simple_n128(a, tpk, tm3, st);
+    if (rc != WSR_EUNSUPPORTED) return rc;
+  }
+  if (tm3) {
+    const int rc = wsr_ct_run_tm3(a, tpk, st);
+    if (rc != WSR_EUNSUPPORTED) return rc;
   }
   if (tpk == 2 && N > 16 && N <= 32 && a.nphase != 4 && WSR_ENV_INT("WSR_CT_NARROW_WK", 0)) {  // (tuning: 16-wave K-step shares)
     const int rc = wsr_ct_run_narrow_wk(a, tpk, st);
@@ -82,6 +102,8 @@ int dispatch_ct(CtArgs& a, int tpk, hipStream_t st) {
   // (short reductions - the z-folded last conv's input gradient, 16 channels x 25 taps - stay on the generic
   // wide tiles: the 512-voxel N = 144 instantiation is kept for the 5x5x5 144 -> 144 conv it is tuned and
   // profiled for)
+  // (a SIMPLE == 2 instantiation of the 144-wide tile - channel scale and two-tensor concat kept - measured 7.13 -> 7.15-7.17 ms
+  // on the 5x5x5 conv: its launches are 7 ms of main loop, and that loop did not get shorter; not shipped)
   if (N == 144 && (long)a.nchunks * a.KX * a.KY * a.KZ >= 256) return wsr_ct_run_n144(a, tpk, st);
   if (N > 64 && N <= 128 && !WSR_ENV_SET("WSR_CT_NO_N128")) {  // (the env switch is a tuning aid)
     const int rc = wsr_ct_run_n128(a, tpk, st);

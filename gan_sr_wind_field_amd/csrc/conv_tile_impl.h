@@ -184,7 +184,13 @@ template <> __device__ __forceinline__ uint4 ct_zero4<F32>() { return make_uint4
 // every weight stage between them - a volume of 80 tiles leaves three quarters of the chip's SIMDs without a wave while
 // each of its two-wave workgroups walks 28..162 dependent K-steps; with the reduction over four waves the same workgroup
 // is four times shorter, and the partial sums meet in LDS (fixed order: bit-reproducible) before the epilogue.
-template <int WM, int WN, int TM, int TN, int TPK, bool PIPE, bool MASK, class T = BF16, int WK = 1>
+// SIMPLE (the trunk's launches - stride 1, no lattice / parity / up-sampling gather, no split reduction, no planar output,
+// whole 4-channel groups; SIMPLE == 1: also no per-sample channel scale and no two-tensor concat, == 2: those stay - the
+// 5x5x5 conv): the general forms' run-time switches become constants.  The kernel
+// takes ~100 uniform arguments and the general epilogue tests many of them per (m-tile, n-tile): the 32-wide instantiation
+// carried 108-185 spilled SGPRs (2 559 v_readlane in 9 500 lines of ISA, a third of its epilogue), i.e. a prologue and an
+// epilogue paid in SGPR reloads on launches that last 16-30 us.
+template <int WM, int WN, int TM, int TN, int TPK, bool PIPE, bool MASK, class T = BF16, int WK = 1, int SIMPLE = 0>
 __global__ __launch_bounds__(WM * WN * WK * 64) __attribute__((amdgpu_waves_per_eu(1, WM * WN * WK <= 4 ? 1 : 8)))
 void conv_tile_kernel(const CtArgs a) {
   using E = typename T::elem;
@@ -202,10 +208,18 @@ void conv_tile_kernel(const CtArgs a) {
   const int wk = WK > 1 ? wave / (WM * WN) : 0;            // which share of every stage's K-steps (waves 0 .. WM*WN-1: share 0)
   const int wmn = WK > 1 ? wave - wk * (WM * WN) : wave;
   const int wm = wmn / WN, wn = wmn % WN;
+  // (SIMPLE: constants; else the arguments)
+  const int sx = SIMPLE ? 1 : a.sx, sy = SIMPLE ? 1 : a.sy, sz = SIMPLE ? 1 : a.sz;
+  const int il_m = SIMPLE ? 1 : a.il_m, il_ox = SIMPLE ? 0 : a.il_ox, il_oy = SIMPLE ? 0 : a.il_oy;
+  const int ol_m = SIMPLE ? 1 : a.ol_m, ol_mz = SIMPLE ? 1 : a.ol_mz;
+  const int ol_ox = SIMPLE ? 0 : a.ol_ox, ol_oy = SIMPLE ? 0 : a.ol_oy, ol_oz = SIMPLE ? 0 : a.ol_oz;
+  const int nphase = SIMPLE ? 1 : a.nphase, ups = SIMPLE ? 0 : a.ups, ksplit = SIMPLE ? 1 : a.ksplit;
+  const bool out_planar = SIMPLE ? false : (a.out_planar != 0);
+  const float* const chan_scale = SIMPLE == 1 ? nullptr : a.chan_scale;
   CT_STAMP(0);
   CT_STAMP(6);
 
-  const int Lx = (a.TX - 1) * a.sx + a.KX, Ly = (a.TY - 1) * a.sy + a.KY, Lz = (a.TZ - 1) * a.sz + a.KZ;
+  const int Lx = (a.TX - 1) * sx + a.KX, Ly = (a.TY - 1) * sy + a.KY, Lz = (a.TZ - 1) * sz + a.KZ;
   const int L = Lx * Ly * Lz;
   const int M = a.TX * a.TY * a.TZ;  // <= MR
   constexpr int MR = WM * TM * 16;    // MFMA rows of the workgroup
@@ -220,8 +234,8 @@ void conv_tile_kernel(const CtArgs a) {
   unsigned bid = (unsigned)xcd_remap(blockIdx.x, gridDim.x);
   int c_begin = 0, nchunks_l = a.nchunks;  // this workgroup's slice of the reduction channels
   float* part = nullptr;
-  if (a.ksplit > 1) {
-    const unsigned per = gridDim.x / (unsigned)a.ksplit, ksi = bid / per;
+  if (ksplit > 1) {
+    const unsigned per = gridDim.x / (unsigned)ksplit, ksi = bid / per;
     bid -= ksi * per;
     c_begin = (int)ksi * a.cps;
     nchunks_l = min(a.cps, a.nchunks - c_begin);
@@ -230,9 +244,9 @@ void conv_tile_kernel(const CtArgs a) {
   const unsigned tile = fdiv(bid, a.ngroups, a.mg_ng);
   const int ng = (int)(bid - tile * a.ngroups);
   // the four parity convs of a sub-pixel launch sit side by side in the grid: they gather the same halo (L2)
-  const int pha = a.nphase == 4 ? (int)((tile >> 1) & 1) : 0, phb = a.nphase == 4 ? (int)(tile & 1) : 0;
+  const int pha = nphase == 4 ? (int)((tile >> 1) & 1) : 0, phb = nphase == 4 ? (int)(tile & 1) : 0;
   const int ppx = a.px - pha, ppy = a.py - phb;
-  unsigned r = a.nphase == 4 ? tile >> 2 : tile, r2;
+  unsigned r = nphase == 4 ? tile >> 2 : tile, r2;
   r2 = fdiv(r, a.tiles_z, a.mg_tz); const int tz = (int)(r - r2 * a.tiles_z); r = r2;
   r2 = fdiv(r, a.tiles_y, a.mg_ty); const int ty = (int)(r - r2 * a.tiles_y); r = r2;
   r2 = fdiv(r, a.tiles_x, a.mg_tx); const int tx = (int)(r - r2 * a.tiles_x);
@@ -251,7 +265,7 @@ void conv_tile_kernel(const CtArgs a) {
   const int lane_plane = VM ? (fg & 1) * 16 : (fg % PL) * a.P;
   const int lane_tsub = fg / PL;           // which of the K-step's TPK taps this lane's octet belongs to
 
-  const int U = a.ups ? 1 : 0;
+  const int U = ups ? 1 : 0;
   const int nstages = (a.nts + a.TS - 1) / a.TS;
   const int stage_units = a.TS * NTW;  // 1 KB fragments per weight stage
   const int UPP = VM ? (L + 31) >> 5 : (L + 63) >> 6;  // 1 KB DMA units per activation plane (VM: per chunk)
@@ -285,8 +299,8 @@ void conv_tile_kernel(const CtArgs a) {
   // Offsets are 32-bit and RELATIVE to the first x-plane the tile's halo touches (a 64-bit workgroup-uniform base):
   // tensors beyond 2^32 elements (the literal 128^3 -> 512 x 512 x 128 reading of BASELINE.json configs[2]: 4.8e9 in a
   // 144-channel HR tensor) only need the halo's few planes to stay below 2^32 elements (checked on the host).
-  const int gx_lo = max(x0 * a.sx - ppx, 0) >> U;  // first stored x-plane of the halo
-  const long vox_base = ((long)b * a.Xi + gx_lo) * a.il_m * ((long)a.Yi * a.il_m) * a.Zi;
+  const int gx_lo = max(x0 * sx - ppx, 0) >> U;  // first stored x-plane of the halo
+  const long vox_base = ((long)b * a.Xi + gx_lo) * il_m * ((long)a.Yi * il_m) * a.Zi;
   const E* in_base = reinterpret_cast<const E*>(a.in) + vox_base * a.in_ctot;
   const E* in2_base = TWO && a.in2 ? reinterpret_cast<const E*>(a.in2) + vox_base * a.in2_ctot : nullptr;
   unsigned xoff[XK];  // element offset of the lane's voxel + window + piece (TWO: the voxel index; the rest per issue)
@@ -308,13 +322,13 @@ void conv_tile_kernel(const CtArgs a) {
       }
       if (v < L) {
         const unsigned q = fdiv((unsigned)v, Lz, a.mg_Lz), hx = fdiv(q, Ly, a.mg_Ly);
-        const int gx = x0 * a.sx - ppx + (int)hx, gy = y0 * a.sy - ppy + (int)(q - hx * Ly),
-                  gz = z0 * a.sz - a.pz + (int)(v - q * Lz);
+        const int gx = x0 * sx - ppx + (int)hx, gy = y0 * sy - ppy + (int)(q - hx * Ly),
+                  gz = z0 * sz - a.pz + (int)(v - q * Lz);
         if ((unsigned)gx < (unsigned)(a.Xi << U) && (unsigned)gy < (unsigned)(a.Yi << U) &&
             (unsigned)gz < (unsigned)a.Zi) {
           // 32-bit arithmetic on the voxel index relative to plane gx_lo (the host checked the halo's extent)
-          const unsigned vox = ((((unsigned)((gx >> U) - gx_lo)) * a.il_m + a.il_ox) * (a.Yi * a.il_m) +
-                                (gy >> U) * a.il_m + a.il_oy) * a.Zi + gz;
+          const unsigned vox = ((((unsigned)((gx >> U) - gx_lo)) * il_m + il_ox) * (a.Yi * il_m) +
+                                (gy >> U) * il_m + il_oy) * a.Zi + gz;
           off = TWO ? vox : vox * (unsigned)a.in_ctot + (unsigned)(a.in_off + EPP * pl);
         }
       }
@@ -358,7 +372,7 @@ void conv_tile_kernel(const CtArgs a) {
     const unsigned q = fdiv((unsigned)m, a.TZ, a.mg_TZ), ox = fdiv(q, a.TY, a.mg_TY);
     const unsigned oz = m - q * a.TZ, oy = q - ox * a.TY;
     mtab[m] = m < M ? (ox | (oy << 8) | (oz << 16)) : (1u << 24);
-    htab[m] = m < M ? (unsigned short)((ox * a.sx * Ly + oy * a.sy) * Lz + oz * a.sz) : (unsigned short)0;
+    htab[m] = m < M ? (unsigned short)((ox * sx * Ly + oy * sy) * Lz + oz * sz) : (unsigned short)0;
   }
   // per-channel epilogue constants of this workgroup's columns: bias (where it applies) and
   // channel scale * alpha - fetched now, so that the epilogue finds them in LDS instead of waiting for
@@ -368,7 +382,7 @@ void conv_tile_kernel(const CtArgs a) {
     const int co = nt0 * 16 + k;
     const bool in = co < a.Cout;
     btab[k] = (a.bias && in && co < a.act_c1) ? a.bias[co] : 0.f;
-    btab[NTW * 16 + k] = ((a.chan_scale && in) ? a.chan_scale[(long)b * a.Cout + co] : 1.f) * a.alpha;
+    btab[NTW * 16 + k] = ((chan_scale && in) ? chan_scale[(long)b * a.Cout + co] : 1.f) * a.alpha;
   }
   for (int k = t; k < a.nts * TPK; k += NT) {
     int off = 0;
@@ -575,18 +589,18 @@ void conv_tile_kernel(const CtArgs a) {
   // every tile would pay a full memory round trip).  The n-tiles are walked one at a time; the operands
   // of n-tile j+1 (bias, channel scale, residual and mask values of its TM rows) are fetched before the
   // stores of n-tile j are issued.
-  const long vox_per_b = (long)a.Xo * a.Yo * a.Zo * (a.ol_m * a.ol_m * a.ol_mz);
-  const int olx = a.ol_ox + pha, oly = a.ol_oy + phb, oYo = a.Yo * a.ol_m, oZo = a.Zo * a.ol_mz;
+  const long vox_per_b = (long)a.Xo * a.Yo * a.Zo * (ol_m * ol_m * ol_mz);
+  const int olx = ol_ox + pha, oly = ol_oy + phb, oYo = a.Yo * ol_m, oZo = a.Zo * ol_mz;
   const int cob = (nt0 + wn * TN) * 16 + fg * 4;  // this lane's first channel of n-tile j is cob + 16*j
-  const bool fast = a.vec_ok && !a.out_planar && (a.Cout & 3) == 0 && (a.mask_c1 & 3) == 0;
+  const bool fast = SIMPLE || (a.vec_ok && !out_planar && (a.Cout & 3) == 0 && (a.mask_c1 & 3) == 0);
   long mrow[TM];   // flat output voxel of row `fr` of m-tile i, or -1
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
     const unsigned mv = mtab[(wm * TM + i) * 16 + fr];
     const int gx = x0 + (int)(mv & 255), gy = y0 + (int)((mv >> 8) & 255), gz = z0 + (int)((mv >> 16) & 255);
     const bool ok = !(mv >> 24) && gx < a.Xo && gy < a.Yo && gz < a.Zo;
-    mrow[i] = ok ? (long)b * vox_per_b + ((long)(gx * a.ol_m + olx) * oYo + gy * a.ol_m + oly) * oZo +
-                       gz * a.ol_mz + a.ol_oz
+    mrow[i] = ok ? (long)b * vox_per_b + ((long)(gx * ol_m + olx) * oYo + gy * ol_m + oly) * oZo +
+                       gz * ol_mz + ol_oz
                  : -1;
   }
   if (part) {  // split reduction: raw sums, [voxel][16*NT_total] fp32 rows; the reduce pass applies the epilogue
@@ -722,7 +736,7 @@ void conv_tile_kernel(const CtArgs a) {
       for (int q = 0; q < 4; ++q) {
         if (co0 + q >= a.Cout) continue;
         float x = v[q];
-        if (a.out_planar) {
+        if (out_planar) {
           reinterpret_cast<float*>(a.out)[((long)b * a.Cout + co0 + q) * vox_per_b + vi] = x;
         } else {
           if (a.res && co0 + q < a.res_c1)
@@ -751,7 +765,7 @@ void conv_tile_kernel(const CtArgs a) {
 
 static inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 
-template <int WM, int WN, int TM, int TN, int TPK, bool MASK = false, class T = BF16, int WK = 1>
+template <int WM, int WN, int TM, int TN, int TPK, bool MASK = false, class T = BF16, int WK = 1, int SIMPLE = 0>
 int launch_ct(CtArgs& a, hipStream_t st) {
   constexpr int WAVES = WM * WN * WK, NTW = WN * TN;
   const int taps = a.KX * a.KY * a.KZ;
@@ -773,6 +787,12 @@ int launch_ct(CtArgs& a, hipStream_t st) {
   if (a.ol_mz < 1) a.ol_mz = 1;
   if (a.nphase != 4) a.nphase = 1;
   if ((a.il_m > 1 || a.ol_m > 1 || a.ol_mz > 1 || a.nphase > 1) && (a.ups || a.sx != 1 || a.sy != 1 || a.sz != 1)) return WSR_EUNSUPPORTED;
+  if constexpr (SIMPLE) {  // what the kernel's SIMPLE form takes for granted (the caller goes on to the general instantiation)
+    if (a.sx != 1 || a.sy != 1 || a.sz != 1 || a.il_m != 1 || a.ol_m != 1 || a.ol_mz != 1 || a.nphase != 1 || a.ups ||
+        a.il_ox || a.il_oy || a.ol_ox || a.ol_oy || a.ol_oz || a.out_planar || !a.vec_ok || (a.Cout & 3) || (a.mask_c1 & 3))
+      return WSR_EUNSUPPORTED;
+    if (SIMPLE == 1 && (a.chan_scale || a.in2 || a.out2)) return WSR_EUNSUPPORTED;
+  }
   const int L = ((a.TX - 1) * a.sx + a.KX) * ((a.TY - 1) * a.sy + a.KY) * ((a.TZ - 1) * a.sz + a.KZ);
   if (L > 65535) return WSR_EUNSUPPORTED;
   a.nts = (taps + TPK - 1) / TPK;
@@ -853,7 +873,7 @@ int launch_ct(CtArgs& a, hipStream_t st) {
   constexpr bool PIPE = TN <= 7 || WAVES <= 4;
   if (a.mask_y && !MASK) return WSR_EUNSUPPORTED;
   if (std::is_same<T, F32>::value) a.ws = nullptr;  // (the split-reduction second pass writes bf16)
-  auto kern = conv_tile_kernel<WM, WN, TM, TN, TPK, PIPE, MASK, T, WK>;
+  auto kern = conv_tile_kernel<WM, WN, TM, TN, TPK, PIPE, MASK, T, WK, SIMPLE>;
   static bool attr_done = false;
   if (!attr_done) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -875,6 +895,7 @@ int launch_ct(CtArgs& a, hipStream_t st) {
   a.ksplit = 1;
   a.part = nullptr;
   const int wg = a.ntiles * a.nphase * a.ngroups;
+  if (SIMPLE && a.ws && wg <= 128 && a.nchunks >= 4) return WSR_EUNSUPPORTED;  // (might split the reduction: general form)
   if (a.ws && wg <= 128 && a.nchunks >= 4 && a.nphase == 1 && a.ol_m == 1 && a.ol_mz == 1 && !a.res && !a.mask_y && !a.chan_scale &&
       !a.out_planar && a.act <= 1 && a.act_c1 == 0x7FFFFFFF && (a.Cout & 3) == 0 && a.vec_ok && !WSR_ENV_SET("WSR_CT_NOSPLITK")) {
     int ks = 256 / wg;

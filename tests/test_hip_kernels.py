@@ -1539,3 +1539,52 @@ def test_conv_thin_paired_stores_equal_the_plain_form(hip, monkeypatch):
             assert bool((rest == 7.0).all())
     monkeypatch.delenv("WSR_CT3_PAIR")
     reload_wsr_env()
+
+
+@pytest.mark.gpu
+def test_conv_tile_simple_instantiations_equal_the_general_ones(hip, monkeypatch):
+    """conv_tile_simple_*.hip: the trunk's plain stride-1 launches run instantiations whose stride / lattice / parity /
+    split-reduction / planar-output switches are compile-time constants (fewer spilled SGPRs, half the code).  Same
+    arithmetic in the same order: bit-identical to the general instantiations (WSR_CT_SIMPLE=0) on the split dense-block
+    forward (128-wide block-input part with bias + LeakyReLU on the first window only, 32-wide second stage with the
+    partial sums joining before the activation), on the stacked input gradient's windows (128-wide accumulate, 32-wide
+    with the LeakyReLU-backward mask) - at the trunk's tile sizes and on a small volume (128-voxel tiles, K-step shares)."""
+    o = ops()
+    dt = torch.bfloat16
+    gen = torch.Generator().manual_seed(11)
+    nf, gc, ctot = 128, 32, 256
+    for xyz in ((32, 32, 64), (16, 16, 10), (16, 24, 40)):
+        buf0 = (torch.randn((1,) + xyz + (ctot,), generator=gen) * 0.5).to(dt).to(DEV)
+        gd0 = (torch.randn((1,) + xyz + (ctot,), generator=gen) * 0.5).to(dt).to(DEV)
+        w_pre = torch.randn((4 * gc, nf, 3, 3, 3), generator=gen) / math.sqrt(nf * 27)
+        w_grow = torch.randn((gc, 2 * gc, 3, 3, 3), generator=gen) / math.sqrt(2 * gc * 27)
+        b_pre = torch.randn(4 * gc, generator=gen).to(DEV)
+        b_grow = torch.randn(gc, generator=gen).to(DEV)
+        f_pre = o.pack_filter_frag(packed_master(w_pre), dtype=dt)
+        f_grow = o.pack_filter_frag(packed_master(w_grow), dtype=dt)
+        ft_pre = o.pack_filter_frag(packed_master(w_pre), transpose=True, dtype=dt)
+        ft_grow = o.pack_filter_frag(packed_master(w_grow), transpose=True, dtype=dt)
+        d_pre = o.make_desc(o.ConvGeom(nf, 4 * gc, (3, 3, 3), (1, 1, 1), (1, 1, 1)), dt, 1, xyz, ctot, 0, ctot, nf)
+        d_grow = o.make_desc(o.ConvGeom(2 * gc, gc, (3, 3, 3), (1, 1, 1), (1, 1, 1)), dt, 1, xyz, ctot, nf, ctot, nf + 2 * gc)
+        # input gradients: 128 produced channels from the 4*gc growth gradients; 32 produced from 2*gc of them, masked
+        g_pre = o.make_desc(o.ConvGeom(nf, 4 * gc, (3, 3, 3), (1, 1, 1), (1, 1, 1)), dt, 1, xyz, ctot, 0, ctot, nf)
+        g_grow = o.make_desc(o.ConvGeom(gc, 2 * gc, (3, 3, 3), (1, 1, 1), (1, 1, 1)), dt, 1, xyz, ctot, nf, ctot, nf + gc)
+        ft_win = o.pack_filter_frag(packed_master(torch.randn((2 * gc, gc, 3, 3, 3), generator=gen) / math.sqrt(gc * 27)),
+                                    transpose=True, dtype=dt)
+        outs = []
+        for simple in ("0", "1"):
+            monkeypatch.setenv("WSR_CT_SIMPLE", simple)
+            reload_wsr_env()
+            buf, gd = buf0.clone(), gd0.clone()
+            assert o.conv_fwd_tile(d_pre, buf, f_pre, buf, bias=b_pre, act=True, slope=0.2, act_c1=gc)
+            assert o.conv_fwd_tile(d_grow, buf, f_grow, buf, bias=b_grow, res=buf, res_off=nf + 2 * gc, beta=1.0, act=2,
+                                   slope=0.2)
+            assert o.conv_dgrad_tile(g_grow, gd, ft_win, gd, alpha=1.0, accumulate=True, mask=(buf, nf, 0, gc, 0.2))
+            assert o.conv_dgrad_tile(g_pre, gd, ft_pre, gd, alpha=1.0, accumulate=True)
+            outs.append((buf, gd))
+        assert torch.equal(outs[0][0], outs[1][0]), xyz
+        assert torch.equal(outs[0][1], outs[1][1]), xyz
+        assert not torch.equal(outs[1][0], buf0) and not torch.equal(outs[1][1], gd0)
+        assert bool(torch.isfinite(outs[1][0].float()).all()) and bool(torch.isfinite(outs[1][1].float()).all())
+    monkeypatch.delenv("WSR_CT_SIMPLE")
+    reload_wsr_env()
