@@ -254,8 +254,7 @@ int wsr_wgrad_tile_bf16(const wsr_conv_t* c, const void* x, const void* dy, floa
                         int x2_c0);  // conv_wgrad_tile.hip
 
 int wsr_wgrad_tile_f32(const wsr_conv_t* c, const void* x, const void* dy, float* dw, long part_stride, int n_parts,
-                       int* plan, void* stream, const void* x2, int x2_ctot, int x2_c0, int tri_base,
-                       int tri_step);  // conv_wgrad_tile_f32.hip
+                       int* plan, void* stream, const void* x2, int x2_ctot, int x2_c0);  // conv_wgrad_tile_f32.hip
 
 // shared body: accumulate (part_stride = 0), deterministic parts (part_stride > 0) or plan only (plan != nullptr)
 // x2 != NULL: the input's channels >= x2_c0 live in a second tensor (tile kernels only)
@@ -265,12 +264,12 @@ static int wgrad_any(const wsr_conv_t* c, const void* x, const void* dy, float* 
   {  // stride-1 bf16 convs: LDS-tile kernel (x / dy read once per tile, not per tap)
     const int rc = wsr_wgrad_tile_bf16(c, x, dy, dw, tri_base, tri_step, part_stride, n_parts, plan, stream, x2, x2_ctot,
                                        x2_c0);
-    if (rc != WSR_EUNSUPPORTED || (tri_step > 0 && c->dtype != WSR_F32)) return rc;
+    if (rc != WSR_EUNSUPPORTED || tri_step > 0) return rc;
   }
   if (c->lat) return WSR_EUNSUPPORTED;  // parity convs of the sub-pixel form: tile kernels only
-  if (c->dtype == WSR_F32) {  // stride-1 fp32 convs: LDS-tile kernel (all taps per workgroup; round 5: the stacked form too)
-    const int rc = wsr_wgrad_tile_f32(c, x, dy, dw, part_stride, n_parts, plan, stream, x2, x2_ctot, x2_c0, tri_base, tri_step);
-    if (rc != WSR_EUNSUPPORTED || tri_step > 0) return rc;
+  if (c->dtype == WSR_F32 && tri_step == 0) {  // stride-1 fp32 convs: LDS-tile kernel (all taps per workgroup)
+    const int rc = wsr_wgrad_tile_f32(c, x, dy, dw, part_stride, n_parts, plan, stream, x2, x2_ctot, x2_c0);
+    if (rc != WSR_EUNSUPPORTED) return rc;
   }
   if (x2) return WSR_EUNSUPPORTED;  // the per-tap kernel reads one tensor
   const int epp = c->dtype == WSR_BF16 ? 8 : 4;

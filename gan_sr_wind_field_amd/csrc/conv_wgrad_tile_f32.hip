@@ -35,12 +35,6 @@ struct WgfArgs {
   int xp_bytes, yp_bytes;       // one c-tile plane of the x image / one n-tile plane of the dy image
   int buf_bytes;                // x image + dy image of one buffer
   long part_stride;             // > 0: split s STORES its sums at dw + s*part_stride; 0: float atomics into dw
-  // Stacked growth convs of a residual dense block (wsr_conv3d_wgrad_tri, reference torch_blocks.py:256-267): row n of dw
-  // belongs to conv n / tri_step, which reads input channels [0, tri_base + (n / tri_step) * tri_step) only - n-tiles whose
-  // conv does not reach this workgroup's c-chunk are skipped, (n-chunk, c-chunk) pairs without any are not launched.
-  int tri_base, tri_step;
-  int n_active;
-  unsigned char act_nc[64], act_cc[64];
 };
 
 __device__ __forceinline__ void wgf_glds16(const void* gsrc, unsigned lds_addr) {
@@ -68,30 +62,11 @@ __global__ __launch_bounds__(512) void wgrad_tile_f32_kernel(const WgfArgs a) {
   const unsigned buf_lds = (unsigned)(unsigned long)(lptr_t)smem;
 
   int bid = xcd_remap(blockIdx.x, gridDim.x);
-  int cc, nc, s0;
-  if (a.n_active > 0) {
-    const int pr = bid % a.n_active;
-    s0 = bid / a.n_active;
-    cc = a.act_cc[pr];
-    nc = a.act_nc[pr];
-  } else {
-    cc = bid % a.c_chunks; bid /= a.c_chunks;
-    nc = bid % a.n_chunks;
-    s0 = bid / a.n_chunks;
-  }
+  const int cc = bid % a.c_chunks; bid /= a.c_chunks;
+  const int nc = bid % a.n_chunks;
+  const int s0 = bid / a.n_chunks;
   const int c0 = cc * 16 * CT, n0 = nc * 16 * TN;
   const int U = a.ups ? 1 : 0;
-  bool act[TN];  // (uniform) n-tile i takes part: it exists and, in the stacked form, its conv reads this c-chunk
-#pragma unroll
-  for (int i = 0; i < TN; ++i) {
-    const int n = n0 + 16 * i;
-    bool ok = n < a.Cout;
-    if (ok && a.tri_step > 0) {
-      const int n_last = (n + 15 < a.Cout) ? n + 15 : a.Cout - 1;
-      ok = c0 < a.tri_base + a.tri_step * (n_last / a.tri_step);
-    }
-    act[i] = ok;
-  }
   // the tensor this workgroup's c-chunk lives in (wsr_conv3d_wgrad_parts_x2: the generator's concat as two tensors)
   const bool second = a.x2 != nullptr && c0 >= a.x2_c0;
   const float* xt = second ? a.x2 : a.x;
@@ -206,8 +181,7 @@ __global__ __launch_bounds__(512) void wgrad_tile_f32_kernel(const WgfArgs a) {
         else bfn = *reinterpret_cast<const float*>(xn + soff[0]);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int i = 0; i < TN; ++i)
-          if (act[i]) acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i], bf[j & 1], acc[j][i], 0, 0, 0);
+        for (int i = 0; i < TN; ++i) acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i], bf[j & 1], acc[j][i], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
       }
       xr = xn;
@@ -230,7 +204,7 @@ __global__ __launch_bounds__(512) void wgrad_tile_f32_kernel(const WgfArgs a) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int n = n0 + 16 * i + 4 * fg + r;
-        if (act[i] && n < a.Cout) {
+        if (n < a.Cout) {
           float* q = dwp + ((long)n * taps + tap) * a.Cin + c;
           if (store) *q = acc[j][i][r];
           else atomicAdd(q, acc[j][i][r]);
@@ -277,28 +251,7 @@ int launch_wgf(WgfArgs& a, int n_parts, int* plan, hipStream_t st) {
   a.ntiles = (int)ntiles;
   a.n_chunks = (a.Cout + 16 * TN - 1) / (16 * TN);
   a.c_chunks = (a.Cin + 16 * CT - 1) / (16 * CT);
-  int combos = a.n_chunks * a.c_chunks;
-  a.n_active = 0;
-  if (a.tri_step > 0) {  // the pairs the triangular structure leaves empty are not launched (same predicate as the kernel's)
-    if (combos > 64) return WSR_EUNSUPPORTED;
-    for (int nc = 0; nc < a.n_chunks; ++nc)
-      for (int cc = 0; cc < a.c_chunks; ++cc) {
-        bool any = false;
-        for (int i = 0; i < TN; ++i) {
-          const int n = nc * 16 * TN + 16 * i;
-          if (n >= a.Cout) continue;
-          const int n_last = (n + 15 < a.Cout) ? n + 15 : a.Cout - 1;
-          any = any || cc * 16 * CT < a.tri_base + a.tri_step * (n_last / a.tri_step);
-        }
-        if (any) {
-          a.act_nc[a.n_active] = (unsigned char)nc;
-          a.act_cc[a.n_active] = (unsigned char)cc;
-          ++a.n_active;
-        }
-      }
-    if (a.n_active == 0) return WSR_EINVAL;
-    combos = a.n_active;
-  }
+  const int combos = a.n_chunks * a.c_chunks;
   int S = 256 / combos;  // ONE round of workgroups over the 256 CUs (a 257th workgroup would double the launch time)
   if (S > a.ntiles) S = a.ntiles;
   if (S < 1) S = 1;
@@ -323,9 +276,8 @@ int launch_wgf(WgfArgs& a, int n_parts, int* plan, hipStream_t st) {
 // WSR_EUNSUPPORTED: shape outside this kernel (strided / lattice convs, ragged channel windows) - the caller falls back
 // to the per-tap kernel.  part_stride / n_parts / plan as in wsr_wgrad_tile_bf16.
 int wsr_wgrad_tile_f32(const wsr_conv_t* c, const void* x, const void* dy, float* dw, long part_stride, int n_parts,
-                       int* plan, void* stream, const void* x2, int x2_ctot, int x2_c0, int tri_base, int tri_step) {
+                       int* plan, void* stream, const void* x2, int x2_ctot, int x2_c0) {
   if (c->dtype != WSR_F32 || (c->sx | c->sy | c->sz) != 1 || c->lat) return WSR_EUNSUPPORTED;
-  if (tri_step > 0 && (x2 || c->upsample_xy || tri_step % 16 || tri_base % 16 || c->Cout % tri_step)) return WSR_EUNSUPPORTED;
   if (x2 && (c->upsample_xy || x2_c0 <= 0 || x2_c0 >= c->Cin || x2_c0 % 128 || x2_ctot % 4 || c->Cin - x2_c0 > x2_ctot))
     return WSR_EUNSUPPORTED;  // (x2_c0 a multiple of every instantiation's c-chunk: 16 .. 128 channels)
   const int taps = c->KX * c->KY * c->KZ;
@@ -336,7 +288,6 @@ int wsr_wgrad_tile_f32(const wsr_conv_t* c, const void* x, const void* dy, float
   WgfArgs a{};
   a.x = (const float*)x; a.dy = (const float*)dy; a.dw = dw;
   a.x2 = (const float*)x2; a.x2_ctot = x2_ctot; a.x2_c0 = x2_c0;
-  a.tri_base = tri_base; a.tri_step = tri_step;
   a.B = c->B; a.Xi = c->Xi; a.Yi = c->Yi; a.Zi = c->Zi; a.Xo = c->Xo; a.Yo = c->Yo; a.Zo = c->Zo;
   a.Cin = c->Cin; a.in_ctot = c->in_ctot; a.in_off = c->in_off;
   a.Cout = c->Cout; a.out_ctot = c->out_ctot; a.out_off = c->out_off;

@@ -52,9 +52,6 @@ WGRAD_STREAM = int(__import__("os").environ.get("WSR_WGRAD_STREAM", "0"))
 #: fp32 programs (the reference's own arithmetic) on the LDS halo-tile kernels too: stride-1 convs, dense-block stacking,
 #: the z-folded last conv (WSR_F32_TILE=0: generic implicit-GEMM kernels as in rounds 1-3)
 F32_TILE = __import__("os").environ.get("WSR_F32_TILE", "1") != "0"
-#: ... and the filter gradients of a dense block's growth convs as ONE block-triangular launch in fp32 as well
-#: (WSR_F32_TRI=0: one launch per conv, rounds 3-4)
-F32_TRI = __import__("os").environ.get("WSR_F32_TRI", "1") != "0"
 #: the LeakyReLU backward of the discriminator's first conv in the epilogue of the strided input gradient above it
 #: (WSR_FOLD_D_MASK=1; default off: measured equal - same-device A/B 97.5 / 97.5 against 97.5 / 98.0 ms per step - the
 #: masked 32-wide parity launches grow by what the pass over the 128^3 x 32 tensor costs; parity-tested either way)
@@ -484,9 +481,7 @@ class ProgramBase:
         (``wsr_conv3d_wgrad_tri``) - conv i reads channels [0, nf + i*gc) of ``buf`` and its output
         gradient sits in channels [nf + i*gc, nf + (i+1)*gc) of ``gd``; fp32: one launch per conv."""
         nf, gc = convs[0].cin, convs[0].cout
-        # (fp32, round 5: the fp32 tile filter-gradient kernel has the block-triangular form too - WSR_F32_TRI=0: per conv)
-        stacked = ((self.dt == torch.bfloat16 or (F32_TILE and F32_TRI and gc % 16 == 0 and nf % 16 == 0))
-                   and len(convs) > 1 and all(
+        stacked = (self.dt == torch.bfloat16 and len(convs) > 1 and all(
             c.kernel == convs[0].kernel and c.stride == (1, 1, 1) and c.pad == convs[0].pad and c.cout == gc
             and c.cin == nf + i * gc and not c.upsample for i, c in enumerate(convs)))
         if not stacked:
