@@ -184,12 +184,14 @@ template <> __device__ __forceinline__ uint4 ct_zero4<F32>() { return make_uint4
 // every weight stage between them - a volume of 80 tiles leaves three quarters of the chip's SIMDs without a wave while
 // each of its two-wave workgroups walks 28..162 dependent K-steps; with the reduction over four waves the same workgroup
 // is four times shorter, and the partial sums meet in LDS (fixed order: bit-reproducible) before the epilogue.
-// SIMPLE (the trunk's launches - stride 1, no lattice / parity / up-sampling gather, no split reduction, no planar output,
-// whole 4-channel groups; SIMPLE == 1: also no per-sample channel scale and no two-tensor concat, == 2: those stay - the
-// 5x5x5 conv): the general forms' run-time switches become constants.  The kernel
-// takes ~100 uniform arguments and the general epilogue tests many of them per (m-tile, n-tile): the 32-wide instantiation
-// carried 108-185 spilled SGPRs (2 559 v_readlane in 9 500 lines of ISA, a third of its epilogue), i.e. a prologue and an
-// epilogue paid in SGPR reloads on launches that last 16-30 us.
+//
+// SIMPLE != 0 (conv_tile_simple_*.hip: the trunk's launches - stride 1, no lattice / parity / up-sampling gather, no split
+// reduction, no planar output, whole 4-channel groups; launch_ct checks the list): the general forms' run-time switches
+// become constants.  The kernel takes ~100 uniform arguments and the general epilogue tests many of them per (m-tile,
+// n-tile): the 32-wide instantiation carried 108-185 spilled SGPRs (2 559 v_readlane in 9 500 lines of ISA, a third of its
+// epilogue), i.e. a prologue and an epilogue paid in SGPR reloads on launches that last 16-30 us.  SIMPLE == 1 (every shipped
+// instantiation): also no per-sample channel scale and no two-tensor concat; == 2 keeps those two (the 144-wide tile of the
+// 5x5x5 conv: measured, no gain - its 7 ms are main loop - and not instantiated in the library).
 template <int WM, int WN, int TM, int TN, int TPK, bool PIPE, bool MASK, class T = BF16, int WK = 1, int SIMPLE = 0>
 __global__ __launch_bounds__(WM * WN * WK * 64) __attribute__((amdgpu_waves_per_eu(1, WM * WN * WK <= 4 ? 1 : 8)))
 void conv_tile_kernel(const CtArgs a) {
