@@ -12,12 +12,21 @@ L2's memory-side requests, Infinity-Cache hits included - "traffic" is what left
 import collections
 import csv
 import json
+import re
 import sys
 
 
 def short(n):
     n = n.replace("void (anonymous namespace)::", "").replace("(anonymous namespace)::", "")
-    return n.split("(")[0].replace(", BF16>", ">")  # (round 4: the tile kernel's element type is a template parameter)
+    n = n.split("(")[0].replace(", BF16>", ">")  # (round 4: the tile kernel's element type is a template parameter)
+    # round 5: conv_tile_kernel<..., BF16, WK, SIMPLE> - the plain instantiation keeps its old name, the others say what they are;
+    # conv_thin3_kernel<..., PS> likewise (paired stores)
+    n = re.sub(r"(conv_tile_kernel<[^>]*), BF16, 1, 0>", r"\1>", n)
+    n = re.sub(r"(conv_tile_kernel<[^>]*), BF16, (\d+), (\d+)>", lambda m: m.group(1) + (f", WK{m.group(2)}" if m.group(2) != "1" else "")
+               + (", SIMPLE" if m.group(3) != "0" else "") + ">", n)
+    n = re.sub(r"(conv_thin3_kernel<[^>]*), false>", r"\1>", n)
+    n = re.sub(r"(conv_thin3_kernel<[^>]*), true>", r"\1, PS>", n)
+    return n
 
 
 def load(path, counters):
@@ -55,7 +64,7 @@ def main(name, stats_csv):
         # conv_thin.hip (round 4): terrain convs, feature conv, the discriminator's first conv (two samples per launch)
         "conv_thin3_kernel<8, 1, 1, 2, 32, 8>": V * 17 * 2,
         "conv_thin3_kernel<16, 1, 1, 2, 32, 8>": V * 32 * 2,
-        "conv_thin3_kernel<8, 8, 1, 4, 16, 8>": v * 132 * 2,
+        "conv_thin3_kernel<8, 8, 1, 4, 16, 8, PS>": v * 132 * 2,
         "conv_thin3_kernel<8, 1, 2, 2, 32, 4>": 2 * V * 35 * 2,
     }
     rows = []
@@ -84,7 +93,7 @@ def main(name, stats_csv):
                    # (forward and input gradient of terrain_convs.1 are launches of ONE kernel: their mean)
                    ("terrain1_fwd", "conv_thin3_kernel<16, 1, 1, 2, 32, 8>"),
                    ("terrain1_dgrad", "conv_thin3_kernel<16, 1, 1, 2, 32, 8>"),
-                   ("feature_fwd", "conv_thin3_kernel<8, 8, 1, 4, 16, 8>"), ("d0_fwd", "conv_thin3_kernel<8, 1, 2, 2, 32, 4>")):
+                   ("feature_fwd", "conv_thin3_kernel<8, 8, 1, 4, 16, 8, PS>"), ("d0_fwd", "conv_thin3_kernel<8, 1, 2, 2, 32, 4>")):
         r = [x for x in rows if x[1] == k]
         if r:
             traffic[key] = r[0][4] + r[0][5]
