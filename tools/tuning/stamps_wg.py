@@ -52,6 +52,8 @@ CASES = {
     "up": lambda: run("up2 128->128 k3 (64^2 -> 128^2)", 128, 128, (3, 3, 3), (64, 64, 128), 128, 128, 0, ups=True),
     "hr0": lambda: run("hr0 144->144 k5", 144, 144, (5, 5, 5), (128, 128, 128), 144, 144, 0),
     "lff": lambda: run("lff 256->128 k1", 256, 128, (1, 1, 1), LR, 256, 128, 0),
+    "d0": lambda: run("D conv0 3(8)->32 k3 @128^3", 8, 32, (3, 3, 3), (128, 128, 128), 8, 32, 0),
+    "t1": lambda: run("terrain1 16->16 k3 @128^3", 16, 16, (3, 3, 3), (128, 128, 128), 16, 16, 0),
 }
 for n in (sys.argv[1:] or list(CASES)):
     CASES[n]()
