@@ -119,16 +119,19 @@ def granted_cores():
     return max(1, n)
 
 
-def cpu_baseline(n_threads, full=False, budget_s=30.0):
+def cpu_baseline(n_threads, full=False, budget_s=30.0, cap_s=90.0):
     """The oracle (CPU restatement of the reference, kind "port") timed on this host as BASELINE.md section 4 lays out:
     full-size G + D at the reference's own CPU-runnable shapes - C1 (16x16x10 -> 64x64x10, D sliced) and C1b
     (32x32x10 -> 128x128x10), B = 1, fp32, ``n_threads`` threads - G-iterations and D-iterations timed SEPARATELY,
     medians reported, TFLOP/s by the algorithmic FLOPs of BASELINE.md section 3.
 
     ``full``: the procedure to the letter (5 warm-up + 20 timed iterations of each kind, both shapes; minutes - run once
-    per round: ``bench.py --cpu-baseline-full``, profiles/r05_cpu_baseline_full.json).  Default: a BOUNDED sample of the
-    same procedure (the default run must finish in minutes): C1 with 1 warm-up pair and at least 5 timed pairs, C1b
-    with 1 warm-up pair and 1-2 timed pairs, about ``budget_s`` seconds in all.
+    per round: ``bench.py --cpu-baseline-full``, profiles/r06_cpu_baseline_full.json).  Default: a BOUNDED sample of the
+    same procedure (the default run must finish in minutes): 1 warm-up pair and 5 timed pairs at each shape (C1 up to 20
+    while its share of ``budget_s`` lasts) - unless the warm-up pair shows that the 5 would not fit the shape's share of
+    ``cap_s`` seconds of wall clock (a noisy or slow host): then as many timed pairs as do fit, at least one, and the
+    shape's record says ``"truncated": true``.  `value` is extrapolated from the C1b rate (since round 5; rounds 1-4
+    used the C1 rate - the records are not comparable across that change).
     (tools/cpu_baseline_check.py times the real reference beside the oracle in the build container.)"""
     import statistics
     from oracle import gan as ogan
@@ -146,12 +149,18 @@ def cpu_baseline(n_threads, full=False, budget_s=30.0):
         gan = ogan.OracleGAN(sdG, sdD, gs, ds, ogan.TrainSpec(d_g_train_period=1))
         LR, HR, Z, x, y = ogan.synthetic_batch(1, n, 10, 4, seed=2001)
         gan.feed_xy(x, y)
-        warm, lo, hi = (5, 20, 20) if full else (1, 5 if name == "C1" else 1, 20 if name == "C1" else 2)
+        warm, lo, hi = (5, 20, 20) if full else (1, 5, 20 if name == "C1" else 5)
         tw = time.time()
         for i in range(warm):
             gan.optimize_parameters(LR, HR, Z, 2 * i)
             gan.optimize_parameters(LR, HR, Z, 2 * i + 1)
-        print(f"[bench] cpu_baseline {name}: {warm} warm-up pair(s) {time.time() - tw:.1f} s", file=sys.stderr, flush=True)
+        warm_s = time.time() - tw
+        truncated = False
+        if not full and warm_s / warm * lo > share * cap_s:  # the hard minimum would run past the wall-clock cap
+            lo = hi = max(1, int(share * cap_s / (warm_s / warm)))
+            truncated = True
+        print(f"[bench] cpu_baseline {name}: {warm} warm-up pair(s) {warm_s:.1f} s" + (f"; capped at {lo} timed pair(s)" if truncated else ""),
+              file=sys.stderr, flush=True)
         tg, td, t0, i = [], [], time.time(), warm
         while len(tg) < lo or (len(tg) < hi and time.time() - t0 < share * budget_s):
             a = time.perf_counter()
@@ -167,6 +176,7 @@ def cpu_baseline(n_threads, full=False, budget_s=30.0):
         shapes[name] = {"g_it_s": round(mg, 3), "d_it_s": round(md, 3), "pair_s": round(mg + md, 3),
                         "g_it_per_s": round(1 / mg, 4), "d_it_per_s": round(1 / md, 4),
                         "steps_per_s": round(1 / (mg + md), 4), "timed_pairs": len(tg), "warmup_pairs": warm,
+                        "truncated": truncated,
                         "g_it_tflops": round((3 * g_f + 3 * d_f) / mg / 1e12, 3),
                         "d_it_tflops": round((g_f + 6 * d_f) / md / 1e12, 3),
                         "pair_tflops": round((4 * g_f + 9 * d_f) / (mg + md) / 1e12, 3)}
@@ -174,7 +184,12 @@ def cpu_baseline(n_threads, full=False, budget_s=30.0):
     return shapes
 
 
-TRAFFIC_JSON = "profiles/r05_hbm_traffic.json"
+TRAFFIC_JSON = "profiles/r06_hbm_traffic.json"
+
+
+def recorded_traffic_commit():
+    """the commit the PMC passes behind TRAFFIC_JSON were taken at (its ``_commit`` entry)"""
+    return recorded_traffic("_commit")
 
 
 def recorded_traffic(key):
@@ -300,12 +315,13 @@ def main():
     torch.cuda.set_device(dev)
     distributed = wdist.init_from_env(args.backend, single_rank=args.single_rank_group)
     assert distributed == (world > 1 or args.single_rank_group)
-    rccl_ranks = 1
+    ranks_answered = 1
+    over_rccl = bool(distributed and args.backend == "nccl")  # (a gloo rehearsal is not evidence about RCCL)
     if distributed:  # an actual collective, not the environment: this many ranks answered
         ones = torch.ones(1, device=dev)
         torch.distributed.all_reduce(ones)
-        rccl_ranks = int(ones.item())
-        assert rccl_ranks == torch.distributed.get_world_size() == args.gpus
+        ranks_answered = int(ones.item())
+        assert ranks_answered == torch.distributed.get_world_size() == args.gpus
 
     gan, cfg = make_gan(args, dev, args.dtype)
     dp = wdist.attach(gan, bucket_mb=cfg.dist.bucket_mb, sync_bn=cfg.dist.sync_bn) if distributed else None
@@ -390,10 +406,13 @@ def main():
     issued = time.perf_counter() - t0  # host time to issue the steps (the loss guards sync once per G-iteration)
     barrier()
     elapsed = time.perf_counter() - t0
+    rank_ms = [elapsed / args.steps * 1e3]
     if distributed:
-        tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
-        elapsed = float(tmax)
+        mine = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        every = [torch.zeros_like(mine) for _ in range(torch.distributed.get_world_size())]
+        torch.distributed.all_gather(every, mine)
+        rank_ms = [float(t) / args.steps * 1e3 for t in every]  # each rank's own clock around the same K steps
+        elapsed = max(float(t) for t in every)  # the step time the line reports: MAX over ranks
     if kind == "gan":
         loss_ok = all(bool(torch.isfinite(v).all()) for v in gan.get_G_train_loss_dict_ref().values())
         assert loss_ok, "non-finite generator loss in the timed region"
@@ -508,12 +527,18 @@ def main():
         # GLOBAL optimiser steps (one step = all ranks' samples): that quantity is `global_steps_per_s`.
         "global_steps_per_s": round(steps_per_s, 4),
         "value_definition": "n_gpus x global_steps_per_s (sample-normalised whole-job rate, weak scaling)",
+        # (judged only where it is defined: 8 ranks over RCCL at the C3' per-GPU shape; null anywhere else)
         "north_star_target": {"quantity": "global_steps_per_s", "target": 10.0, "at": "n_gpus = 8, batch 1/GPU (C3')",
-                              "met_at_this_n": bool(steps_per_s >= 10.0) if args.config == "C3p" else None},
+                              "met": bool(steps_per_s >= 10.0) if (args.config == "C3p" and world == 8 and over_rccl) else None},
+        "ranks": ranks_answered, "rccl_ranks": ranks_answered if over_rccl else None,
+        "backend": args.backend if distributed else None,
+        "rank_ms_per_step": {"min": round(min(rank_ms), 3), "max": round(max(rank_ms), 3),
+                             "mean": round(sum(rank_ms) / len(rank_ms), 3), "per_rank": [round(v, 3) for v in rank_ms]},
         "config": {"workload": f"{desc}: LR {n}x{n}x{nz} -> HR {sX}x{sX}x{nz} (x{s}), batch {B}/GPU, "
                                f"G 16 RRDB nf128 (34.77M)" + (f", D bf32{' sliced' if slicing else ''}" if kind == "gan" else ""),
                    "preset": args.config, "global_batch": B * world, "parallelism": f"dp{world}",
-                   "rccl_ranks": rccl_ranks, "backend": args.backend if distributed else None,
+                   "ranks": ranks_answered, "rccl_ranks": ranks_answered if over_rccl else None,
+                   "backend": args.backend if distributed else None,
                    "global_steps_per_s": round(steps_per_s, 4), "samples_per_s": round(world * B * steps_per_s, 4),
                    "step_tflop": round(step_flops / 1e12, 2),
                    "achieved_tflops_per_gpu": round(step_flops / 1e12 / (elapsed / args.steps), 1),
@@ -527,6 +552,7 @@ def main():
                      "traffic": recorded_traffic("hr0") if default_shape else None,
                      "traffic_source": TRAFFIC_JSON + " (PMC passes of this round)" if default_shape else None,
                      "traffic_measured_in_run": False,
+                     "traffic_measured_at_commit": recorded_traffic_commit() if default_shape else None,
                      "launches_timed": k_n, "avg_launch_ms": round(k_ms, 3) if k_ms else None},
         "roofline_hbm": {"bound": "hbm", "kernel": "conv1x1_kernel (streaming 1x1x1 GEMM): RDB LFF 256->128 fwd + residuals",
                          "achieved": round(h_ach, 1) if h_ach else None, "peak": 8000.0, "unit": "GB/s",

@@ -321,7 +321,14 @@ class wind_field_GAN_3D(BaseGAN):
             # backward for "every term finite, normalisers from HR" goes out now; the flags are looked at behind it
             later = self._flags_later(flags + [redo])
             L["total"] = full
-            full.backward()
+            try:
+                full.backward()
+            except BaseException:
+                # a backward pass that raises (a HIP error an outer loop catches) must not leave the flags waiting for
+                # the NEXT scalar collective - the discriminator iteration's, whose length would then differ on this rank
+                if self.dp is not None:
+                    self.dp.take_unridden()
+                raise
             bad, bad_core, bad_full, redo = later()
             if bad or redo:  # another total, or another graph: this pass does not count
                 raise _GuardsSaidOtherwise()

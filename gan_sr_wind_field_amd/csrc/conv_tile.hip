@@ -506,6 +506,8 @@ static bool split_width_ok(int n, bool f32, int red, int taps, long vox) {
   return n == 144 && nch * taps >= 256 && vox >= 128L * 512;  // (dispatch_ct: smaller volumes run the 128-voxel tiles)
 }
 
+int wsr_wgrad_split_plan_ok(const wsr_conv_t* c, int c0);  // conv_wgrad.hip
+
 extern "C" int wsr_conv_split_ok(const wsr_conv_t* c, int32_t c0) {
   if (!conv_geom_ok_split(c, c0) || WSR_ENV_SET("WSR_NO_SPLIT_CAT")) return 0;
   if ((c->sx | c->sy | c->sz) != 1 || c->upsample_xy || c->lat) return 0;
@@ -516,7 +518,10 @@ extern "C" int wsr_conv_split_ok(const wsr_conv_t* c, int32_t c0) {
   if (c0 % 128) return 0;  // whole reduction chunks / n-tiles / c-chunks of every kernel involved (16 .. 128 channels)
   const long vox_o = (long)c->B * c->Xo * c->Yo * c->Zo, vox_i = (long)c->B * c->Xi * c->Yi * c->Zi;
   // forward: produced width Cout, reduction Cin; input gradient: produced width Cin, reduction Cout
-  return split_width_ok(c->Cout, f32, c->Cin, taps, vox_o) && split_width_ok(c->Cin, f32, c->Cout, taps, vox_i) ? 1 : 0;
+  if (!split_width_ok(c->Cout, f32, c->Cin, taps, vox_o) || !split_width_ok(c->Cin, f32, c->Cout, taps, vox_i)) return 0;
+  // ... and the filter gradient: its tile planners (slots, LDS, c-chunk alignment at c0) have to accept the two-tensor
+  // input as well, or the engine would find out in the middle of a backward pass
+  return wsr_wgrad_split_plan_ok(c, c0) ? 1 : 0;
 }
 
 extern "C" int wsr_conv3d_fwd_tile(const wsr_conv_t* c, const void* x, const void* wfrag, void* y,

@@ -941,16 +941,28 @@ static void pick_tile(CtArgs& a, int M) {
     // split that covers THIS volume with the fewest tiles - 16 x 16 x 10 (the LR patches of the shipped configurations,
     // config/wind_field_GAN_3D_config_cluster.ini:42-47) needs 3 x 3 = 9 tiles of 7 x 7 x 10 but only 2 x 3 = 6 of 8 x 6 x 10:
     // a third of the trunk's workgroups were padding - and among equals the one with the smallest halo image.
+    // Candidates stay inside what the tables can express and what the square picker's launches could afford: tile
+    // coordinates are packed in 8 bits each (mtab: ox | oy << 8 | oz << 16), so cx, cy <= 255 and no larger than the
+    // extent itself (a needle through a long thin volume would wrap them), and a halo image more than 1.3 x the most
+    // nearly square tile's is refused (it would fail the LDS check and fall back to the generic kernel).
+    const int sxs = a.sx > 0 ? a.sx : 1, sys_ = a.sy > 0 ? a.sy : 1;
+    int sq = 1;
+    while ((sq + 1) * (sq + 1) <= rest) ++sq;
+    const long halo_sq = (long)((sq - 1) * sxs + a.KX) * ((rest / sq - 1) * sys_ + a.KY);
+    const int cx_max = a.Xo < 255 ? (a.Xo > 0 ? a.Xo : 1) : 255, cy_max = a.Yo < 255 ? (a.Yo > 0 ? a.Yo : 1) : 255;
     long best_tiles = -1, best_halo = 0;
-    for (int cx = 1; cx <= rest; ++cx) {
-      const int cy = rest / cx;
+    for (int cx = 1; cx <= rest && cx <= cx_max; ++cx) {
+      int cy = rest / cx;
       if (cy < 1) break;
+      if (cy > cy_max) cy = cy_max;
       const long tiles = (long)((a.Xo + cx - 1) / cx) * ((a.Yo + cy - 1) / cy);
-      const long halo = (long)((cx - 1) * (a.sx > 0 ? a.sx : 1) + a.KX) * ((cy - 1) * (a.sy > 0 ? a.sy : 1) + a.KY);
+      const long halo = (long)((cx - 1) * sxs + a.KX) * ((cy - 1) * sys_ + a.KY);
+      if (halo * 10 > halo_sq * 13) continue;
       if (best_tiles < 0 || tiles < best_tiles || (tiles == best_tiles && halo < best_halo)) {
         best_tiles = tiles; best_halo = halo; tx = cx; ty = cy;
       }
     }
+    if (best_tiles < 0) { tx = sq < cx_max ? sq : cx_max; ty = rest / sq < cy_max ? rest / sq : cy_max; }
   }
   a.TX = tx; a.TY = ty; a.TZ = tz;
 }

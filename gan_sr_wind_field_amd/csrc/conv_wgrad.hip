@@ -294,6 +294,15 @@ static int wgrad_any(const wsr_conv_t* c, const void* x, const void* dy, float* 
                               : dispatch_wgrad<F32>(a, as_stream(stream), plan, n_parts);
 }
 
+// wsr_conv_split_ok's third leg (conv_tile.hip): would the FILTER gradient of this conv run on a tile kernel with its
+// input in two tensors (channels >= c0 in the second)?  The planners are asked, nothing is launched; the second
+// tensor's pointer is a non-NULL placeholder no plan path reads through.
+int wsr_wgrad_split_plan_ok(const wsr_conv_t* c, int c0) {
+  int plan = 0;
+  static const char placeholder[16] = {0};
+  return wgrad_any(c, nullptr, nullptr, nullptr, 0, 0, 0, 0, &plan, nullptr, placeholder, c->Cin - c0, c0) == 0 && plan > 0;
+}
+
 extern "C" int wsr_conv3d_wgrad_tri(const wsr_conv_t* c, const void* x, const void* dy, float* dw, int32_t tri_base,
                                     int32_t tri_step, void* stream) {
   if (!conv_geom_ok(c) || !x || !dy || !dw || tri_base <= 0 || tri_step <= 0) return WSR_EINVAL;

@@ -337,6 +337,7 @@ class DataParallel:
         collective of the loss scalars instead of taking one of its own: that all-reduce is a SUM, and a sum of 0 / 1
         flags is > 0 exactly when one rank set it.  ``on_result(summed)`` is called inside that backward, right behind
         the collective.  A caller whose backward pass may hold no such collective asks ``take_unridden`` afterwards."""
+        assert getattr(self, "_rider", None) is None, "a rider is still waiting: its backward pass never ran a scalar collective"
         self._rider = (flags, on_result)
 
     def take_unridden(self):

@@ -237,7 +237,10 @@ def synthetic_batch(B: int, n: int, nz: int, scale: int, seed: int = 2001, in_ch
     if in_ch > 3:
         zc = Z[:, :, ::scale, ::scale, :]
         zc = (zc - Z.min()) / (Z.max() - Z.min())
-        chans.append(zc.expand(B, in_ch - 3, n, n, nz))
+        # extra input channels (pressure / z / above-ground, wind_field_GAN_3D.py:93-96): the first is the normalised
+        # terrain height as before; any further ones are distinct fields (scaled, mirrored) so a channel mix-up shows
+        extra = [zc] + [(1.0 - zc) * (0.5 + 0.25 * j) if j % 2 else zc.flip(2) * (0.5 + 0.25 * j) for j in range(1, in_ch - 3)]
+        chans.append(torch.cat(extra, dim=1))
     LR = torch.cat(chans, dim=1).contiguous()
     x = torch.arange(sn, dtype=torch.float32) * 200.0
     y = torch.arange(sn, dtype=torch.float32) * 200.0

@@ -141,9 +141,10 @@ def build_ref_D(spec: onets.DSpec):
                 enable_slicing=spec.enable_slicing, dropout_probability=spec.dropout_p, normalization_type=spec.norm)
 
 
-def gen_generators(cases=((4, 6, 5), (8, 4, 4))):
+def gen_generators(cases=((4, 6, 5), (8, 4, 4)), in_ch=4):
+    """``in_ch``: 3 + include_pressure + include_z_channel + include_above_ground_channel (wind_field_GAN_3D.py:93-96)"""
     for scale, n, nz in cases:
-        spec = onets.GSpec(upscale=scale, **G_SMALL)
+        spec = onets.GSpec(upscale=scale, **dict(G_SMALL, in_channels=in_ch))
         G = build_ref_G(spec)
         shapes = onets.g_param_shapes(spec)
         ref_shapes = {k: tuple(v.shape) for k, v in G.state_dict().items()}
@@ -151,7 +152,8 @@ def gen_generators(cases=((4, 6, 5), (8, 4, 4))):
         sd = onets.deterministic_state(shapes, seed=11 + scale, scale=0.7)
         G.load_state_dict(sd)
         G.eval()
-        LR, HR, Z, x, y = synthetic_batch(2, n, nz, scale, seed=5 + scale)
+        LR, HR, Z, x, y = synthetic_batch(2, n, nz, scale, seed=5 + scale, in_ch=in_ch)
+        assert LR.shape[1] == in_ch
         out = G(LR, Z)
         g = torch.Generator().manual_seed(99)
         gy = torch.randn(out.shape, generator=g)
@@ -159,7 +161,7 @@ def gen_generators(cases=((4, 6, 5), (8, 4, 4))):
         arrays = {"out": np_(out), "gy": np_(gy)}
         for k, p in G.named_parameters():
             arrays[f"grad.{k}"] = np_(p.grad)
-        save(f"g_small_s{scale}.npz", **arrays)
+        save(f"g_small_s{scale}.npz" if in_ch == 4 else f"g_small_s{scale}_c{in_ch}.npz", **arrays)
 
 
 def gen_discriminators(cases=((True, 64, 4, "batch"), (False, 128, 3, "batch"), (False, 128, 21, "batch"))):
@@ -430,7 +432,7 @@ def gen_config_golden():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["conv", "blocks", "G", "D", "physics", "trace", "init", "config", "c1", "data", "Dinst", "G16"]
+    which = sys.argv[1:] or ["conv", "blocks", "G", "D", "physics", "trace", "init", "config", "c1", "data", "Dinst", "G16", "Gch"]
     if "config" in which:
         gen_config_golden()
     if "conv" in which:
@@ -444,6 +446,9 @@ if __name__ == "__main__":
         # rounding of zero - the reference's fp32 gradients, an fp64 evaluation and the HIP path then differ pairwise by
         # 2e-3 on everything below it, a property of the input, found in round 5)
         gen_generators(((16, 3, 5),))
+    if "Gch" in which:  # generator input widths 3 / 5 / 6: every other combination of the three channel switches
+        for c in (3, 5, 6):
+            gen_generators(((4, 6, 5),), in_ch=c)
     if "D" in which:
         gen_discriminators()
     if "Dinst" in which:  # normalization_type = "instance" (torch_blocks.py:26-30), both slicing modes (the tail stays "batch")

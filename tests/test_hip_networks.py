@@ -98,6 +98,45 @@ def test_generator_bf16_vs_reference(golden, hip):
     assert not bad, bad
 
 
+@pytest.mark.parametrize("in_ch", [3, 5, 6])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["fp32", "bf16"])
+def test_generator_input_widths_vs_reference(golden, hip, in_ch, dtype):
+    """Generator input widths other than 4: in_channels = 3 + include_pressure + include_z_channel +
+    include_above_ground_channel (reference wind_field_GAN_3D.py:93-96).  The feature conv's channel pieces are 4
+    (fp32) / 8 (bf16) wide, so 3 / 5 / 6 run the piece padding of the forward AND of its filter gradient that 4 does
+    not.  Fixtures ``g_small_s4_c{3,5,6}.npz`` come from the imported reference (make_golden.py ``Gch``)."""
+    g = golden(f"g_small_s4_c{in_ch}.npz")
+    spec = onets.GSpec(upscale=4, in_channels=in_ch, out_channels=3, nf=16, n_rrdb=2, hr_kern=5, gc=8, tf=8)
+    G, _ = build_G(spec, dtype, 15)
+    G.eval()
+    LR, HR, Z, x, y = ogan.synthetic_batch(2, 6, 5, 4, seed=9, in_ch=in_ch)
+    assert LR.shape[1] == in_ch and G.state_dict()["model.0.0.weight"].shape[1] == in_ch
+    out = G(LR.to(DEV), Z.to(DEV))
+    assert out.shape == (2, 3, 24, 24, 5) and out.dtype == torch.float32
+    truth = {k: T(g[f"grad.{k}"]) for k, _ in G.named_parameters()}
+    (out * T(g["gy"]).to(DEV)).sum().backward()
+    if dtype == torch.float32:
+        assert rel_l2(out, T(g["out"])) < 2e-5
+        for k, p in G.named_parameters():
+            assert rel_l2(p.grad, truth[k]) < 2e-4, k
+        return
+    assert rel_l2(out, T(g["out"])) < 2e-2
+    sd = onets.deterministic_state(onets.g_param_shapes(spec), seed=15, scale=0.7)
+    for v in sd.values():
+        v.requires_grad_(True)
+    em = onets.GSpec(upscale=4, in_channels=in_ch, out_channels=3, nf=16, n_rrdb=2, hr_kern=5, gc=8, tf=8,
+                     bf16_storage=True)
+    (onets.generator_forward(sd, LR, Z, em) * T(g["gy"])).sum().backward()
+    lim = _emulated_bf16_bounds(truth, {k: v.grad for k, v in sd.items()})
+    errs = {k: rel_l2(p.grad, truth[k]) for k, p in G.named_parameters()}
+    bad = {k: (v, lim[k]) for k, v in errs.items() if not v < lim[k]}
+    assert not bad, bad
+    # the feature conv's own filter gradient, tightly: against an fp32 evaluation of the same bf16-rounded operands
+    # the emulation's gradient of model.0.0.weight is the nearest statement of that
+    k0 = "model.0.0.weight"
+    assert rel_l2(G.state_dict()[k0], sd[k0].detach()) < 1e-6
+
+
 def test_generator_dropout_mask_and_train_mode(hip):
     """Dropout3d channel mask in the hr0 epilogue / backward == oracle with the same mask."""
     spec = onets.GSpec(upscale=4, in_channels=4, out_channels=3, nf=16, n_rrdb=1, hr_kern=5, gc=8, tf=8,

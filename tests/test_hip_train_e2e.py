@@ -28,7 +28,7 @@ pytestmark = pytest.mark.gpu
 LOSS_KEYS = ["total", "adversarial", "pix", "xy_gradient", "z_gradient", "divergence", "xy_divergence", "feature_D"]
 
 
-def _write_ini(path):
+def _write_ini(path, include_pressure=False, include_z_channel=True, include_above_ground_channel=False):
     from gan_sr_wind_field_amd.config.config import Config
 
     cfg = Config(os.path.join(REPO, "gan_sr_wind_field_amd", "config", "wind_field_GAN_3D_config_local.ini"))
@@ -44,6 +44,10 @@ def _write_ini(path):
     cfg.gan_config.start_date, cfg.gan_config.end_date = [2018, 3, 1], [2018, 3, 1]
     cfg.gan_config.number_of_z_layers = 6
     cfg.gan_config.interpolate_z = False
+    # generator input width = 3 + the three switches (reference wind_field_GAN_3D.py:93-96, process_data.py:457-488)
+    cfg.gan_config.include_pressure = include_pressure
+    cfg.gan_config.include_z_channel = include_z_channel
+    cfg.gan_config.include_above_ground_channel = include_above_ground_channel
     cfg.dataset_train.num_workers = cfg.dataset_val.num_workers = 0
     cfg.dataset_train.batch_size = cfg.dataset_val.batch_size = 2
     cfg.training.use_instance_noise = False
@@ -55,7 +59,10 @@ def _write_ini(path):
     return cfg
 
 
-def test_run_train_and_test_vs_oracle_replay(hip, tmp_path, monkeypatch):
+@pytest.mark.parametrize("flags,in_ch", [(dict(), 4), (dict(include_pressure=True), 5),
+                                         (dict(include_pressure=True, include_above_ground_channel=True), 6)],
+                         ids=["z_4ch", "pressure_z_5ch", "pressure_z_above_ground_6ch"])
+def test_run_train_and_test_vs_oracle_replay(hip, tmp_path, monkeypatch, flags, in_ch):
     from gan_sr_wind_field_amd import process_data as pd
     from gan_sr_wind_field_amd import run as runmod
     from gan_sr_wind_field_amd.GAN_models import wind_field_GAN_3D as gmod
@@ -63,7 +70,7 @@ def test_run_train_and_test_vs_oracle_replay(hip, tmp_path, monkeypatch):
     monkeypatch.chdir(tmp_path)
     monkeypatch.setattr(pd, "DATA_ROOT", str(tmp_path / "data"))
     ini = str(tmp_path / "e2e.ini")
-    ref_cfg = _write_ini(ini)
+    ref_cfg = _write_ini(ini, **flags)
 
     calls, state0, val_calls = [], {}, []
     cls = gmod.wind_field_GAN_3D
@@ -101,6 +108,7 @@ def test_run_train_and_test_vs_oracle_replay(hip, tmp_path, monkeypatch):
         assert os.path.isfile(os.path.join(run_dir, f)), f
     assert {c["it"] for c in val_calls} == {3, 6}
 
+    assert state0["G"]["model.0.0.weight"].shape[1] == in_ch and all(c["LR"].shape[1] == in_ch for c in calls)
     # ---- replay through the oracle from the same initial weights, same batches
     g = ref_cfg.generator
     gs = onets.GSpec(in_channels=state0["G"]["model.0.0.weight"].shape[1], nf=16, n_rrdb=1, gc=8, tf=8, hr_kern=g.hr_kern_size,

@@ -75,6 +75,25 @@ def test_generator_small(golden, scale, n, nz):
         assert rel_l2(v.grad, T(g[f"grad.{k}"])) < 2e-4, k
 
 
+@pytest.mark.parametrize("in_ch", [3, 5, 6])
+def test_generator_input_widths(golden, in_ch):
+    """in_channels = 3 + include_pressure + include_z_channel + include_above_ground_channel
+    (wind_field_GAN_3D.py:93-96): the oracle against the reference's fixtures at the widths other than 4."""
+    g = golden(f"g_small_s4_c{in_ch}.npz")
+    spec = onets.GSpec(upscale=4, in_channels=in_ch, out_channels=3, nf=16, n_rrdb=2, hr_kern=5, gc=8, tf=8)
+    sd = onets.deterministic_state(onets.g_param_shapes(spec), seed=15, scale=0.7)
+    for v in sd.values():
+        v.requires_grad_(True)
+    LR, HR, Z, x, y = ogan.synthetic_batch(2, 6, 5, 4, seed=9, in_ch=in_ch)
+    assert LR.shape[1] == in_ch  # ... of pairwise distinct fields, so a channel mix-up would show
+    assert all(not torch.equal(LR[:, a], LR[:, b]) for a in range(in_ch) for b in range(a))
+    out = onets.generator_forward(sd, LR, Z, spec)
+    assert rel_l2(out, T(g["out"])) < 2e-5
+    (out * T(g["gy"])).sum().backward()
+    for k, v in sd.items():
+        assert rel_l2(v.grad, T(g[f"grad.{k}"])) < 2e-4, k
+
+
 @pytest.mark.parametrize("slicing,xy,nz,norm", [(True, 64, 4, "batch"), (False, 128, 3, "batch"), (False, 128, 21, "batch"),
                                                 (False, 128, 3, "instance"), (True, 64, 4, "instance")])
 def test_discriminator_small(golden, slicing, xy, nz, norm):

@@ -97,6 +97,11 @@ def main(name, stats_csv):
         r = [x for x in rows if x[1] == k]
         if r:
             traffic[key] = r[0][4] + r[0][5]
+    import subprocess
+    try:  # the commit these counter passes were taken at (bench.py prints it beside `traffic`)
+        traffic["_commit"] = subprocess.run(["git", "rev-parse", "--short", "HEAD"], capture_output=True, text=True, check=True).stdout.strip()
+    except (OSError, subprocess.CalledProcessError):
+        traffic["_commit"] = None
     traffic["source"] = f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes '{name}', 2 x FETCH + WRITE, bytes per launch"
     json.dump(traffic, open(f"profiles/{name.split('_')[0]}_hbm_traffic.json", "w"), indent=1)
 
