@@ -164,6 +164,10 @@ class wind_field_GAN_3D(BaseGAN):
     def feed_xy_niter(self, x: torch.Tensor, y: torch.Tensor, niter: torch.Tensor, d_g_train_ratio: int,
                       d_g_train_period: int):
         self.x, self.y, self.niter = x, y, niter
+        # host copy of the iteration budget (ONE read here, none per step): label smoothing and the instance-noise scale
+        # are scalar functions of (it, niter) - evaluated on the host in the reference's fp32 tensor arithmetic they cost
+        # no launches on the step path (round 6: ~50 of the ~350 ATen micro-launches of a G + D iteration pair)
+        self._niter_cpu = niter.detach().to("cpu") if torch.is_tensor(niter) else torch.tensor(niter)
         self.d_g_train_ratio, self.d_g_train_period = d_g_train_ratio, d_g_train_period
 
     # ------------------------------------------------------------ batch-global ops
@@ -177,7 +181,7 @@ class wind_field_GAN_3D(BaseGAN):
 
     def _flags(self, flags) -> list:
         """host-side truth of a list of 0-d device flags in one round trip - set when set on ANY rank"""
-        f = torch.stack([v.reshape(()).to(torch.float32) for v in flags])
+        f = flags.to(torch.float32) if torch.is_tensor(flags) else torch.stack([v.reshape(()).to(torch.float32) for v in flags])
         if self.dp is not None:
             f = self.dp.global_max(f)
         return [v > 0 for v in f.tolist()]
@@ -185,7 +189,7 @@ class wind_field_GAN_3D(BaseGAN):
     def _flags_later(self, flags):
         """the same flags, fetched WITHOUT waiting: the copy to pinned host memory is queued now, the returned callable
         waits for it (by then long finished) and gives the booleans"""
-        f = torch.stack([v.reshape(()).to(torch.float32) for v in flags])
+        f = flags.to(torch.float32) if torch.is_tensor(flags) else torch.stack([v.reshape(()).to(torch.float32) for v in flags])
         host = torch.empty(f.shape, dtype=f.dtype, pin_memory=True)
         done = torch.cuda.Event()
 
@@ -211,6 +215,10 @@ class wind_field_GAN_3D(BaseGAN):
         return get
 
     def _noise(self, sigma: float, shape, it):
+        if torch.device(self.device).type == "cuda" and getattr(self, "_niter_cpu", None) is not None:
+            # scalars on the host (CPU tensors: the reference's own arithmetic), the draw and its scaling on the device
+            it_c = it.detach().cpu() if torch.is_tensor(it) else torch.tensor(int(it))
+            return trainingtricks.instance_noise(torch.tensor(float(sigma)), shape, it_c, self._niter_cpu, device=self.device)
         return trainingtricks.instance_noise(self._scalar(sigma), shape, it, self.niter, device=self.device)
 
     def _scalar(self, v, dtype=None) -> torch.Tensor:
@@ -221,7 +229,14 @@ class wind_field_GAN_3D(BaseGAN):
             return torch.tensor(v, device=self.device) if dtype is None else torch.tensor(v, device=self.device, dtype=dtype)
         if dtype is None:
             dtype = torch.int64 if isinstance(v, int) else torch.float32
-        return torch.full((), v, dtype=dtype, device=self.device)
+        # (read-only constants: one fill per distinct value for the life of the model, not one per use)
+        cache = self.__dict__.setdefault("_scalar_cache", {})
+        key = (v, dtype)
+        if key not in cache:
+            if len(cache) > 64:
+                cache.clear()
+            cache[key] = torch.full((), v, dtype=dtype, device=self.device)
+        return cache[key]
 
     # ------------------------------------------------------------------ D passes
     def D_forward(self, HR: torch.Tensor, fake_HR: torch.Tensor, it: torch.Tensor, train_D: bool):
@@ -291,35 +306,38 @@ class wind_field_GAN_3D(BaseGAN):
         if self.feature_extractor is not None:
             feat = self.feature_D_criterion(self.feature_extractor(HR).detach(), self.feature_extractor(fake_HR))
 
-        L = {
-            "adversarial": adv * t.adversarial_loss_weight,
-            "feature_D": feat * t.feature_D_loss_weight,
-            "pix": pix * t.pixel_loss_weight,
-            "xy_gradient": l_xy * t.gradient_xy_loss_weight,
-            "z_gradient": l_z * t.gradient_z_loss_weight,
-            "divergence": l_div * t.divergence_loss_weight,
-            "xy_divergence": l_div2 * t.xy_divergence_loss_weight,
-        }
+        # The seven weighted terms as ONE vector product and the guards as ONE finiteness test (was a multiply per term,
+        # eight adds and twelve isnan / isinf / or / any launches - the scalar tail of the step is launch-, not work-bound).
         # The reference tests the four physics terms for NaN / Inf (dropping them from the total) and the total
         # itself (skipping the Adam step) in up to 9 host round trips (:434-460); here all flags - plus "a
         # normaliser came from SR" of the fused path - travel in ONE.  Under data parallelism they are OR-ed over
         # the ranks: replicas that took different branches would drift apart for good (parameters are
         # broadcast only once).
-        def nonfinite(v):
-            return torch.logical_or(v.isnan(), v.isinf()).any()
+        keys = ("adversarial", "feature_D", "pix", "xy_gradient", "z_gradient", "divergence", "xy_divergence")
+        wkey = (str(self.device), t.adversarial_loss_weight, t.feature_D_loss_weight, t.pixel_loss_weight, t.gradient_xy_loss_weight,
+                t.gradient_z_loss_weight, t.divergence_loss_weight, t.xy_divergence_loss_weight)
+        if getattr(self, "_loss_w", (None,))[0] != wkey:
+            self._loss_w = (wkey, torch.tensor([float(v) for v in wkey[1:]], dtype=torch.float32).to(self.device))
+        L = {}
 
-        def totals():
-            core = L["adversarial"] + L["pix"] + L["feature_D"]
-            full = (L["adversarial"] + L["pix"] + L["xy_gradient"] + L["z_gradient"] + L["divergence"]
-                    + L["xy_divergence"] + L["feature_D"])
-            physics = torch.stack([L["divergence"], L["xy_divergence"], L["z_gradient"], L["xy_gradient"]])
-            return core, full, [nonfinite(physics), nonfinite(core), nonfinite(full)]
+        def weigh(unweighted):
+            Lv = torch.stack([v.reshape(()) for v in unweighted]) * self._loss_w[1]
+            L.update(zip(keys, Lv.unbind()))
+            L["feature_D"] = L["feature_D"].reshape(1)  # (the reference's placeholder is torch.zeros(1): totals are (1,))
+            return Lv
 
-        core, full, flags = totals()
+        def totals(Lv):
+            core = (Lv[0] + Lv[2] + Lv[1]).reshape(1)
+            full = Lv.sum().reshape(1)
+            bad = ~torch.isfinite(torch.cat([Lv[3:], core, full]))  # [xy, z, div, xydiv | core | full]
+            return core, full, torch.cat([bad[:4].any().reshape(1), bad[4:]])
+
+        Lv = weigh([adv, feat, pix, l_xy, l_z, l_div, l_div2])
+        core, full, flags = totals(Lv)
         redo = sr_branch if sr_branch is not None else torch.zeros((), dtype=torch.bool, device=core.device)
         if training_iteration and getattr(self, "_speculating", False):
             # backward for "every term finite, normalisers from HR" goes out now; the flags are looked at behind it
-            later = self._flags_later(flags + [redo])
+            later = self._flags_later(torch.cat([flags, redo.reshape(1)]))
             L["total"] = full
             try:
                 full.backward()
@@ -338,13 +356,10 @@ class wind_field_GAN_3D(BaseGAN):
                 self.dp.wait()  # the gradient collectives of the skipped step must still complete
             self.log_G_losses(fake_HR, L, training_iteration)
             return full
-        bad, bad_core, bad_full, redo = self._flags(flags + [redo])
+        bad, bad_core, bad_full, redo = self._flags(torch.cat([flags, redo.reshape(1)]))
         if redo and torch.is_grad_enabled():  # rare: SR a hundred times larger than HR (see _content_losses)
             _, l_xy, l_z, l_div, l_div2, _ = self._content_losses(HR, fake_HR, Z, fused=False)
-            L.update({"xy_gradient": l_xy * t.gradient_xy_loss_weight, "z_gradient": l_z * t.gradient_z_loss_weight,
-                      "divergence": l_div * t.divergence_loss_weight,
-                      "xy_divergence": l_div2 * t.xy_divergence_loss_weight})
-            core, full, flags = totals()
+            core, full, flags = totals(weigh([adv, feat, pix, l_xy, l_z, l_div, l_div2]))
             bad, bad_core, bad_full = self._flags(flags)
         total, total_bad = (core, bad_core) if bad else (full, bad_full)
         L["total"] = total
@@ -488,7 +503,12 @@ class wind_field_GAN_3D(BaseGAN):
                       + self.criterion(fake_y_pred - m_real, self.fake_HR_labels)) / 2.0
             # reference (:558-559): ``if torch.all(labels == 0.9): loss_D -= 0.1985`` - the same value without
             # the host round trip of the ``if``
-            loss_D = loss_D - 0.1985 * torch.all(self.HR_labels == 0.9)
+            host = getattr(self, "_labels_all_09", None)
+            if host is not None and host[0] is self.HR_labels:  # labels made on the host (make_new_labels): the test is free
+                if host[1]:
+                    loss_D = loss_D - 0.1985
+            else:
+                loss_D = loss_D - 0.1985 * torch.all(self.HR_labels == 0.9)
         else:
             raise NotImplementedError(f"Only relativistic and relativisticavg GAN are implemented, not {gan_type}")
         if training_epoch:
@@ -500,7 +520,8 @@ class wind_field_GAN_3D(BaseGAN):
     def compute_losses_and_optimize(self, LR, HR, Z, it, training_iteration: bool = False):
         self.batch_size = HR.size(0)
         it_int = int(it)
-        it = self._scalar(it)
+        # (CUDA: the iteration number stays a host tensor - its only uses are scalar schedules evaluated on the host)
+        it = torch.tensor(it_int) if torch.device(self.device).type == "cuda" else self._scalar(it)
         self.make_new_labels(it)
         t = self.cfg.training
         if self.use_D_feature_extractor_cost and it_int % t.feature_D_update_period == 0:
@@ -534,17 +555,30 @@ class wind_field_GAN_3D(BaseGAN):
         """Real / fake label vectors of this iteration (reference :627-678)."""
         t = self.cfg.training
         pred_real, pred_fake = (False, True) if t.flip_labels else (True, False)
-        real = self._scalar(1.0)
-        fake = self._scalar(0.0)
+        on_host = torch.device(self.device).type == "cuda" and getattr(self, "_niter_cpu", None) is not None
+        if on_host:
+            # CUDA: both label vectors on the host in the reference's fp32 arithmetic (the normal draw is a CPU draw there
+            # too, trainingtricks.py:37-39), ONE pinned upload for the pair - was ~25 fill / add / clamp launches
+            it_c = it.detach().cpu() if torch.is_tensor(it) else torch.tensor(int(it))
+            niter, dev, mk = self._niter_cpu, torch.device("cpu"), torch.tensor
+        else:
+            it_c, niter, dev, mk = it, self.niter, self.device, self._scalar
+        real = mk(1.0)
+        fake = mk(0.0)
         if t.use_one_sided_label_smoothing and t.flip_labels:
-            fake = self._scalar(0.1) - 0.1 * it / self.niter
+            fake = mk(0.1) - 0.1 * it_c / niter
         elif t.use_one_sided_label_smoothing:
-            real = self._scalar(0.9) + 0.1 * it / self.niter
+            real = mk(0.9) + 0.1 * it_c / niter
         extra = {} if t.use_noisy_labels else {"noise_stddev": 0.0}
-        self.HR_labels = trainingtricks.noisy_labels(pred_real, self.batch_size, true_label_val=real,
-                                                     false_label_val=fake, device=self.device, **extra).squeeze()
-        self.fake_HR_labels = trainingtricks.noisy_labels(pred_fake, self.batch_size, true_label_val=real,
-                                                          false_label_val=fake, device=self.device, **extra).squeeze()
+        a = trainingtricks.noisy_labels(pred_real, self.batch_size, true_label_val=real, false_label_val=fake, device=dev, **extra)
+        b = trainingtricks.noisy_labels(pred_fake, self.batch_size, true_label_val=real, false_label_val=fake, device=dev, **extra)
+        if on_host:
+            up = torch.stack([a.reshape(-1), b.reshape(-1)]).pin_memory().to(self.device, non_blocking=True)
+            self.HR_labels, self.fake_HR_labels = up[0].squeeze(), up[1].squeeze()
+            self._labels_all_09 = (self.HR_labels, bool(torch.all(a == 0.9)))  # (update_D's reference test, known here)
+        else:
+            self.HR_labels, self.fake_HR_labels = a.squeeze(), b.squeeze()
+            self._labels_all_09 = None
 
     # ------------------------------------------------------------------ getters
     def get_G_train_loss_dict_ref(self):

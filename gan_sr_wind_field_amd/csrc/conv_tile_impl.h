@@ -813,9 +813,21 @@ int launch_ct(CtArgs& a, hipStream_t st) {
   // (one chunk: the second activation buffer would never be filled - the LDS it frees lets a second workgroup share
   // the CU, whose prologue and epilogue then overlap this one's main loop: terrain convs, 3-channel inputs)
   const int xb_first = WSR_ENV_INT("WSR_CT_XBUFS", (a.nchunks == 1 || (NTW == 1 && WSR_ENV_SET("WSR_CT_N16_ONEBUF"))) ? 1 : 2);  // env: tuning aid
+  // Two workgroups per CU for the 32-wide launches (WSR_CT_DIET=1, round 6): their 125 registers leave room for four
+  // waves per SIMD, so a workgroup that keeps to half the LDS (one activation buffer, shorter weight stages) shares
+  // its CU with a second one whose prologue / epilogue / DMA waits then run under this one's K-steps.
+  // Measured (profiles/r06_b_ab_diet.txt, single launches, same device): at batch 4 (1 024 tiles = four rounds) the
+  // 32 -> 32 / 64 -> 32 / 96 -> 32 growth stages take 55.8 / 78.2 / 102.6 us as one 128 KB workgroup per CU and
+  // 45.1 / 69.8 / 98.8 us as two 67 KB ones; at batch 1 (256 tiles: nothing to share a CU with) the single buffer costs
+  // 14.6 -> 15.6, 20.5 -> 23.0, 28.3 -> 33.9 us, and 512 tiles of 256 voxels (WSR_CT_NARROW_M=256) are no better than
+  // that (16.0 / 24.9 / 34.3): the diet is taken from two rounds of workgroups on (WSR_CT_DIET=0 / 1 forces it).
+  const long nwg_all = (long)a.B * ((a.Xo + a.TX - 1) / a.TX) * ((a.Yo + a.TY - 1) / a.TY) * ((a.Zo + a.TZ - 1) / a.TZ) *
+                       ((a.Cout + 16 * NTW - 1) / (16 * NTW)) * (a.nphase == 4 ? 4 : 1);
+  const bool diet = NTW <= 2 && WAVES == 8 && a.nchunks > 1 && WSR_ENV_INT("WSR_CT_DIET", nwg_all >= 512 ? 1 : 0);
+  const int lds_cap = diet ? 80 * 1024 : 160 * 1024;
   for (a.xbufs = xb_first; a.xbufs >= 1; --a.xbufs) {
     a.off_ws = a.off_xs + a.xbufs * (VM ? 1 : PL) * a.P;
-    const int avail = 160 * 1024 - a.off_ws;
+    const int avail = lds_cap - a.off_ws;
     ts_max = avail / (2 * NTW * 1024);
     const int cap_kb = WSR_ENV_INT("WSR_WSTAGE_KB", 48);  // tuning aid
     const int cap = cap_kb / NTW > 0 ? cap_kb / NTW : 1;  // <= 48 KB per weight stage (measured: up-convs +7 %, others flat)

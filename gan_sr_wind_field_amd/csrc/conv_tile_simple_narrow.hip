@@ -13,6 +13,11 @@ int wsr_ct_run_simple_narrow(CtArgs& a, int tpk, int tm3, hipStream_t st) {
     if (a.mask_y) return launch_ct<8, 1, 3, 2, 2, true, BF16, 1, true>(a, st);
     return launch_ct<8, 1, 3, 2, 2, false, BF16, 1, true>(a, st);
   }
+  if (WSR_ENV_INT("WSR_CT_NARROW_M", 512) == 256) {  // (round 6 A/B: twice the workgroups of half the voxels - two per CU with WSR_CT_DIET=1)
+    pick_tile(a, 256);
+    if (a.mask_y) return launch_ct<8, 1, 2, 2, 2, true, BF16, 1, true>(a, st);
+    return launch_ct<8, 1, 2, 2, 2, false, BF16, 1, true>(a, st);
+  }
   pick_tile(a, 512);
   if (a.mask_y) return launch_ct<8, 1, 4, 2, 2, true, BF16, 1, true>(a, st);
   return launch_ct<8, 1, 4, 2, 2, false, BF16, 1, true>(a, st);

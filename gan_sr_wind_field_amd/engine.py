@@ -1741,6 +1741,16 @@ class DiscriminatorProgram(ProgramBase):
         x = xs[0]
         recs = []
         nbt: Dict[int, list] = {}  # num_batches_tracked counters to advance, by identity: [tensor, calls]
+        eval_consts: Dict[int, tuple] = {}
+        if not training:
+            # eval-mode BatchNorm constants of ALL layers in two launches (was an add + an rsqrt per layer)
+            bns = [l.bn for l in self.layers if l.bn is not None and not l.inorm]
+            if bns:
+                with torch.no_grad():
+                    inv = torch._foreach_add([b.running_var.detach().float() for b in bns], [b.eps for b in bns]) \
+                        if len({b.eps for b in bns}) > 1 else torch._foreach_add([b.running_var.detach().float() for b in bns], bns[0].eps)
+                    torch._foreach_rsqrt_(inv)
+                eval_consts = {id(b): (b.running_mean.detach().float(), v) for b, v in zip(bns, inv)}
         for l in self.layers:
             s = l.conv
             g = ConvGeom(s.cin, s.cout, s.kernel, s.stride, s.pad)
@@ -1778,8 +1788,7 @@ class DiscriminatorProgram(ProgramBase):
                 h = a
                 continue
             if not training:
-                mean = bn.running_mean.detach().float()
-                invstd = torch.rsqrt(bn.running_var.detach().float() + bn.eps)
+                mean, invstd = eval_consts[id(bn)]
                 ops.bn_apply_lrelu(y, a, mean, invstd, bn.weight.detach(), bn.bias.detach(), l.act, sl)
                 recs.append(dict(inp=h, y=y, a=a, mean=[mean], invstd=[invstd], count=[float(y.numel() // y.shape[-1])],
                                  training=False, groups=1))
@@ -1862,6 +1871,18 @@ class DiscriminatorProgram(ProgramBase):
         premasked = False  # g already carries the LeakyReLU derivative of the layer it is the output gradient of
         dx = None
         recs = saved["recs"]
+        bn_grad_jobs: Dict[int, tuple] = {}  # group -> (gradient slots, per-channel sums): BatchNorm weight / bias gradients
+
+        def flush_bn_grads():
+            with torch.no_grad():
+                for gi in sorted(bn_grad_jobs):
+                    dst, src = bn_grad_jobs[gi]
+                    if gi == 0:
+                        torch._foreach_copy_(dst, src)
+                    else:
+                        torch._foreach_add_(dst, src)
+            bn_grad_jobs.clear()
+
         for li in reversed(range(len(self.layers))):
             l, r = self.layers[li], recs[li]
             s = l.conv
@@ -1897,12 +1918,12 @@ class DiscriminatorProgram(ProgramBase):
                         sums = sums_all[gi - g0]
                         ops.bn_bwd_reduce(gg, ag, yg, r["mean"][gi], r["invstd"][gi], l.act, sl, sums)
                         if need_dw:  # (every group's batch statistics are a call of their own: the gradients add)
-                            if gi == 0:
-                                sp.view(flat, bn.bias).copy_(sums[:C_])
-                                sp.view(flat, bn.weight).copy_(sums[C_:])
-                            else:
-                                sp.view(flat, bn.bias).add_(sums[:C_])
-                                sp.view(flat, bn.weight).add_(sums[C_:])
+                            # (written behind the layer loop: one foreach copy for the first group of every layer, one
+                            # foreach add per further group - was four 4 us launches per layer)
+                            bn_dst = [sp.view(flat, bn.bias), sp.view(flat, bn.weight)]
+                            bn_grad_jobs.setdefault(gi, ([], []))
+                            bn_grad_jobs[gi][0].extend(bn_dst)
+                            bn_grad_jobs[gi][1].extend([sums[:C_], sums[C_:]])
                     if self.stat_allreduce is not None:
                         sums_all = sums_all.clone()
                         self.stat_allreduce(sums_all)
@@ -1935,6 +1956,7 @@ class DiscriminatorProgram(ProgramBase):
                 if not (lattice_ok and self.strided_wgrad_active(li) and self.strided_wgrad(li, inp, gy, flat, sp)):
                     self.wgrad(s, inp, 0, gy, 0, flat, sp, scratch)
                 if self.grad_ready_hook is not None:
+                    flush_bn_grads()  # (the slots may lie inside the range handed over)
                     hi = sp.offsets[id(s.weight)][0] + (s.weight.numel() + 63) // 64 * 64
                     self.grad_ready_hook(flat, done, hi, self.flush_unpack)
                     done = hi
@@ -1957,6 +1979,7 @@ class DiscriminatorProgram(ProgramBase):
                 dx = torch.empty((inp.shape[0],) + tuple(saved["in_shape"][1:]), dtype=torch.float32, device=dev)
                 self.dgrad(s, gy, 0, dx, 0, tuple(inp.shape[1:4]), dx_planar=True)
         if need_dw:
+            flush_bn_grads()
             self.end_backward()
         if need_dw and self.grad_done_hook is not None:
             self.grad_done_hook()

@@ -35,4 +35,9 @@ def instance_noise(sigma_base: torch.Tensor, shape, it: torch.Tensor, niter: tor
     (The reference's comment says N(0,1) but it draws ``torch.rand``; NaN once
     it > niter + 1, also as in the reference.)
     """
-    return torch.rand(shape, device=device) * torch.sqrt(sigma_base * (1 - (it - 1) / niter))
+    scale = torch.sqrt(sigma_base * (1 - (it - 1) / niter))
+    if scale.device.type == "cpu" and torch.device(device).type == "cuda":
+        # scalars given on the host (wind_field_GAN_3D._noise): the factor is a Python float, draw and scaling are two
+        # launches instead of nine (same values: one fp32 multiply per element by the same fp32 factor)
+        return torch.rand(shape, device=device).mul_(float(scale))
+    return torch.rand(shape, device=device) * scale
