@@ -321,15 +321,20 @@ class wind_field_GAN_3D(BaseGAN):
         L = {}
 
         def weigh(unweighted):
-            Lv = torch.stack([v.reshape(()) for v in unweighted]) * self._loss_w[1]
-            L.update(zip(keys, Lv.unbind()))
+            # two vectors, two graphs: the total WITHOUT the physics terms (taken when one of them is not finite) must not
+            # hang on their graph at all - a zero upstream gradient times a NaN derivative is a NaN in every filter gradient
+            wv = self._loss_w[1]
+            Lc = torch.stack([v.reshape(()) for v in unweighted[:3]]) * wv[:3]
+            Lp = torch.stack([v.reshape(()) for v in unweighted[3:]]) * wv[3:]
+            L.update(zip(keys, Lc.unbind() + Lp.unbind()))
             L["feature_D"] = L["feature_D"].reshape(1)  # (the reference's placeholder is torch.zeros(1): totals are (1,))
-            return Lv
+            return Lc, Lp
 
         def totals(Lv):
-            core = (Lv[0] + Lv[2] + Lv[1]).reshape(1)
-            full = Lv.sum().reshape(1)
-            bad = ~torch.isfinite(torch.cat([Lv[3:], core, full]))  # [xy, z, div, xydiv | core | full]
+            Lc, Lp = Lv
+            core = Lc.sum().reshape(1)
+            full = core + Lp.sum()
+            bad = ~torch.isfinite(torch.cat([Lp, core, full]))  # [xy, z, div, xydiv | core | full]
             return core, full, torch.cat([bad[:4].any().reshape(1), bad[4:]])
 
         Lv = weigh([adv, feat, pix, l_xy, l_z, l_div, l_div2])
