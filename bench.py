@@ -484,6 +484,15 @@ def main():
             blk.update({"algorithmic_gflop": round(flops / 1e9, 2), "hbm_floor_us": round(hbm_us, 2),
                         "mfma_floor_us": round(mfma_us, 2), "binding_roofline": "mfma" if mfma_us > hbm_us else "hbm",
                         "frac_of_binding_roofline": round(max(hbm_us, mfma_us) / (ms_ * 1e3), 4)})
+            if achieved:
+                # ... and the same two floors with the matrix side priced at a rate this chip has been SEEN to hold - the
+                # 5x5x5 conv's own measured rate in this run - instead of the nominal peak: a launch whose arithmetic takes
+                # longer than its bytes at that rate is co-bound, and 0.60 of the HBM figure is then out of its reach
+                ach_us = flops / (achieved * 1e12) * 1e6
+                blk.update({"mfma_floor_us_at_achieved_rate": round(ach_us, 2), "achieved_mfma_rate_tflops": round(achieved, 1),
+                            "binding_roofline_at_achieved_rate": "mfma" if ach_us > hbm_us else "hbm",
+                            "frac_of_binding_roofline_at_achieved_rate": round(max(hbm_us, ach_us) / (ms_ * 1e3), 4),
+                            "hbm_frac_ceiling_at_achieved_rate": round(min(1.0, hbm_us / ach_us), 4)})
         return blk
 
     hr1_flops = 2.0 * V * 125 * c_hr * 3  # (the fold computes 16 columns for 15: counted as the conv's 3 x 125 taps)

@@ -28,8 +28,9 @@ class ProgramStack(nn.Sequential):
     """``Generator_3D.model`` / ``.hr_convs`` / ``.terrain_convs``: the reference's ``nn.Sequential`` (same children,
     same ``state_dict`` keys) whose elements are executed by the generator's HIP program.  Calling the stack, or a
     slice of it - ``G.model[:2](LR)``, ``G.hr_convs[:-2](t)``, ``G.terrain_convs(Z)`` as in the reference's
-    ``plot_data.py:770-793`` - runs those elements one after the other on planar fp32 tensors (inference only: no
-    gradients); the training path is ``Generator_3D.forward``."""
+    ``plot_data.py:770-793`` - runs those elements one after the other on planar fp32 tensors: under ``torch.no_grad()``
+    through the fused program's stages, with gradients enabled layer by layer on the HIP conv kernels (``layerwise.py``:
+    differentiable like the reference's ``nn.Sequential``); the training path is ``Generator_3D.forward``."""
 
     def bind(self, owner: "Generator_3D", name: str, lo: int = 0):
         import weakref
@@ -59,11 +60,14 @@ class ProgramStack(nn.Sequential):
             raise RuntimeError("this stack is not bound to a Generator_3D")
         if not x.is_cuda:
             raise RuntimeError("Generator_3D runs on the MI355X HIP kernels only (no CPU fallback)")
-        if torch.is_grad_enabled() and x.requires_grad:
-            # the reference's nn.Sequential would be differentiable here; this one is not: say so instead of handing
-            # back a tensor that silently carries no graph
-            raise RuntimeError(f"Generator_3D.{self._stack}[...] runs inference only on the HIP program: call it under "
-                               "torch.no_grad() / on a detached input (gradients flow through Generator_3D.forward)")
+        if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
+            # the reference's nn.Sequential is differentiable here (Generator_3D_Resnet_ESRGAN.py:220-229): so is this
+            # one - layer by layer, every convolution (forward, input gradient, filter gradient) a HIP launch
+            # (layerwise.py); under torch.no_grad() / on frozen parameters the fused program below runs instead
+            from .. import layerwise
+            for child in self:
+                x = layerwise.run(child, x, owner.compute_dtype)
+            return x
         prog = owner.program()
         with torch.no_grad():
             for k, child in enumerate(self):

@@ -792,6 +792,56 @@ def test_generator_stacks_are_callable_and_sliceable(hip, dt):
         G.model[:2](LR)  # CPU tensors: no fallback
 
 
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16], ids=["fp32", "bf16"])
+def test_generator_substacks_are_differentiable(hip, dt):
+    """The reference's ``G.model`` / ``G.terrain_convs`` / ``G.hr_convs`` are plain ``nn.Sequential``s: a slice called with
+    gradients enabled is differentiable (reference Generator_3D_Resnet_ESRGAN.py:220-229).  Here such a call runs layer by
+    layer on the HIP conv kernels (layerwise.py): chained as the reference's forward chains them (:225-229) the slices
+    reproduce ``G(LR, Z)``, and their gradients - parameters AND the input - equal the oracle's."""
+    spec = onets.GSpec(in_channels=4, nf=16, n_rrdb=1, gc=8, tf=8, hr_kern=5, upscale=4)
+    G, sd = build_G(spec, dt, 23, scale=0.5)
+    G.eval()
+    LR, HR, Z, x, y = ogan.synthetic_batch(2, 5, 4, 4, seed=6)
+    LRd = LR.to(DEV).requires_grad_(True)
+    Zd = Z.to(DEV)
+    feat = G.model(LRd)
+    assert feat.requires_grad and feat.is_cuda
+    out = G.hr_convs(torch.cat((feat, G.terrain_convs(Zd)), dim=1))
+    with torch.no_grad():
+        fused = G(LRd.detach(), Zd)
+    tol_o, tol_g = (2e-5, 2e-4) if dt == torch.float32 else (2e-2, 6e-2)
+    assert out.shape == fused.shape and rel_l2(out, fused) < tol_o
+    gy = torch.randn(out.shape, generator=torch.Generator().manual_seed(5))
+    (out * gy.to(DEV)).sum().backward()
+    # the oracle on the same inputs (fp32 on the CPU)
+    for v in sd.values():
+        v.requires_grad_(True)
+    LRc = LR.clone().requires_grad_(True)
+    ref = onets.generator_forward(sd, LRc, Z, spec)
+    assert rel_l2(out, ref) < tol_o
+    (ref * gy).sum().backward()
+    truth = dict({k: v.grad for k, v in sd.items()}, LR=LRc.grad)
+    got = dict({k: p.grad for k, p in G.named_parameters()}, LR=LRd.grad)
+    if dt == torch.float32:
+        lim = {k: tol_g for k in truth}
+    else:  # per tensor: what a bf16-storage evaluation of the same graph shows on it (as in test_generator_bf16_vs_reference)
+        sd2 = onets.deterministic_state(onets.g_param_shapes(spec), seed=23, scale=0.5)
+        for v in sd2.values():
+            v.requires_grad_(True)
+        LR2 = LR.clone().requires_grad_(True)
+        em = onets.GSpec(in_channels=4, nf=16, n_rrdb=1, gc=8, tf=8, hr_kern=5, upscale=4, bf16_storage=True)
+        (onets.generator_forward(sd2, LR2, Z, em) * gy).sum().backward()
+        lim = _emulated_bf16_bounds(truth, dict({k: v.grad for k, v in sd2.items()}, LR=LR2.grad))
+    bad = {k: (rel_l2(got[k], truth[k]), lim[k]) for k in truth if got[k] is None or not rel_l2(got[k], truth[k]) < lim[k]}
+    assert not bad, bad
+    # a slice in the middle, a frozen slice (no parameter gradients wanted: the fused stages run) and the no-grad form agree
+    mid = G.model[1:2](G.model[:1](LRd))
+    for p in G.parameters():
+        p.requires_grad_(False)
+    frozen = G.model[:2](LRd.detach())
+    assert not frozen.requires_grad and rel_l2(mid, frozen) < tol_o
+
+
 def test_full_size_generator_properties(hip):
     """Shipped-config G (34.77 M parameters) at 16x16x10 -> 64x64x10: linear response of the
     output to the last conv's bias, bf16 close to fp32, parameter gradients finite."""
