@@ -39,6 +39,7 @@ int wsr_ct_run_tm3(CtArgs& a, int tpk, hipStream_t st);            // conv_tile_
 int wsr_ct_run_narrow_wk(CtArgs& a, int tpk, hipStream_t st);      // conv_tile_narrow_wk.hip
 int wsr_ct_run_simple_narrow(CtArgs& a, int tpk, int tm3, hipStream_t st);  // conv_tile_simple_narrow.hip
 int wsr_ct_run_simple_n128(CtArgs& a, int tpk, int tm3, hipStream_t st);    // conv_tile_simple_n128.hip
+int wsr_ct_run_simple_mid(CtArgs& a, int tpk, hipStream_t st);              // conv_tile_simple_mid.hip
 int wsr_ct_run_simple_small(CtArgs& a, int tpk, hipStream_t st);            // conv_tile_simple_small.hip
 long wsr_ct_tiles(const CtArgs& a, int rows);                      // conv_tile_tm3.hip
 int wsr_ct_run_strided(CtArgs& a, int tpk, hipStream_t st);        // conv_tile_strided.hip
@@ -80,6 +81,12 @@ int dispatch_ct(CtArgs& a, int tpk, hipStream_t st) {
   if (tpk == 2 && ((N > 16 && N <= 32) || (N > 64 && N <= 128 && !a.mask_y)) && a.nphase != 4 && !a.ups && !WSR_ENV_SET("WSR_CT_NO_TM3")) {
     const long n4 = wsr_ct_tiles(a, 512), n3 = wsr_ct_tiles(a, 384);
     tm3 = ((n3 + 255) / 256) * 3 < ((n4 + 255) / 256) * 4;
+  }
+  // the source-grouped stages of a dense block's forward (act = 2 with a partial activation window; engine.conv_dense)
+  if ((simple & 1) && tpk == 2 && N > 32 && N <= 96 && !a.mask_y && a.act == 2 && a.act_c1 != 0x7FFFFFFF && a.nphase != 4 &&
+      !a.ups && !WSR_ENV_SET("WSR_CT_NO_MID")) {
+    const int rc = wsr_ct_run_simple_mid(a, tpk, st);
+    if (rc != WSR_EUNSUPPORTED) return rc;
   }
   if ((simple & 1) && tpk == 2 && N > 16 && N <= 32 && !(WSR_ENV_INT("WSR_CT_NARROW_WK", 0))) {
     const int rc = wsr_ct_run_simple_narrow(a, tpk, tm3, st);

@@ -671,12 +671,13 @@ void conv_tile_kernel(const CtArgs a) {
       float v[4];
       const bool act_here = a.act && co0 < a.act_c1;  // (act_c1 is a multiple of 4)
       if (fast && a.act == 2) {  // second stage of a split conv: the partial sums in `res` join before the activation
+        // (channels >= act_c1 - windows of later convs in a source-grouped stage - stay raw sums: no bias, no activation)
         const float4 rv = ct_cvt4<T>(rr[s][i]);
         const float r4[4] = {rv.x, rv.y, rv.z, rv.w};
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           float x = acc[i][j][q] + bb[s][q] + a.beta * r4[q];
-          x = x > 0.f ? x : x * a.slope;
+          if (act_here) x = x > 0.f ? x : x * a.slope;
           v[q] = x * ss[s][q];
         }
         st4<T>(orow[i] + 16 * j, make_float4(v[0], v[1], v[2], v[3]));

@@ -35,6 +35,13 @@ STACK_DGRAD = __import__("os").environ.get("WSR_STACK_DGRAD", "1") != "0"
 #: split the growth convs of a dense block into one conv over the block input + narrow convs over the growth
 #: channels (WSR_STACK_FWD=0: one launch per conv over its whole input window)
 STACK_FWD = __import__("os").environ.get("WSR_STACK_FWD", "1") != "0"
+#: ... and the growth-channel part of that forward grouped by SOURCE window (round 6, measured and NOT kept: WSR_FWD_REGROUP=1 turns
+#: it on): the window conv j - 1 just produced is contracted into the windows of all later convs at once - 96 / 64 / 32 outputs at a
+#: reduction of one window - instead of every conv re-reading every earlier window (32 outputs at 1 / 2 / 3 windows).  Same FLOPs, fewer
+#: LDS fragment reads and halo bytes per MFMA; at C3' the three launches take 37.2 + 27.5 + 16.6 = 81.3 us against 72 us for the per-conv
+#: stages (step 88.8 vs 87.6 ms, profiles/r06_g_ab_fwd_regroup.txt): prologue and epilogue grow with the produced width (a 96-wide
+#: epilogue re-reads and re-writes three windows of partial sums) and eat what the wider K-steps save.
+FWD_REGROUP = __import__("os").environ.get("WSR_FWD_REGROUP", "0") == "1"
 #: keep the running gradient of a dense block's output in channels [0, nf) of the dense gradient buffer
 #: (WSR_GD_INPLACE=0: separate tensor + one add per block)
 GD_INPLACE = __import__("os").environ.get("WSR_GD_INPLACE", "1") != "0"
@@ -550,6 +557,11 @@ class ProgramBase:
                   nc * gc, nf)]
         specs += [((id(convs[0].weight), "grow", i), [(convs[i].weight, False, nf, i * gc, 0, 0)], gc, i * gc)
                   for i in range(1, nc)]
+        if FWD_REGROUP and self.dt == torch.bfloat16:
+            # by source window j (= the output of conv j - 1, channels [nf + (j-1) gc, nf + j gc)): the rows of convs j .. nc-1
+            specs += [((id(convs[0].weight), "src", j),
+                       [(convs[i].weight, False, nf + (j - 1) * gc, gc, 0, (i - j) * gc) for i in range(j, nc)],
+                       (nc - j) * gc, gc) for j in range(1, nc)]
         return specs
 
     def conv_dense(self, convs: Sequence[ConvSite], buf: Tensor) -> bool:
@@ -573,6 +585,34 @@ class ProgramBase:
             run_pre()
         if not done[0]:
             return False
+        # Grouped by SOURCE window (FWD_REGROUP; volumes of >= 128 tiles of 512 voxels - below that the 128-voxel-tile
+        # kernels run and a launch is one workgroup's dependent K-loop either way): stage j adds the contribution of window
+        # j to the windows of convs j .. nc-1 and completes conv j's (bias + LeakyReLU on its first gc channels only).  Each
+        # later window's partial sums pass through bf16 once per stage (conv 3: three times instead of once).
+        if (FWD_REGROUP and self.dt == torch.bfloat16 and nc > 2 and gc * (nc - 1) <= 96
+                and B * xyz[0] * xyz[1] * xyz[2] >= 128 * 512):
+            for j in range(1, nc):
+                n_out = (nc - j) * gc
+                dj = ops.make_desc(ConvGeom(gc, n_out, k, (1, 1, 1), pad), self.dt, B, xyz, ctot, nf + (j - 1) * gc, ctot,
+                                   nf + j * gc)
+                bj = convs[j].bias.detach() if convs[j].bias is not None else None
+                fr = self.filters.get_stacked((id(convs[0].weight), "src", j))
+                ok = []
+
+                def run_src(dj=dj, bj=bj, fr=fr, off=nf + j * gc, c1=gc if j < nc - 1 else 0):
+                    ok.append(ops.conv_fwd_tile(dj, buf, fr, buf, bias=bj, res=buf, res_off=off, beta=1.0, act=2, slope=sl,
+                                                act_c1=c1))
+
+                if self.launch_probe is not None:
+                    self.launch_probe(f"fwd_dense_src{j}:" + convs[0].name, run_src)
+                else:
+                    run_src()
+                if not ok[0]:
+                    if j == 1:
+                        break  # nothing written yet: the per-conv stages below take over
+                    raise RuntimeError("source-grouped dense-block stage outside the tile kernels (set WSR_FWD_REGROUP=0)")
+            else:
+                return True
         for i in range(1, nc):
             di = ops.make_desc(ConvGeom(i * gc, gc, k, (1, 1, 1), pad), self.dt, B, xyz, ctot, nf, ctot, nf + i * gc)
             bi = convs[i].bias.detach() if convs[i].bias is not None else None
@@ -1468,7 +1508,7 @@ class GeneratorProgram(ProgramBase):
         return flat
 
     def stacked_fwd_specs(self):
-        key = (self.use_tile, STACK_FWD)
+        key = (self.use_tile, STACK_FWD, FWD_REGROUP)
         if self._stack_fwd_specs is None or self._stack_fwd_specs[0] != key:
             specs = [sp for rdbs in self.rrdbs for convs, _, _ in rdbs if STACK_FWD and self.dense_stackable(convs)
                      for sp in self.dense_fwd_specs(convs)]

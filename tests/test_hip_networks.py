@@ -842,6 +842,41 @@ def test_generator_substacks_are_differentiable(hip, dt):
     assert not frozen.requires_grad and rel_l2(mid, frozen) < tol_o
 
 
+def test_dense_forward_grouped_by_source_window(hip, monkeypatch):
+    """Round 6: at large volumes the growth-channel part of a dense block's bf16 forward is grouped by SOURCE window (the
+    window conv j - 1 produced goes into the windows of all later convs in one 96- / 64- / 32-wide launch, engine.conv_dense
+    FWD_REGROUP) instead of by produced window.  Same arithmetic as the reference's RDB (torch_blocks.py:202-214, 278-290):
+    the trunk stage of a generator with 16-channel growth at 32 x 32 x 64 (>= 128 tiles of 512 voxels) against the oracle,
+    and the two groupings against each other (they differ by where partial sums pass through bf16)."""
+    import torch.nn.functional as F
+    from gan_sr_wind_field_amd import engine
+
+    spec = onets.GSpec(in_channels=4, nf=32, n_rrdb=1, gc=16, tf=8, hr_kern=5, upscale=4)
+    G, sd = build_G(spec, torch.bfloat16, 29, scale=0.5)
+    G.eval()
+    g = torch.Generator().manual_seed(3)
+    f = torch.randn((1, 32, 32, 32, 64), generator=g) * 0.5
+    outs, launches = {}, {}
+    for on in (True, False):
+        monkeypatch.setattr(engine, "FWD_REGROUP", on)
+        seen = []
+        prog = G.program()
+        prog.launch_probe = lambda tag, fn, seen=seen: (seen.append(tag.split(":")[0]), fn())[1]
+        with torch.no_grad():
+            outs[on] = G.model[1:2](f.to(DEV)).cpu()
+        prog.launch_probe = None
+        launches[on] = seen
+    assert sum(t.startswith("fwd_dense_src") for t in launches[True]) == 3 * 3 and not any(
+        t.startswith("fwd_dense_grow") for t in launches[True])
+    assert sum(t.startswith("fwd_dense_grow") for t in launches[False]) == 3 * 3 and not any(
+        t.startswith("fwd_dense_src") for t in launches[False])
+    t = f
+    t = onets.rrdb_forward(sd, "model.1.module.0", t, spec)
+    ref = f + F.conv3d(t, sd["model.1.module.1.0.weight"], None, 1, 1)
+    assert rel_l2(outs[True], ref) < 2e-2 and rel_l2(outs[False], ref) < 2e-2
+    assert rel_l2(outs[True], outs[False]) < 6e-3
+
+
 def test_full_size_generator_properties(hip):
     """Shipped-config G (34.77 M parameters) at 16x16x10 -> 64x64x10: linear response of the
     output to the last conv's bias, bf16 close to fp32, parameter gradients finite."""
