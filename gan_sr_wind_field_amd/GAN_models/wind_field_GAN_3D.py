@@ -39,6 +39,9 @@ D_PAIR = __import__("os").environ.get("WSR_D_PAIR", "1") != "0"
 # been issued for the outcome that is the rule - every term finite - instead of stalling the launch queue in front of it.
 # An iteration whose flags then say otherwise is run again from the random-number state it started with (see update_G).
 SPECULATE_GUARDS = __import__("os").environ.get("WSR_SPECULATE_GUARDS", "1") != "0"
+#: the relativistic-average losses (reference :360-364, :552-556) from one launch each, derivatives included (round 6,
+#: wsr_ragan_loss; WSR_FUSED_RAGAN=0: torch's composed ops, ~25 B-element launches per loss and pass)
+FUSED_RAGAN = __import__("os").environ.get("WSR_FUSED_RAGAN", "1") != "0"
 #: ... and stop speculating for a while when the guards keep firing (a dataset whose physics terms are non-finite on
 #: most patches, SR >> HR early in training): every miss costs a whole discarded generator pass, so after this many
 #: CONSECUTIVE misses the next SPEC_BACKOFF generator iterations take the careful path (flags read before backward,
@@ -179,6 +182,23 @@ class wind_field_GAN_3D(BaseGAN):
         """both RaGAN average logits; under data parallelism in ONE collective per pass"""
         return (torch.mean(a), torch.mean(b)) if self.dp is None else self.dp.batch_means(a, b)
 
+    def _ragan(self, u: torch.Tensor, v: torch.Tensor, means_uv) -> torch.Tensor:
+        """( BCEWithLogits(u - mean v, HR_labels) + BCEWithLogits(v - mean u, fake_HR_labels) ) / 2 - the generator's
+        adversarial term with (u, v) = (D(fake), D(real)) (reference :360-364), the discriminator's loss with (D(real),
+        D(fake)) (:552-556).  ``means_uv`` = (mean u, mean v) when the caller already holds the batch-global means.
+        CUDA: forward and all derivatives in one launch (``wsr_ragan_loss``; WSR_FUSED_RAGAN=0: the composed ops)."""
+        if means_uv is None and self.dp is not None:
+            m_u, m_v = self._means(u, v)
+        else:
+            m_u, m_v = means_uv if means_uv is not None else (None, None)
+        if FUSED_RAGAN and u.is_cuda and isinstance(self.criterion, nn.BCEWithLogitsLoss) and u.numel() == v.numel() \
+                and u.numel() == self.HR_labels.numel() == self.fake_HR_labels.numel():
+            from .. import hip_ops
+            return hip_ops.ragan_loss(u, v, self.HR_labels, self.fake_HR_labels, m_u, m_v)
+        if m_u is None:
+            m_u, m_v = self._means(u, v)
+        return (self.criterion(u - m_v, self.HR_labels) + self.criterion(v - m_u, self.fake_HR_labels)) / 2.0
+
     def _flags(self, flags) -> list:
         """host-side truth of a list of 0-d device flags in one round trip - set when set on ANY rank"""
         f = flags.to(torch.float32) if torch.is_tensor(flags) else torch.stack([v.reshape(()).to(torch.float32) for v in flags])
@@ -298,9 +318,7 @@ class wind_field_GAN_3D(BaseGAN):
         if t.gan_type == "relativistic":
             adv = self.criterion(fake_y_pred - y_pred, self.HR_labels)
         else:
-            m_real, m_fake = means[0] if means else self._means(y_pred, fake_y_pred)
-            adv = (self.criterion(fake_y_pred - m_real, self.HR_labels)
-                   + self.criterion(y_pred - m_fake, self.fake_HR_labels)) / 2.0
+            adv = self._ragan(fake_y_pred, y_pred, means[0][::-1] if means else None)
 
         feat = torch.zeros(1, device=self.device)
         if self.feature_extractor is not None:
@@ -503,9 +521,7 @@ class wind_field_GAN_3D(BaseGAN):
         if gan_type == "relativistic":
             loss_D = self.criterion(y_pred - fake_y_pred, self.HR_labels)
         elif gan_type == "relativisticavg":
-            m_real, m_fake = self._means(y_pred, fake_y_pred)
-            loss_D = (self.criterion(y_pred - m_fake, self.HR_labels)
-                      + self.criterion(fake_y_pred - m_real, self.fake_HR_labels)) / 2.0
+            loss_D = self._ragan(y_pred, fake_y_pred, None)
             # reference (:558-559): ``if torch.all(labels == 0.9): loss_D -= 0.1985`` - the same value without
             # the host round trip of the ``if``
             host = getattr(self, "_labels_all_09", None)

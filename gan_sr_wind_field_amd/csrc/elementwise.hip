@@ -943,6 +943,71 @@ __global__ void wind_gradient_bwd_kernel(const float* __restrict__ g, const floa
     }                                          \
   } while (0)
 
+// ---- relativistic average GAN loss, forward + all partial derivatives (wsr_ragan_loss) --------------------------
+// One workgroup: B is the per-GPU batch (1 .. 32 in every shipped configuration).  Sums are taken in a fixed order
+// (lane-strided partials, then a shared-memory tree): bit-reproducible.
+namespace {
+__device__ __forceinline__ float rg_block_sum(float v, float* sh) {
+  const int t = threadIdx.x;
+  sh[t] = v;
+  __syncthreads();
+  for (int s = blockDim.x >> 1; s > 0; s >>= 1) {
+    if (t < s) sh[t] += sh[t + s];
+    __syncthreads();
+  }
+  const float r = sh[0];
+  __syncthreads();
+  return r;
+}
+__device__ __forceinline__ float rg_bce(float x, float t) {  // (1 - t) x - logsigmoid(x)
+  return (1.f - t) * x - (fminf(x, 0.f) - log1pf(expf(-fabsf(x))));
+}
+__device__ __forceinline__ float rg_sigmoid(float x) { return 1.f / (1.f + expf(-x)); }
+
+__global__ __launch_bounds__(256) void ragan_loss_kernel(const float* u, const float* v, const float* lu, const float* lv,
+                                                         const float* mu_in, const float* mv_in, int B, float* out) {
+  __shared__ float sh[256];
+  const int t = threadIdx.x;
+  float su = 0.f, sv = 0.f;
+  if (!mu_in || !mv_in)
+    for (int i = t; i < B; i += 256) { su += u[i]; sv += v[i]; }
+  const float inv = 1.f / (float)B;
+  const float mu = mu_in ? *mu_in : rg_block_sum(su, sh) * inv;
+  const float mv = mv_in ? *mv_in : rg_block_sum(sv, sh) * inv;
+  float loss = 0.f, sa = 0.f, sb = 0.f;
+  for (int i = t; i < B; i += 256) {
+    const float xu = u[i] - mv, xv = v[i] - mu;
+    loss += rg_bce(xu, lu[i]) + rg_bce(xv, lv[i]);
+    const float a = 0.5f * inv * (rg_sigmoid(xu) - lu[i]), b = 0.5f * inv * (rg_sigmoid(xv) - lv[i]);
+    out[1 + i] = a;          // dL/d(u_i - mean v)
+    out[1 + B + i] = b;      // dL/d(v_i - mean u)
+    sa += a;
+    sb += b;
+  }
+  loss = rg_block_sum(loss, sh);
+  sa = rg_block_sum(sa, sh);
+  sb = rg_block_sum(sb, sh);
+  // dL/d mean(u) = -sum b, dL/d mean(v) = -sum a: handed to the caller, or folded into du / dv (mean over these B)
+  if (!mu_in)
+    for (int i = t; i < B; i += 256) out[1 + i] -= sb * inv;
+  if (!mv_in)
+    for (int i = t; i < B; i += 256) out[1 + B + i] -= sa * inv;
+  if (t == 0) {
+    out[0] = 0.5f * inv * loss;
+    out[2 * B + 1] = mu_in ? -sb : 0.f;
+    out[2 * B + 2] = mv_in ? -sa : 0.f;
+  }
+}
+}  // namespace
+
+extern "C" int wsr_ragan_loss(const float* u, const float* v, const float* lu, const float* lv, const float* mu, const float* mv,
+                              int32_t B, float* out, void* stream) {
+  if (!u || !v || !lu || !lv || !out || B < 1 || B > 65536) return WSR_EINVAL;
+  hipLaunchKernelGGL(ragan_loss_kernel, dim3(1), dim3(256), 0, as_stream(stream), u, v, lu, lv, mu, mv, (int)B, out);
+  WSR_LAUNCH_CHECK();
+  return 0;
+}
+
 extern "C" int wsr_abi_version(void) { return WSR_ABI_VERSION; }
 
 extern "C" const char* wsr_error_string(int code) {

@@ -697,6 +697,48 @@ def physics_loss_stats(hr: Tensor, sr: Tensor, xs: Tensor, ys: Tensor, zc: Tenso
     return _PhysicsLossStats.apply(f(hr), f(sr), f(xs), f(ys), f(zc))
 
 
+class _RaganLoss(torch.autograd.Function):
+    """( BCEWithLogits(u - mean v, lu) + BCEWithLogits(v - mean u, lv) ) / 2 with every partial derivative from ONE launch
+    (``wsr_ragan_loss``); the backward is one multiply of the saved derivative vector by the upstream scalar."""
+
+    @staticmethod
+    def forward(ctx, u: Tensor, v: Tensor, lu: Tensor, lv: Tensor, mu: Optional[Tensor], mv: Optional[Tensor]):
+        B = u.numel()
+        flat = [t.detach().reshape(-1).float().contiguous() for t in (u, v, lu, lv)]
+        if any(t.numel() != B for t in flat):
+            raise ValueError("ragan_loss: logits and labels must have one element per sample")
+        sc = [None if m is None else m.detach().reshape(1).float().contiguous() for m in (mu, mv)]
+        _need_cuda(*flat, *sc)
+        out = torch.empty(2 * B + 3, dtype=torch.float32, device=u.device)
+        check(_lib.lib().wsr_ragan_loss(_p(flat[0]), _p(flat[1]), _p(flat[2]), _p(flat[3]), _p(sc[0]), _p(sc[1]), B, _p(out),
+                                        _stream()), "ragan_loss")
+        ctx.save_for_backward(out)
+        ctx.meta = (B, u.shape, v.shape, u.dtype, v.dtype, None if mu is None else (mu.shape, mu.dtype),
+                    None if mv is None else (mv.shape, mv.dtype))
+        return out[0].clone()
+
+    @staticmethod
+    def backward(ctx, g: Tensor):
+        (out,) = ctx.saved_tensors
+        B, us, vs, ud, vd, mum, mvm = ctx.meta
+        d = out[1:] * g
+        du = d[:B].reshape(us).to(ud) if ctx.needs_input_grad[0] else None
+        dv = d[B:2 * B].reshape(vs).to(vd) if ctx.needs_input_grad[1] else None
+        dmu = d[2 * B].reshape(mum[0]).to(mum[1]) if mum is not None and ctx.needs_input_grad[4] else None
+        dmv = d[2 * B + 1].reshape(mvm[0]).to(mvm[1]) if mvm is not None and ctx.needs_input_grad[5] else None
+        return du, dv, None, None, dmu, dmv
+
+
+def ragan_loss(u: Tensor, v: Tensor, lu: Tensor, lv: Tensor, mean_u: Optional[Tensor] = None,
+               mean_v: Optional[Tensor] = None) -> Tensor:
+    """Relativistic average GAN loss of the reference (wind_field_GAN_3D.py:360-364 with u = D(fake), v = D(real);
+    :552-556 with u = D(real), v = D(fake)); ``mean_u`` / ``mean_v``: batch-global means from the caller's collective
+    (both or neither), else the means over these samples."""
+    if (mean_u is None) != (mean_v is None):
+        raise ValueError("ragan_loss takes both means or neither")
+    return _RaganLoss.apply(u, v, lu, lv, mean_u, mean_v)
+
+
 def zfold(t: Tensor, y: Tensor, bias: Optional[Tensor], kz: int, pz: int) -> Tensor:
     """``y[b,c,x,y,z] = bias[c] + sum_k t[b, c*kz+k, x, y, z+k-pz]`` - planar fp32 (see ``wsr_zfold``)."""
     _need_cuda(t, y)

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define WSR_ABI_VERSION 8
+#define WSR_ABI_VERSION 9
 
 enum wsr_dtype { WSR_F32 = 0, WSR_BF16 = 1 };
 
@@ -462,6 +462,20 @@ typedef struct wsr_adam_job {
  *  exp_avg / exp_avg_sq follow torch's to the last bits instead of to 1e-5)                                           */
 int wsr_adam_multi(const wsr_adam_job_t* jobs_dev, int32_t n_jobs, double lr, double beta1, double beta2, double eps,
                    double weight_decay, int32_t step, void* stream);
+
+/* ---- relativistic average GAN loss -------------------------------------------
+ * ABI 9 - the adversarial term of a generator iteration (wind_field_GAN_3D.py:360-364) and the loss of a
+ * discriminator iteration (:552-556), both of the form
+ *     L = ( BCEWithLogits(u - mean(v), lu) + BCEWithLogits(v - mean(u), lv) ) / 2
+ * (generator: u = D(fake), v = D(real); discriminator: u = D(real), v = D(fake); lu / lv the label vectors of
+ * :627-678), forward AND every partial derivative in one launch - the reference's composed ops are ~25 launches of
+ * B-element kernels per loss and pass.  u, v, lu, lv: B floats each.  mu / mv: device scalars holding mean(u) /
+ * mean(v) when the caller computed them (data parallelism: batch-global means from a collective), NULL: taken here
+ * over the B elements and the chain rule through them folded into du / dv.  out: 2 B + 3 floats
+ *     [0] L, [1 .. B] dL/du, [B+1 .. 2B] dL/dv, [2B+1] dL/dmu, [2B+2] dL/dmv   (the last two 0 when mu / mv are NULL)
+ * BCEWithLogits(x, t) = mean_i (1 - t_i) x_i - logsigmoid(x_i), torch's formula.  1 <= B <= 65536.             */
+int wsr_ragan_loss(const float* u, const float* v, const float* lu, const float* lv, const float* mu, const float* mv,
+                   int32_t B, float* out, void* stream);
 
 #ifdef __cplusplus
 }

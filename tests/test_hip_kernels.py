@@ -1585,3 +1585,38 @@ def test_conv_tile_simple_instantiations_equal_the_general_ones(hip, monkeypatch
         assert bool(torch.isfinite(outs[1][0].float()).all()) and bool(torch.isfinite(outs[1][1].float()).all())
     monkeypatch.delenv("WSR_CT_SIMPLE")
     reload_wsr_env()
+
+
+@pytest.mark.parametrize("B", [1, 2, 5, 32, 300])
+@pytest.mark.parametrize("ext_means", [False, True], ids=["own_means", "given_means"])
+def test_ragan_loss_vs_torch(hip, B, ext_means):
+    """``wsr_ragan_loss`` (ABI 9): the relativistic-average GAN loss of the reference (wind_field_GAN_3D.py:360-364 generator
+    term, :552-556 discriminator loss) and all its partial derivatives from one launch, against torch's composed ops
+    (``nn.BCEWithLogitsLoss`` on ``u - mean(v)`` / ``v - mean(u)``) and their autograd - with the means taken inside, and
+    with batch-global means handed in as differentiable scalars (the data-parallel form)."""
+    o = ops()
+    g = torch.Generator().manual_seed(B)
+    u0, v0 = torch.randn(B, generator=g) * 3, torch.randn(B, generator=g) * 3 + 0.5
+    lu = (torch.full((B,), 0.9) + 0.05 * torch.randn(B, generator=g)).clamp(0, 1)
+    lv = (0.05 * torch.randn(B, generator=g)).clamp(0, 1)
+    crit = torch.nn.BCEWithLogitsLoss()
+    w = 1.7  # upstream gradient
+    res = {}
+    for which in ("torch", "hip"):
+        u, v = u0.clone().to(DEV).requires_grad_(True), v0.clone().to(DEV).requires_grad_(True)
+        mu_l, mv_l = (u * 1.0).mean() + 0.1, (v * 1.0).mean() - 0.2  # "global" means: functions of the inputs, not THE means
+        if which == "torch":
+            mu, mv = (mu_l, mv_l) if ext_means else (u.mean(), v.mean())
+            loss = (crit(u - mv, lu.to(DEV)) + crit(v - mu, lv.to(DEV))) / 2.0
+        else:
+            loss = o.ragan_loss(u, v, lu.to(DEV), lv.to(DEV), *((mu_l, mv_l) if ext_means else ()))
+        (loss * w).backward()
+        res[which] = (float(loss), u.grad.cpu(), v.grad.cpu())
+    assert res["hip"][0] == pytest.approx(res["torch"][0], rel=2e-6, abs=1e-7)
+    assert rel_l2(res["hip"][1], res["torch"][1]) < 3e-6 and rel_l2(res["hip"][2], res["torch"][2]) < 3e-6
+    # 0-d logits (batch 1 squeezed, as the train step has them) and a detached real side
+    if B == 1:
+        u, v = u0[0].clone().to(DEV).requires_grad_(True), v0[0].clone().to(DEV)
+        loss = o.ragan_loss(u, v, lu[0].to(DEV), lv[0].to(DEV))
+        loss.backward()
+        assert loss.shape == () and u.grad.shape == () and float(loss) == pytest.approx(res["torch"][0], rel=2e-6) or ext_means

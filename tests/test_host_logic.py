@@ -83,7 +83,7 @@ def test_abi_library_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(lib, name), f"{name} declared in windsr_hip.h but not exported"
     assert set(_lib.EXPORTS) == declared
-    assert _lib.lib().wsr_abi_version() == 8
+    assert _lib.lib().wsr_abi_version() == 9
     assert b"invalid" in _lib.lib().wsr_error_string(-1)
 
 
