@@ -411,12 +411,53 @@ void conv_tile_kernel(const CtArgs a) {
 #ifdef WSR_CT_STAMPS
   long long st_dma = 0, st_bar = 0;  // shader cycles this wave spent waiting for its DMAs / at the phase barrier
 #endif
+  // Epilogue operands requested EARLY (round 6; the 32-wide SIMPLE instantiations: one workgroup per CU by LDS, so the
+  // registers are free): the partial sums / running gradient a launch adds to (`res`) and the saved activation its
+  // LeakyReLU mask is taken from were written by earlier launches - their loads go out at the top of the LAST phase and
+  // land under its K-steps instead of costing a global-memory round trip between the main loop and the first store.
+  // Measured and NOT shipped (build the 32-wide translation units with -DWSR_CT_EPF to have it; profiles/r06_i_ab_epilogue_prefetch.txt):
+  // C3' 90.12 / 90.17 ms with, 89.93 / 90.07 without - the loads' latency was not what the 3 us epilogue is made of - and the
+  // 145-164 registers it takes end the two-workgroups-per-CU form of multi-round launches (C4 332.2 vs 326.8 ms).
+#ifdef WSR_CT_EPF
+  constexpr bool EPF = SIMPLE == 1 && TN <= 2 && WK == 1;
+#else
+  constexpr bool EPF = false;
+#endif
+  V4 pre_rr[EPF ? TN : 1][EPF ? TM : 1], pre_yy[EPF ? TN : 1][EPF ? TM : 1];
+  auto epilogue_prefetch = [&]() __attribute__((always_inline)) {
+    if constexpr (EPF) {
+      const int cob_ = (nt0 + wn * TN) * 16 + fg * 4;
+      const long vpb = (long)a.Xo * a.Yo * a.Zo;
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const unsigned mv = mtab[(wm * TM + i) * 16 + fr];
+        const int gx = x0 + (int)(mv & 255), gy = y0 + (int)((mv >> 8) & 255), gz = z0 + (int)((mv >> 16) & 255);
+        const bool ok = !(mv >> 24) && gx < a.Xo && gy < a.Yo && gz < a.Zo;
+        const long m = ok ? (long)b * vpb + ((long)gx * a.Yo + gy) * a.Zo + gz : -1;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          const int co0 = cob_ + 16 * j;
+          pre_rr[j][i] = ct_zero4<T>();
+          pre_yy[j][i] = ct_ones4<T>();
+          if (m < 0 || co0 >= a.Cout) continue;
+          if (a.res && co0 < a.res_c1)
+            pre_rr[j][i] = *reinterpret_cast<const V4*>(reinterpret_cast<const E*>(a.res) + m * a.res_ctot + a.res_off + co0);
+          if (MASK && a.mask_y && co0 >= a.mask_c0 && co0 < a.mask_c1)
+            pre_yy[j][i] = *reinterpret_cast<const V4*>(reinterpret_cast<const E*>(a.mask_y) + m * a.mask_ctot + a.mask_off +
+                                                        (co0 - a.mask_c0));
+        }
+      }
+    }
+  };
   const int total_phases = nchunks_l * nstages;
   int chunk = 0, st = 0;
   // static priority for the second-dispatched half (it loses the issue arbitration against the older half on
   // every phase otherwise: MI355X_MICROARCH.md, two waves per SIMD, item 4)
   if (a.prio && wave >= WAVES / 2) __builtin_amdgcn_s_setprio(1);
   for (int ph = 0; ph < total_phases; ++ph) {
+    if constexpr (EPF) {
+      if (ph + 1 == total_phases) epilogue_prefetch();
+    }
     // ---- prefetch: next weight stage, and a slice of the next chunk's activations.  The burst costs each
     // wave several hundred issue cycles during which it feeds no MFMAs, so the two halves of the workgroup
     // (waves w and w + WAVES/2 share a SIMD) take turns: the first half issues at the top of the phase, the
@@ -647,6 +688,14 @@ void conv_tile_kernel(const CtArgs a) {
     // LeakyReLU backward of the layer whose output gradient this is (channels [mask_c0, mask_c1)): the
     // multiply by (y > 0 ? 1 : slope) happens in this epilogue, after the accumulation, not in its own pass
     const bool masked = MASK && co0 >= a.mask_c0 && co0 < a.mask_c1;
+    if constexpr (EPF) {  // (requested at the top of the last phase: epilogue_prefetch)
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        rr[s][i] = pre_rr[j][i];
+        yy[s][i] = pre_yy[j][i];
+      }
+      return;
+    }
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
       rr[s][i] = ct_zero4<T>();
