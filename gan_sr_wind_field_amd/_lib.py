@@ -17,7 +17,7 @@ WSR_F32, WSR_BF16 = 0, 1
 WSR_EUNSUPPORTED = -2
 
 EXPORTS = [
-    "wsr_abi_version", "wsr_error_string", "wsr_reload_env", "wsr_ragan_loss", "wsr_conv3d_fwd", "wsr_conv3d_dgrad", "wsr_conv3d_wgrad", "wsr_conv3d_wgrad_tri", "wsr_conv3d_wgrad_nparts", "wsr_conv3d_wgrad_parts", "wsr_conv3d_wgrad_parts_x2", "wsr_conv_split_ok", "wsr_unpack_wgrad_reduce_multi", "wsr_conv3d_fwd_tile", "wsr_conv3d_dgrad_tile",
+    "wsr_abi_version", "wsr_error_string", "wsr_reload_env", "wsr_ragan_loss", "wsr_bn_train_stats", "wsr_conv3d_fwd", "wsr_conv3d_dgrad", "wsr_conv3d_wgrad", "wsr_conv3d_wgrad_tri", "wsr_conv3d_wgrad_nparts", "wsr_conv3d_wgrad_parts", "wsr_conv3d_wgrad_parts_x2", "wsr_conv_split_ok", "wsr_unpack_wgrad_reduce_multi", "wsr_conv3d_fwd_tile", "wsr_conv3d_dgrad_tile",
     "wsr_frag_filter_elems", "wsr_pack_filter_frag", "wsr_pack_filter_frag_multi",
     "wsr_pack_filter", "wsr_unpack_wgrad", "wsr_unpack_wgrad_multi", "wsr_lrelu_bwd_inplace", "wsr_chan_axpby", "wsr_chan_sum", "wsr_chan_sum_rows", "wsr_chan_sum_partials", "wsr_upsample2_bwd", "wsr_subpixel_fold", "wsr_subpixel_unfold", "wsr_strided_parity_filters", "wsr_strided_parity_unfold",
     "wsr_planar_to_ndhwc", "wsr_ndhwc_to_planar", "wsr_zfold", "wsr_zunfold", "wsr_wind_gradient", "wsr_wind_gradient_bwd", "wsr_plane_sum", "wsr_linear_rows", "wsr_physics_loss_workspace_floats", "wsr_physics_loss_stats", "wsr_physics_loss_bwd", "wsr_bn_stats", "wsr_bn_mean", "wsr_bn_shard_stats", "wsr_bn_combine_shards", "wsr_bn_finalize", "wsr_bn_apply_lrelu", "wsr_bn_bwd_reduce",
@@ -136,6 +136,7 @@ def lib() -> C.CDLL:
         "wsr_adam_step": [vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, i32, vp],
         "wsr_adam_multi": [vp, i32, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, i32, vp],
         "wsr_ragan_loss": [vp, vp, vp, vp, vp, vp, i32, vp, vp],   # ABI 9
+        "wsr_bn_train_stats": [vp, i32, i64, i32, f32, f32, vp, vp, vp, vp, i32, vp],   # ABI 9
     }
     for name, argtypes in sig.items():
         fn = getattr(L, name)

@@ -442,22 +442,34 @@ __global__ void bn_combine_shards_kernel(const float* __restrict__ allr, int wor
 
 // from the shifted sums {sum d, sum d^2}, d = x - mean: biased variance, invstd, running-stat update
 // (nn.BatchNorm3d: momentum update with the unbiased variance)
+// per-channel tail of the two-pass statistics: s1 = sum d, s2 = sum d^2 with d = x - mean.  Every product and sum is rounded
+// on its own (no contraction): the two kernels that call this (bn_finalize_kernel, bn_final_finalize_kernel) give the same
+// bits whatever the compiler would have fused in either.
+__device__ __forceinline__ float bn_finalize_channel(float s1, float s2, float cnt, float mean, float eps, float momentum,
+                                                     float* invstd, float* running_mean, float* running_var) {
+#pragma clang fp contract(off)  // (HIP's __fmul_rn / __fadd_rn are plain operators: they do not stop the contraction)
+  const float dm = s1 / cnt;
+  float var = s2 / cnt - dm * dm;
+  var = var > 0.f ? var : 0.f;
+  *invstd = rsqrtf(var + eps);
+  if (running_mean) {
+    const float unb = var * (cnt / fmaxf(cnt - 1.f, 1.f));
+    const float keep = 1.f - momentum;
+    *running_mean = keep * *running_mean + momentum * mean;
+    *running_var = keep * *running_var + momentum * unb;
+  }
+  return var;
+}
+
 __global__ void bn_finalize_kernel(const float* __restrict__ sums2, const float* count_dev, float count_host,
                                    const float* __restrict__ mean, float eps, float momentum, float* invstd,
                                    float* var_out, float* running_mean, float* running_var, int C) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
   const float cnt = count_dev ? *count_dev : count_host;
-  const float dm = sums2[c] / cnt;
-  float var = sums2[C + c] / cnt - dm * dm;
-  var = var > 0.f ? var : 0.f;
-  invstd[c] = rsqrtf(var + eps);
+  const float var = bn_finalize_channel(sums2[c], sums2[C + c], cnt, mean[c], eps, momentum, invstd + c,
+                                        running_mean ? running_mean + c : nullptr, running_var ? running_var + c : nullptr);
   if (var_out) var_out[c] = var;
-  if (running_mean) {
-    const float unb = var * (cnt / fmaxf(cnt - 1.f, 1.f));
-    running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean[c];
-    running_var[c] = (1.f - momentum) * running_var[c] + momentum * unb;
-  }
 }
 
 template <class T>
@@ -706,6 +718,14 @@ __global__ __launch_bounds__(256) void bn_reduce_v4_kernel(typename T::elem* dy,
   const int groups = C >> 2, lanes = 256 / groups;
   const int g = threadIdx.x % groups, vl = threadIdx.x / groups;
   float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
+  if (!BWD && gridDim.y > 1) {
+    // statistics of several BATCH GROUPS in one launch (wsr_bn_train_stats: D(real) and D(fake) of an iteration keep their
+    // own statistics): group blockIdx.y owns voxels [y * nvox, (y + 1) * nvox), row 2C + C.. of the shift table, and the
+    // partial rows [y * gridDim.x, ...)
+    x += (long)blockIdx.y * nvox * C;
+    if (mean_or_shift) mean_or_shift += (long)blockIdx.y * 2 * C;
+    part += (long)blockIdx.y * gridDim.x * 2 * C;
+  }
   if (vl < lanes) {
     float4 mu = make_float4(0.f, 0.f, 0.f, 0.f), is = make_float4(1.f, 1.f, 1.f, 1.f);
     if (mean_or_shift) mu = *reinterpret_cast<const float4*>(mean_or_shift + 4 * g);
@@ -1005,6 +1025,92 @@ extern "C" int wsr_ragan_loss(const float* u, const float* v, const float* lu, c
   if (!u || !v || !lu || !lv || !out || B < 1 || B > 65536) return WSR_EINVAL;
   hipLaunchKernelGGL(ragan_loss_kernel, dim3(1), dim3(256), 0, as_stream(stream), u, v, lu, lv, mu, mv, (int)B, out);
   WSR_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---- train-mode BatchNorm statistics of all batch groups of a layer in four launches (wsr_bn_train_stats) -------------
+// The column sums of `rows` partial rows in chan_sum_final_kernel's order (bit-identical to the two-launch form).
+namespace {
+__device__ __forceinline__ float bn_rows_sum(const float* __restrict__ part, int rows, int C2, float* sh) {
+  const int lanes = 1024 / C2;
+  const int c = threadIdx.x % C2, rl = threadIdx.x / C2;
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  if (rl < lanes) {
+    int r = rl;
+    for (; r + 3 * lanes < rows; r += 4 * lanes) {
+      a0 += part[(long)r * C2 + c];
+      a1 += part[(long)(r + lanes) * C2 + c];
+      a2 += part[(long)(r + 2 * lanes) * C2 + c];
+      a3 += part[(long)(r + 3 * lanes) * C2 + c];
+    }
+    for (; r < rows; r += lanes) a0 += part[(long)r * C2 + c];
+  }
+  __syncthreads();  // (sh is reused between calls)
+  sh[threadIdx.x] = (a0 + a1) + (a2 + a3);
+  __syncthreads();
+  float a = 0.f;
+  if (rl == 0) {
+    a = sh[c];
+    for (int l = 1; l < lanes; ++l) a += sh[l * C2 + c];
+  }
+  return a;  // valid for threads with rl == 0: column c
+}
+
+// pass 1 tail: mean of group blockIdx.x -> work[g][0 .. C)
+__global__ __launch_bounds__(1024) void bn_final_mean_kernel(const float* __restrict__ part, int rows, int C, float cnt,
+                                                            float* __restrict__ work) {
+  __shared__ float sh[1024];
+  const int g = blockIdx.x;
+  const float a = bn_rows_sum(part + (long)g * rows * 2 * C, rows, 2 * C, sh);
+  if (threadIdx.x < C) work[(long)g * 2 * C + threadIdx.x] = a / cnt;  // (threads < 2C hold rl == 0; columns < C are sum d)
+}
+
+// pass 2 tail: one workgroup, the groups IN ORDER (each is a call of its own to the running statistics)
+__global__ __launch_bounds__(1024) void bn_final_finalize_kernel(const float* __restrict__ part, int rows, int C, int groups,
+                                                                float cnt, float eps, float momentum, float* __restrict__ work,
+                                                                float* running_mean, float* running_var) {
+  __shared__ float sh[1024];
+  __shared__ float col[1024];
+  for (int g = 0; g < groups; ++g) {
+    const float a = bn_rows_sum(part + (long)g * rows * 2 * C, rows, 2 * C, sh);
+    if (threadIdx.x < 2 * C) col[threadIdx.x] = a;
+    __syncthreads();
+    if (threadIdx.x < C) {
+      const int c = threadIdx.x;
+      float* wg = work + (long)g * 2 * C;
+      bn_finalize_channel(col[c], col[C + c], cnt, wg[c], eps, momentum, wg + C + c, running_mean ? running_mean + c : nullptr,
+                          running_var ? running_var + c : nullptr);
+    }
+    __syncthreads();
+  }
+}
+}  // namespace
+
+extern "C" int wsr_bn_train_stats(const void* x, int32_t C, int64_t nvox_g, int32_t groups, float eps, float momentum,
+                                  float* work, float* running_mean, float* running_var, float* partials, int32_t dtype,
+                                  void* stream) {
+  if (!x || !work || !partials || C <= 0 || C % 4 || C > 512 || nvox_g <= 0 || groups < 1 || groups > 64) return WSR_EINVAL;
+  if ((running_mean == nullptr) != (running_var == nullptr)) return WSR_EINVAL;
+  const int grid = bn_v4_grid(C, nvox_g);  // (<= WSR_CHAN_SUM_ROWS rows PER GROUP: the per-group launches' partition, same bits)
+  auto kb = bn_reduce_v4_kernel<BF16, false>;
+  auto kf = bn_reduce_v4_kernel<F32, false>;
+  hipStream_t st = as_stream(stream);
+  const float cnt = (float)nvox_g;
+  for (int pass = 0; pass < 2; ++pass) {
+    const float* shift = pass ? work : nullptr;  // pass 2: d = x - mean of the group (work[g][0 .. C), row stride 2C)
+    DISPATCH_T(dtype,
+               hipLaunchKernelGGL(kb, dim3(grid, groups), dim3(256), 0, st, (unsigned short*)nullptr, (const unsigned short*)nullptr,
+                                  (const unsigned short*)x, shift, (const float*)nullptr, C, (long)nvox_g, 0, 0.f, partials),
+               hipLaunchKernelGGL(kf, dim3(grid, groups), dim3(256), 0, st, (float*)nullptr, (const float*)nullptr,
+                                  (const float*)x, shift, (const float*)nullptr, C, (long)nvox_g, 0, 0.f, partials));
+    WSR_LAUNCH_CHECK();
+    if (pass == 0)
+      hipLaunchKernelGGL(bn_final_mean_kernel, dim3(groups), dim3(1024), 0, st, partials, grid, C, cnt, work);
+    else
+      hipLaunchKernelGGL(bn_final_finalize_kernel, dim3(1), dim3(1024), 0, st, partials, grid, C, groups, cnt, eps, momentum,
+                         work, running_mean, running_var);
+    WSR_LAUNCH_CHECK();
+  }
   return 0;
 }
 

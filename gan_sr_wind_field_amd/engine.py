@@ -42,6 +42,9 @@ STACK_FWD = __import__("os").environ.get("WSR_STACK_FWD", "1") != "0"
 #: stages (step 88.8 vs 87.6 ms, profiles/r06_g_ab_fwd_regroup.txt): prologue and epilogue grow with the produced width (a 96-wide
 #: epilogue re-reads and re-writes three windows of partial sums) and eat what the wider K-steps save.
 FWD_REGROUP = __import__("os").environ.get("WSR_FWD_REGROUP", "0") == "1"
+#: train-mode BatchNorm statistics of all batch groups of a discriminator layer in four launches (wsr_bn_train_stats, round 6;
+#: WSR_FUSED_BN_STATS=0: six launches per group); single-process runs only - SyncBN has its collective between the passes
+FUSED_BN_STATS = __import__("os").environ.get("WSR_FUSED_BN_STATS", "1") != "0"
 #: keep the running gradient of a dense block's output in channels [0, nf) of the dense gradient buffer
 #: (WSR_GD_INPLACE=0: separate tensor + one add per block)
 GD_INPLACE = __import__("os").environ.get("WSR_GD_INPLACE", "1") != "0"
@@ -1846,6 +1849,25 @@ class DiscriminatorProgram(ProgramBase):
             # a data-parallel run synchronises all groups of a layer with one collective.
             st = torch.empty((G, 4 * C_), dtype=torch.float32, device=x.device)  # (bn_stats overwrites; rows 16-B aligned)
             work = torch.empty((G, 2 * C_), dtype=torch.float32, device=x.device)
+            track = bn.track_running_stats
+            if (FUSED_BN_STATS and self.stat_allgather is None and (not track or bn.momentum is not None) and y.is_contiguous()
+                    and y.shape[0] == G * Bg
+                    and ops.bn_train_stats(y, G, work, bn.eps, float(bn.momentum) if track else 0.0,
+                                           bn.running_mean if track else None, bn.running_var if track else None)):
+                # all groups of the layer in four launches (both passes, the per-channel tails and the running-statistics
+                # updates in call order: wsr_bn_train_stats) instead of six per group
+                for gi in range(G):
+                    yg, ag = y[gi * Bg:(gi + 1) * Bg], a[gi * Bg:(gi + 1) * Bg]
+                    mean, invstd = work[gi, :C_], work[gi, C_:]
+                    if track:
+                        nbt.setdefault(id(bn.num_batches_tracked), [bn.num_batches_tracked, 0])[1] += 1
+                    ops.bn_apply_lrelu(yg, ag, mean, invstd, bn.weight.detach(), bn.bias.detach(), l.act, sl)
+                    means.append(mean)
+                    invstds.append(invstd)
+                    counts.append(count)
+                recs.append(dict(inp=h, y=y, a=a, mean=means, invstd=invstds, count=counts, training=True, groups=G))
+                h = a
+                continue
             for gi in range(G):
                 yg = y[gi * Bg:(gi + 1) * Bg]
                 ops.bn_stats(yg, st[gi, :2 * C_])

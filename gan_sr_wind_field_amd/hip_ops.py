@@ -808,6 +808,30 @@ def bn_stats(x: Tensor, sums: Tensor, shift: Optional[Tensor] = None) -> None:
                                   _stream()), "bn_stats")
 
 
+_bn_group_ws: dict = {}
+
+
+def bn_train_stats(x: Tensor, groups: int, work: Tensor, eps: float, momentum: float, running_mean: Optional[Tensor],
+                   running_var: Optional[Tensor]) -> bool:
+    """Train-mode BatchNorm statistics of ``groups`` equal batch groups of ``x`` (NDHWC) in four launches
+    (``wsr_bn_train_stats``): ``work[g] = (mean | invstd)`` of group g; the running statistics are updated once per group,
+    in order.  False: shape outside the vectorised kernels (the caller runs the per-group ops)."""
+    _need_cuda(x, work, running_mean, running_var)
+    C_ = x.shape[-1]
+    if C_ % 4 or C_ > 512 or x.shape[0] % groups or not x.is_contiguous() or groups > 64:
+        return False
+    if work.dtype != torch.float32 or tuple(work.shape) != (groups, 2 * C_) or not work.is_contiguous():
+        raise ValueError("bn_train_stats wants a contiguous fp32 (groups, 2C) work buffer")
+    nvox_g = x.numel() // C_ // groups
+    key = (x.device, groups)
+    ws = _bn_group_ws.get(key)
+    if ws is None or ws.numel() < groups * CHAN_SUM_ROWS * 2 * C_:
+        ws = _bn_group_ws[key] = torch.empty(groups * CHAN_SUM_ROWS * 2 * max(C_, 128), dtype=torch.float32, device=x.device)
+    check(_lib.lib().wsr_bn_train_stats(_p(x), C_, nvox_g, groups, eps, momentum, _p(work), _p(running_mean), _p(running_var),
+                                        _p(ws), dtype_id(x.dtype), _stream()), "bn_train_stats")
+    return True
+
+
 def bn_mean(sums: Tensor, mean: Tensor, count: float, count_dev: Optional[Tensor] = None) -> None:
     check(_lib.lib().wsr_bn_mean(_p(sums), _p(count_dev), float(count), _p(mean), mean.numel(), _stream()), "bn_mean")
 

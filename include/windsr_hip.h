@@ -463,6 +463,16 @@ typedef struct wsr_adam_job {
 int wsr_adam_multi(const wsr_adam_job_t* jobs_dev, int32_t n_jobs, double lr, double beta1, double beta2, double eps,
                    double weight_decay, int32_t step, void* stream);
 
+/* ABI 9 - train-mode statistics of ALL batch groups of a BatchNorm3d layer (torch_blocks.py:20-25; the groups are the
+ * reference's separate calls D(real), D(fake) of one iteration, wind_field_GAN_3D.py:247-304, batched into one pass) in four
+ * launches: what wsr_bn_stats + wsr_bn_mean + wsr_bn_stats(shift = mean) + wsr_bn_finalize compute per group in twelve,
+ * bit for bit.  x: `groups` consecutive blocks of nvox_g voxels x C channels (NDHWC).  work: [groups][2C] floats out - mean
+ * | 1 / sqrt(biased var + eps) of each group.  running_mean / running_var (NULL: untouched) are updated once per group, in
+ * group order, as the groups' separate calls would (momentum; unbiased variance).  partials: caller-owned scratch of
+ * groups * WSR_CHAN_SUM_ROWS * 2C floats.  C a multiple of 4, <= 512; 1 <= groups <= 64.                          */
+int wsr_bn_train_stats(const void* x, int32_t C, int64_t nvox_g, int32_t groups, float eps, float momentum, float* work,
+                       float* running_mean, float* running_var, float* partials, int32_t dtype, void* stream);
+
 /* ---- relativistic average GAN loss -------------------------------------------
  * ABI 9 - the adversarial term of a generator iteration (wind_field_GAN_3D.py:360-364) and the loss of a
  * discriminator iteration (:552-556), both of the form

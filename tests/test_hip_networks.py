@@ -278,6 +278,41 @@ def test_discriminator_pair_equals_two_calls(hip, dt, mode):
         assert rel_l2(b2.grad, b1.grad) < (2e-5 if dt == torch.float32 else 2e-3)
 
 
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16], ids=["fp32", "bf16"])
+def test_fused_batchnorm_statistics_are_bit_identical(hip, dt, monkeypatch):
+    """Round 6: the train-mode BatchNorm statistics of both batch groups of a discriminator layer in four launches
+    (``wsr_bn_train_stats``, engine.FUSED_BN_STATS) against the six-launches-per-group form (``wsr_bn_stats`` / ``_mean`` /
+    ``_stats`` / ``_finalize``): logits, running statistics (two updates per layer, in call order: reference
+    torch_blocks.py:20-25 called twice, wind_field_GAN_3D.py:247-304) and every parameter gradient - bit for bit."""
+    import copy
+    from gan_sr_wind_field_amd import engine
+
+    spec = onets.DSpec(bf=8, nz=4, enable_slicing=True)
+    D1, _ = build_D(spec, dt, 23)
+    D2 = copy.deepcopy(D1)
+    D2.features.compute_dtype = D1.features.compute_dtype
+    gen = torch.Generator().manual_seed(9)
+    a = (torch.rand((2, 3, 64, 64, 4), generator=gen) * 2 - 1).to(DEV)
+    b = (torch.rand((2, 3, 64, 64, 4), generator=gen) * 2 - 1).to(DEV)
+    wgt = torch.tensor([[1.0], [-0.5]], device=DEV)
+    outs = []
+    for D, fused in ((D1, True), (D2, False)):
+        monkeypatch.setattr(engine, "FUSED_BN_STATS", fused)
+        D.train()
+        pa, pb = D.forward_pair(a, b)
+        ((pa - pb.mean()) * wgt).sum().backward()
+        ya = D(a)  # a single-group call as well (the generator iteration's D(real) when the pair is off)
+        outs.append((pa.detach().clone(), pb.detach().clone(), ya.detach().clone()))
+    for u, v in zip(outs[0], outs[1]):
+        assert torch.equal(u, v)
+    for (k, p1), (_, p2) in zip(D1.named_parameters(), D2.named_parameters()):
+        assert torch.equal(p1.grad, p2.grad), k
+    for (k, v1), (_, v2) in zip(D1.state_dict().items(), D2.state_dict().items()):
+        assert torch.equal(v1, v2), k
+        if "num_batches" in k:
+            assert int(v1) == 3, k
+
+
 def test_discriminator_pair_keeps_the_order_of_random_draws(hip):
     """Dropout3d masks and the second input's instance noise are drawn in the order of two consecutive calls
     (first mask, noise, second mask): same seed -> same logits as D(a), D(b + noise())."""
