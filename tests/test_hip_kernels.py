@@ -755,6 +755,23 @@ def test_conv_tile_shapes_fp32_vs_cpu(hip, name, cin, cout, k, xyz, B, ups):
 
 
 @pytest.mark.parametrize("name,cin,cout,k,xyz,B,ups", [
+    # z extents that leave the x-y tile budget no power of two (512 / 10 = 51) on volumes no square tile suits: the picker
+    # takes the split with the fewest tiles among candidates INSIDE the 8-bit coordinate fields of the tile tables, no wider
+    # than the volume and with a halo at most 1.3 x the most nearly square tile's (conv_tile_impl.h pick_tile, round 6)
+    ("needle_x", 32, 32, (3, 3, 3), (300, 3, 10), 1, False),    # long along x: a 51 x 1 tile would be the "fewest tiles"
+    ("needle_y", 32, 32, (3, 3, 3), (2, 290, 10), 1, False),    # long along y, beyond 255 voxels
+    ("thin_slab", 128, 128, (3, 3, 3), (70, 5, 10), 1, False),  # the 128-wide tile on a 5-voxel-wide slab
+    ("k5_needle", 144, 144, (5, 5, 5), (40, 3, 10), 1, False),  # 5x5x5 halo on a 3-voxel-wide volume
+])
+def test_conv_tile_long_thin_volumes(hip, monkeypatch, name, cin, cout, k, xyz, B, ups):
+    """the halo-tile kernels on long thin 10-level volumes (tile coordinates are packed in 8 bits per axis: a needle-shaped
+    tile through such a volume must not wrap them), against the CPU conv; WSR_CT_NOSMALL keeps them on the 512-voxel tiles"""
+    monkeypatch.setenv("WSR_CT_NOSMALL", "1")
+    reload_wsr_env()
+    _check_tile_conv(name, cin, cout, k, xyz, B, ups)
+
+
+@pytest.mark.parametrize("name,cin,cout,k,xyz,B,ups", [
     # the tile geometry of the benchmarked 128-level workloads (conv_tile_impl.h pick_tile: 4 x 8 x 16 voxels,
     # several z tiles); WSR_CT_NOSMALL keeps these small volumes on the kernels the full-size volumes take
     ("hr0_prod", 144, 144, (5, 5, 5), (12, 16, 32), 1, False),   # <8,1,4,9>: one activation buffer, 9 chunks
