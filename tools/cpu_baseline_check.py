@@ -9,7 +9,7 @@ the reference.
     python tools/cpu_baseline_check.py [threads] [C1|C1b] > profiles/r03_cpu_baseline_check.txt
 
 ``C1b`` is the reference's real patch size (LR 32x32x10 -> HR 128x128x10, D without slicing) - four times
-the generator work of C1 per pair; three timed pairs instead of five.
+the generator work of C1 per pair; three timed pairs instead of nine.
 """
 import os
 import sys
@@ -33,7 +33,7 @@ def one_pair(step, i):
 def main():
     threads = int(sys.argv[1]) if len(sys.argv) > 1 else (os.cpu_count() or 1)
     shape = sys.argv[2] if len(sys.argv) > 2 else "C1"
-    n_lr, slicing, reps = {"C1": (16, True, 5), "C1b": (32, False, 3)}[shape]
+    n_lr, slicing, reps = {"C1": (16, True, 9), "C1b": (32, False, 3)}[shape]
     torch.set_num_threads(threads)
     from oracle import gan as ogan
     from oracle import nets as onets
