@@ -873,7 +873,15 @@ int launch_ct(CtArgs& a, hipStream_t st) {
   // that (16.0 / 24.9 / 34.3): the diet is taken from two rounds of workgroups on (WSR_CT_DIET=0 / 1 forces it).
   const long nwg_all = (long)a.B * ((a.Xo + a.TX - 1) / a.TX) * ((a.Yo + a.TY - 1) / a.TY) * ((a.Zo + a.TZ - 1) / a.TZ) *
                        ((a.Cout + 16 * NTW - 1) / (16 * NTW)) * (a.nphase == 4 ? 4 : 1);
-  const bool diet = NTW <= 2 && WAVES == 8 && a.nchunks > 1 && WSR_ENV_INT("WSR_CT_DIET", nwg_all >= 512 ? 1 : 0);
+  // (only where it was measured - the trunk's SIMPLE 32-wide instantiations - and only when half the LDS still holds one
+  // activation buffer and weight stages of >= 3 K-steps: a strided 32-wide conv of the discriminator, whose 105 KB halo image
+  // does not fit, would otherwise have been turned away to smaller tiles)
+  bool diet = SIMPLE == 1 && NTW <= 2 && WAVES == 8 && a.nchunks > 1 && WSR_ENV_INT("WSR_CT_DIET", nwg_all >= 512 ? 1 : 0);
+  if (diet) {
+    const int room = 80 * 1024 - (a.off_xs + (VM ? 1 : PL) * a.P);
+    const int ts_diet = room / (2 * NTW * 1024);
+    if (ts_diet < 3 && ts_diet < a.nts) diet = false;
+  }
   const int lds_cap = diet ? 80 * 1024 : 160 * 1024;
   for (a.xbufs = xb_first; a.xbufs >= 1; --a.xbufs) {
     a.off_ws = a.off_xs + a.xbufs * (VM ? 1 : PL) * a.P;
